@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE implementation (build container only).
+
+Imports /root/reference/tulip/model/tulip.py with the two import stubs of SURVEY.md Appendix B
+(neither touches hot-path arithmetic), runs it on key-seeded weights / seeded inputs, asserts the
+oracle (oracle/tulip_oracle.py) reproduces it, and stores inputs-by-seed + expected outputs as
+plain arrays.  Nothing from /root/reference is written into the repo: fixtures are data only.
+
+Usage:  python tests/golden/make_golden.py            (needs /root/reference; ~1-2 min on 8 cores)
+"""
+import json
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import tulip_oracle as O  # noqa: E402
+
+REF = "/root/reference/tulip"
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not mounted; fixtures can only be regenerated in the build container")
+    timm = types.ModuleType("timm")
+    timm_models = types.ModuleType("timm.models")
+    timm_layers = types.ModuleType("timm.models.layers")
+
+    class _DP(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    timm_layers.DropPath = _DP
+    timm_layers.to_2tuple = lambda v: (v, v) if not isinstance(v, (tuple, list)) else tuple(v)
+    timm_layers.trunc_normal_ = nn.init.trunc_normal_
+    sys.modules.update({"timm": timm, "timm.models": timm_models, "timm.models.layers": timm_layers})
+    cd = types.ModuleType("chamfer_distance")
+    cd.ChamferDistance = object
+    sys.modules["chamfer_distance"] = cd
+    sys.path.insert(0, REF)
+    import model.tulip as T  # noqa
+    return T
+
+
+def ref_model(T, cfg: O.TulipConfig, drop_path_rate: float):
+    m = T.TULIP(img_size=cfg.img_size, target_img_size=cfg.target_img_size, patch_size=cfg.patch_size,
+                in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, window_size=list(cfg.window_size),
+                depths=cfg.depths, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+                drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=drop_path_rate,
+                norm_layer=partial(nn.LayerNorm, eps=cfg.ln_eps), pixel_shuffle=cfg.pixel_shuffle,
+                circular_padding=cfg.circular_padding, log_transform=cfg.log_transform,
+                patch_unmerging=cfg.patch_unmerging)
+    return m
+
+
+def sub(t: torch.Tensor, stride: int = 257) -> np.ndarray:
+    return t.detach().reshape(-1)[::stride].numpy().copy()
+
+
+def check(name, a, b, tol):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-30
+    print(f"  {name:48s} max|d|={err:.3e}  rel={err / ref:.3e}")
+    assert err <= tol * max(1.0, ref), f"{name}: oracle != reference ({err} > {tol})"
+    return err
+
+
+# ------------------------------------------------------------------ G1: index ops (bit exact)
+def golden_index(T):
+    from einops import rearrange
+    out = {}
+    wa = T.WindowAttention(dim=96, window_size=[2, 8], num_heads=3, shift=False)
+    out["rel_pos_index_2x8"] = wa.relative_position_index.numpy().copy()
+    assert np.array_equal(out["rel_pos_index_2x8"], O.relative_position_index(2, 8))
+    grids = [(8, 64), (4, 32), (16, 256), (2, 32), (1, 32), (32, 512)]
+    for (H, W) in grids:
+        for shift in (False, True):
+            a = T.WindowAttention(dim=96, window_size=[2, 8], num_heads=3, shift=shift)
+            ids = torch.arange(H * W, dtype=torch.float32).reshape(1, H, W, 1)
+            # replay the reference's own index manipulations on a token-id image
+            if H < a.window_size[0]:
+                a.window_size = a.backup_window_size
+                if a.shift:
+                    a.shift_size = a.backup_shift_size
+            x = ids
+            if a.shift:
+                x = torch.roll(x, shifts=(-a.shift_size[0], -a.shift_size[1]), dims=(1, 2))
+                mask = a.create_mask(x).numpy().copy()
+            else:
+                mask = None
+            part = a.window_partition(x)
+            tok = part.reshape(part.shape[0], -1).long().numpy().copy()
+            win, sft = O.effective_window(H, (2, 8), shift)
+            assert win == tuple(a.window_size)
+            mine = O.window_token_index(H, W, win, sft)
+            assert np.array_equal(tok, mine), (H, W, shift)
+            tag = f"{H}x{W}_{'s' if shift else 'n'}"
+            out[f"win_tok_{tag}"] = tok.astype(np.int32)
+            # inverse: partition -> reverse -> unroll must give identity
+            back = rearrange(part, '(B Nh Nw) Mh Mw C -> B (Nh Mh) (Nw Mw) C', Nh=H // win[0], Nw=W // win[1])
+            if a.shift_size != 0:
+                back = torch.roll(back, shifts=(a.shift_size[0], a.shift_size[1]), dims=(1, 2))
+            assert torch.equal(back, ids)
+            if mask is not None:
+                mm = O.shift_attention_mask(H, W, win, sft)
+                assert np.array_equal(mask, mm), (H, W)
+                out[f"mask_{tag}"] = (mask != 0).astype(np.uint8)
+                lab = O.shift_region_labels(H, W, win, sft)
+                out[f"labels_{tag}"] = lab.astype(np.uint8)
+    # patch merging gather order (tulip.py:92-99) on a token-id image
+    for (H, W) in [(4, 8), (16, 256)]:
+        ids = torch.arange(H * W, dtype=torch.float32).reshape(1, H, W, 1)
+        g = T.PatchMerging.merging(ids).reshape(-1, 4).long().numpy()
+        assert np.array_equal(g, O.patch_merge_gather_index(H, W))
+        out[f"merge_gather_{H}x{W}"] = g.astype(np.int32)
+    # pixel shuffle permutation for r=2,4
+    for r in (2, 4):
+        C, H, W = 3, 2, 3
+        ids = torch.arange(C * r * r * H * W, dtype=torch.float32).reshape(1, C * r * r, H, W)
+        ps = nn.PixelShuffle(r)(ids)
+        mine = torch.empty_like(ps)
+        for c in range(C):
+            for i in range(r):
+                for j in range(r):
+                    mine[0, c, i::r, j::r] = ids[0, O.pixel_shuffle_source_channel(c, i, j, r)]
+        assert torch.equal(ps, mine)
+        out[f"pixel_shuffle_r{r}"] = ps.long().numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "g1_index.npz"), **out)
+    print(f"G1 index fixtures: {len(out)} arrays")
+
+
+# ------------------------------------------------------------------ whole-model fixtures
+def golden_model(T, name, cfg: O.TulipConfig, batch, seed, with_grads, drop_path=False, bf16_ref=True):
+    print(f"== {name}")
+    sd = O.key_seeded_state_dict(cfg, seed=seed)
+    lo, hi = O.synthetic_batch(cfg, batch, seed=1234 + seed)
+    m = ref_model(T, cfg, drop_path_rate=cfg.drop_path_rate if drop_path else 0.0)
+    ref_sd = m.state_dict()
+    spec = O.state_dict_spec(cfg)
+    assert list(ref_sd.keys()) == list(spec.keys()), "state_dict key order/name mismatch"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == spec[k][0], (k, v.shape, spec[k][0])
+    m.load_state_dict(sd, strict=True)
+    out = {"n_params": np.int64(sum(p.numel() for p in m.parameters()))}
+    meta = {"name": name, "batch": batch, "seed": seed, "cfg": cfg.__dict__, "drop_path": drop_path}
+
+    drop_u = None
+    if drop_path:
+        m.train()
+        torch.manual_seed(4321)
+        enc, dec = O.drop_path_rates(cfg)
+        # reference draws torch.rand((B,1,1,1)) twice per block with rate>0, in execution order
+        g = torch.Generator().manual_seed(4321)
+        drop_u = {}
+        order = [(f"layers.{s}.blocks.{b}", enc[s][b]) for s in range(cfg.num_layers) for b in range(cfg.depths[s])]
+        order += [(f"layers_up.{i}.blocks.{b}", dec[i][b]) for i in range(cfg.num_layers - 1)
+                  for b in range(cfg.depths[cfg.num_layers - i - 2])]
+        for p, rate in order:
+            if rate > 0:
+                drop_u[p] = torch.stack([torch.rand(batch, generator=g), torch.rand(batch, generator=g)])
+        out["drop_u_keys"] = np.array(list(drop_u.keys()))
+        out["drop_u"] = torch.stack([drop_u[k] for k in drop_u]).numpy()
+    else:
+        m.eval()
+
+    if with_grads:
+        m.zero_grad()
+        pred, loss, pix = m(lo, hi)
+        loss.backward()
+        ref_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        opred, oloss, opix, ograds = O.tulip_loss_and_grads(sd, cfg, lo, hi, drop_u=drop_u)
+    else:
+        with torch.no_grad():
+            pred, loss, pix = m(lo, hi)
+            opred, oloss, opix = O.tulip_forward(sd, cfg, lo, hi, drop_u=drop_u)
+        ref_grads = ograds = None
+
+    check("pred", opred, pred, 2e-5)
+    check("loss", oloss, loss, 1e-6)
+    check("pixel_loss", opix, pix, 1e-6)
+    if with_grads:
+        worst = 0.0
+        for k in ref_grads:
+            a, b = ograds[k].double(), ref_grads[k].double()
+            e = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+            worst = max(worst, e)
+            assert e < 2e-3, (k, e)
+        print(f"  grads: {len(ref_grads)} tensors, worst rel-to-max err {worst:.3e}")
+        out["grad_keys"] = np.array(list(ref_grads.keys()))
+        out["grad_l2"] = np.array([ref_grads[k].double().norm().item() for k in ref_grads])
+        out["grad_absmax"] = np.array([ref_grads[k].abs().max().item() for k in ref_grads])
+        for k in ("patch_embed.proj.weight", "layers.0.blocks.1.attn.relative_position_bias_table",
+                  "layers.0.blocks.0.attn.qkv.bias", "decoder_pred.weight", "norm_up.weight",
+                  "layers.0.downsample.reduction.weight", "skip_connection_layers.0.weight",
+                  "first_patch_expanding.expand.bias"):
+            if k in ref_grads:
+                out["grad::" + k] = ref_grads[k].numpy().copy()
+
+    out["loss"] = np.float64(loss.item())
+    out["pixel_loss"] = np.float64(pix.item())
+    if pred.numel() <= 1 << 17:
+        out["pred"] = pred.detach().numpy().copy()
+    out["pred_sub257"] = sub(pred)
+    out["pred_abs_mean"] = np.float64(pred.detach().abs().mean().item())
+
+    # per-stage activation checksums via the oracle taps (already proven equal at the output)
+    taps = {}
+    with torch.no_grad():
+        O.tulip_forward(sd, cfg, lo, hi, drop_u=drop_u, taps=taps)
+    out["tap_keys"] = np.array(list(taps.keys()))
+    out["tap_abs_mean"] = np.array([t.abs().double().mean().item() for t in taps.values()])
+    out["tap_sum"] = np.array([t.double().sum().item() for t in taps.values()])
+
+    if bf16_ref and not drop_path:
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            pb, lb, xb = m(lo, hi)
+        out["autocast_bf16_pred_sub257"] = sub(pb.float())
+        out["autocast_bf16_loss"] = np.float64(lb.item())
+        d = (pb.float() - pred).abs()
+        out["autocast_bf16_vs_fp32_maxabs"] = np.float64(d.max().item())
+        out["autocast_bf16_vs_fp32_meanabs"] = np.float64(d.mean().item())
+        print(f"  reference self-consistency bf16-autocast vs fp32: max {d.max().item():.3e} mean {d.mean().item():.3e}"
+              f"  loss rel {(lb.item() - loss.item()) / loss.item():+.3e}")
+        with torch.no_grad():
+            lp, ll, _ = O.tulip_forward(sd, cfg, lo, hi, lowp=True)
+        d2 = (lp - pred).abs()
+        print(f"  oracle lowp(bf16 operands, fp32 stream) vs fp32: max {d2.max().item():.3e} mean {d2.mean().item():.3e}"
+              f"  loss rel {(ll.item() - loss.item()) / loss.item():+.3e}")
+        out["oracle_lowp_vs_fp32_maxabs"] = np.float64(d2.max().item())
+        out["oracle_lowp_vs_fp32_meanabs"] = np.float64(d2.mean().item())
+
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(meta, f, indent=1, default=list)
+
+
+def golden_lr(T):
+    sys.path.insert(0, REF)
+    import util.lr_sched as L  # dependency-free
+    rows = []
+    for (step_epoch, lr, min_lr, warm, epochs) in [(0.0, 5e-4, 0.0, 60, 600), (0.5, 5e-4, 0.0, 60, 600),
+                                                  (59.99, 5e-4, 0.0, 60, 600), (60.0, 5e-4, 0.0, 60, 600),
+                                                  (300.25, 5e-4, 1e-6, 60, 600), (599.9, 5e-4, 0.0, 60, 600),
+                                                  (3.0, 1e-3, 1e-5, 5, 10)]:
+        args = types.SimpleNamespace(lr=lr, min_lr=min_lr, warmup_epochs=warm, epochs=epochs)
+
+        class Opt:
+            param_groups = [{"lr": 0.0}]
+        got = L.adjust_learning_rate(Opt(), step_epoch, args)
+        mine = O.cosine_lr(step_epoch, lr, min_lr, warm, epochs)
+        assert abs(got - mine) <= 1e-12 * max(1, abs(got)), (got, mine)
+        rows.append([step_epoch, lr, min_lr, warm, epochs, got])
+    np.savez_compressed(os.path.join(HERE, "g_lr_sched.npz"), table=np.array(rows))
+    print("LR schedule fixture:", len(rows), "rows")
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 8)
+    T = import_reference()
+    golden_index(T)
+    golden_lr(T)
+    tiny = O.tiny_config()
+    golden_model(T, "g3_tiny_fp32", tiny, batch=2, seed=0, with_grads=True)
+    golden_model(T, "g3_tiny_droppath", tiny, batch=4, seed=1, with_grads=True, drop_path=True)
+    tiny_nc = O.tiny_config(circular_padding=False)
+    golden_model(T, "g3_tiny_noncircular", tiny_nc, batch=2, seed=2, with_grads=False, bf16_ref=False)
+    golden_model(T, "g4_kitti_base", O.tulip_base_config(), batch=2, seed=0, with_grads=False)
+    large = O.tulip_large_config(img_size=(16, 2048), target_img_size=(64, 2048))
+    golden_model(T, "g5_large_16x2048", large, batch=1, seed=0, with_grads=False, bf16_ref=False)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
