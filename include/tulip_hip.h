@@ -1,0 +1,136 @@
+/* tulip_hip.h -- C ABI of libtulip_hip.so: the MI355X (gfx950) kernels behind the TULIP Swin hot path.
+ *
+ * The reference (ethz-asl/TULIP) is pure Python and defines no FFI; the boundary it exposes for
+ * this path is the nn.Module in tulip/model/tulip.py.  Each entry point below replaces the ATen
+ * op sequence of the cited reference lines (paths relative to the reference repo).  The Python
+ * host (tulip_amd/model/tulip.py) binds them with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every buffer is owned by the caller and lives in device memory.
+ *   - bf16 tensors are uint16_t (raw bits), row-major, innermost dimension contiguous.
+ *   - every call is asynchronous on `stream`, allocates nothing, keeps no global state, performs
+ *     no synchronisation and is legal under HIP-graph capture.
+ *   - return value: 0 on success, TULIP_ERR_ARG (-1) for an unsupported argument combination,
+ *     -(1000 + hipError_t) if the launch failed.  Nothing throws, nothing exits.
+ *   - "stream" tensors (the residual stream) are fp32 (B,H,W,C); GEMM operands are bf16 with
+ *     fp32 accumulation (the autocast contract of engine_upsampling.py:77, bf16 instead of fp16).
+ */
+#ifndef TULIP_HIP_H_
+#define TULIP_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+/* GEMM epilogues */
+#define TULIP_EPI_BF16 0         /* out_bf16 = acc + bias                                             */
+#define TULIP_EPI_GELU_DUAL 1    /* out = bf16(acc+bias) ; out2 = bf16(gelu_erf(out))  (tulip.py:195-196) */
+#define TULIP_EPI_GELU_BWD 2     /* out_bf16 = acc * gelu'(aux_bf16)                                    */
+#define TULIP_EPI_F32 3          /* out_f32 (+)= acc + bias                                             */
+#define TULIP_EPI_RESID_F32 4    /* out_f32 = aux_f32 + rowscale[m/rows_per_sample]*(acc+bias) (tulip.py:343-344,350-351) */
+#define TULIP_EPI_PIXSHUF2_F32 5 /* PatchUnmerging scatter: PixelShuffle(2) + BCHW->BHWC (tulip.py:120-122) */
+#define TULIP_EPI_ATOMIC_F32 6   /* out_f32 += acc (split-K weight gradients)                           */
+
+/* C[M,N] = opA[M,K] . opB[N,K]^T, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+ * a_trans=0: A is [M][lda]; a_trans=1: A is [K][lda] (A^T stored).  Same for B ([N][ldb] / [K][ldb]).
+ * Replaces nn.Linear / 1x1 nn.Conv2d forward (tulip.py:298,318,195,198,105,119,716,175) and their
+ * autograd dgrad/wgrad.  Requirements: K%8==0, N%4==0, lda%8==0, ldb%8==0 (and M%8 / N%8 for the
+ * transposed operands).  splits>1 only with TULIP_EPI_ATOMIC_F32. */
+int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,
+                    int epi, const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
+                    const float* rowscale, int rows_per_sample, int accumulate, int psH, int psW, int splits,
+                    hipStream_t stream);
+
+/* LayerNorm over the last dim of an fp32 stream tensor -> bf16 (the next op is always a GEMM).
+ * merge=0: x is [rows][C].  merge=1 (PatchMerging, tulip.py:92-105): x is (B,H,W,C/4) and row
+ * (b,h',w') is the concat [x(2h',2w'), x(2h'+1,2w'), x(2h',2w'+1), x(2h'+1,2w'+1)]; rows=B*H/2*W/2.
+ * Saves mean/rstd per row for the backward.  Replaces tulip.py:340,347,104,720. */
+int tulip_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* mean, float* rstd,
+                        int rows, int C, float eps, int merge, int B, int H, int W, hipStream_t stream);
+
+/* dx = dres + LayerNorm-backward(dy) in the layout of x (scatter for merge=1).  dres may be NULL
+ * (treated as zero) or alias dx. */
+int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, int rows, int C, int merge, int B, int H, int W,
+                        hipStream_t stream);
+
+/* dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy   (atomic accumulation into fp32) */
+int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, const float* mean, const float* rstd, float* dgamma,
+                               float* dbeta, int rows, int C, int merge, int B, int H, int W, hipStream_t stream);
+
+/* PatchEmbedding (tulip.py:63-73): optional circular W padding by (2,2), Conv2d(Cin->E,(p0,kw),
+ * stride (p0,p1)), BCHW->BHWC, LayerNorm(E).  img (B,Cin,Hin,Win) fp32 -> out (B,Hin/p0,Win/p1,E). */
+int tulip_patch_embed_fwd(const float* img, const float* w, const float* b, const float* gamma, const float* beta,
+                          float* out, int B, int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular,
+                          float eps, hipStream_t stream);
+/* parameter gradients of the above (the input image needs no gradient); accumulates atomically. */
+int tulip_patch_embed_bwd(const float* img, const float* w, const float* b, const float* gamma, const float* dout,
+                          float* dw, float* db, float* dgamma, float* dbeta, int B, int Cin, int Hin, int Win, int E,
+                          int p0, int p1, int kw, int circular, float eps, hipStream_t stream);
+
+/* Shifted-window attention core (tulip.py:289-323 minus the two Linears): cyclic shift, window
+ * partition, q*scale, QK^T, + relative-position bias gathered through rel_index, + shift mask
+ * (0/-100 from region labels, tulip.py:254-280), softmax, PV, window reverse, reverse shift -- all
+ * as address arithmetic on natural-order tokens.  qkv is [B*H*W][3C] with channel order (T,Nh,P)
+ * (tulip.py:298); out is [B*H*W][C] with channel order (Nh,P).  L = wh*ww must be 16; head dim P
+ * in {16,32}.  rel_index is the module's (L,L) relative_position_index buffer as int32.
+ * masked!=0 for shifted blocks. */
+int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_table, const int32_t* rel_index, uint16_t* out, int B,
+                          int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream);
+/* dqkv from dout; d(bias) accumulated densely into dbias_dense[nh][L][L] (fp32, atomic). */
+int tulip_window_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* bias_table, const int32_t* rel_index,
+                          uint16_t* dqkv, float* dbias_dense, int B, int H, int W, int C, int nh, int wh, int ww,
+                          int sh, int sw, int masked, hipStream_t stream);
+/* dtable[rel_index[i][j]][h] += dbias_dense[h][i][j]  (tulip.py:304-308 backward) */
+int tulip_bias_table_scatter(const float* dbias_dense, const int32_t* rel_index, float* dtable, int nh, int L,
+                             hipStream_t stream);
+
+/* y_bf16 = bf16(x * rowscale[row/rows_per_sample]) ; rowscale may be NULL. x is [rows][cols]. */
+int tulip_cast_f32_bf16(const float* x, uint16_t* y, int rows, int cols, const float* rowscale, int rows_per_sample,
+                        hipStream_t stream);
+/* out[r] = bf16(concat(a[r], b[r]))  -- skip connection input, tulip.py:715 */
+int tulip_concat_cast(const float* a, const float* b, uint16_t* out, int rows, int C, hipStream_t stream);
+/* inverse of the PatchUnmerging scatter: dz[(b,h,w)][4c+2i+j] = bf16(dx[b,2h+i,2w+j,c]); dx is (B,2H,2W,C2) */
+int tulip_unshuffle2_cast(const float* dx, uint16_t* dz, int B, int H, int W, int C2, hipStream_t stream);
+/* out[c] += sum_rows x[r][c]   (bias gradients) */
+int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream);
+/* flat fp32 -> bf16 copy (weight shadow refresh) */
+int tulip_cast_flat(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
+
+/* Fused head (tulip.py:724-731): conv1x1 E->16E (+bias), LeakyReLU(0.01), PixelShuffle(4),
+ * conv1x1 E->1 (no bias); xn is norm_up's bf16 output [B*H*W][E]; pred is (B,1,4H,4W) fp32.  The
+ * (B,16E,H,W) intermediate (100 MB at B=8) is never materialised.  upscale factor 4, in_chans 1. */
+int tulip_tail_fwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, float* pred, int B, int H,
+                   int W, int E, hipStream_t stream);
+/* backward of the head w.r.t. the expand pre-activation: dz[B*H*W][16E] (bf16) and dwd[E] (+=). */
+int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
+                   uint16_t* dz, float* dwd, int B, int H, int W, int E, hipStream_t stream);
+
+/* forward_loss (tulip.py:690-700): losses[0]=mean|pred-target|, losses[1]=mean|expm1(pred)-expm1(target)|
+ * (or a copy of losses[0] when log_transform==0).  partials: scratch of 2*1024 floats. Deterministic. */
+int tulip_l1_loss_fwd(const float* pred, const float* target, float* partials, float* losses, int64_t n,
+                      int log_transform, hipStream_t stream);
+/* dpred = gscale * sign(pred-target)/n ; gscale read from device memory if gscale_dev!=NULL */
+int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscale_dev, float gscale, float* dpred,
+                      int64_t n, hipStream_t stream);
+
+/* Fused AdamW over a flat parameter range (torch.optim.AdamW semantics, main_lidar_upsampling.py:283):
+ * hyper (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}.
+ * Also refreshes the bf16 weight shadow. */
+int tulip_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
+                float wd_mult, hipStream_t stream);
+
+/* library self-description */
+int tulip_abi_version(void);
+const char* tulip_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TULIP_HIP_H_ */

@@ -1,0 +1,361 @@
+"""GPU parity tests, one per C-ABI entry point: the HIP kernel vs an fp32 PyTorch/oracle
+restatement of the same op on identical (bf16-representable) inputs.
+
+Tolerances: index/permutation behaviour is exact by construction (wrong indices give O(1) errors);
+bf16 outputs are checked to ~1 bf16 ulp (rtol 2^-7) plus an absolute floor scaled to the output
+magnitude; fp32 outputs of fp32 math to 1e-5; fp32 outputs of bf16 GEMMs to 1e-3 of the scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tulip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tulip_amd import ops as _ops
+    from tulip_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + int(np.prod(shape)) % 1000)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def close(a, b, rtol, atol_scale, what=""):
+    a, b = a.float(), b.float()
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs()
+    tol = rtol * b.abs() + atol_scale * scale
+    bad = (err > tol)
+    assert not bad.any(), (f"{what}: {bad.sum().item()}/{bad.numel()} out of tolerance; max err "
+                           f"{err.max().item():.4e} (scale {scale:.3e})")
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 96, 96), (200, 144, 48), (512, 2304, 768), (4096, 288, 96), (32, 96, 1536),
+                                   (1024, 48, 192), (64, 4608, 1536)])
+def test_gemm_nt_bias_bf16(ops, M, N, K):
+    A, B, bias = bf(rnd(M, K)), bf(rnd(N, K, scale=0.05)), rnd(N, scale=0.1)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_BF16, bias=bias, out=out)
+    ref = A.float() @ B.float().t() + bias
+    close(out, ref, 2 ** -7, 2e-3, "gemm nt")
+
+
+def test_gemm_gelu_dual_and_bwd(ops):
+    M, N, K = 384, 384, 96
+    A, B, bias = bf(rnd(M, K)), bf(rnd(N, K, scale=0.1)), rnd(N, scale=0.1)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    g = torch.empty_like(h)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_GELU_DUAL, bias=bias, out=h, out2=g, ldo2=N)
+    href = bf(A.float() @ B.float().t() + bias)
+    close(h, href.float(), 2 ** -7, 2e-3, "gelu h")
+    close(g, F.gelu(h.float()), 2 ** -7, 2e-3, "gelu g")     # gelu of the *stored* h
+    # backward epilogue: out = acc * gelu'(h)
+    dY = bf(rnd(M, K, seed=3))
+    W2 = bf(rnd(K, N, scale=0.1, seed=4))                     # fc2 weight [out=K][in=N]
+    dh = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dY, W2, M, N, K, lda=K, ldb=N, b_trans=True, epi=ops.EPI_GELU_BWD, out=dh, aux=h, ldaux=N)
+    hh = h.float().requires_grad_(True)
+    F.gelu(hh).backward(dY.float() @ W2.float())
+    close(dh, hh.grad, 2 ** -6, 3e-3, "gelu bwd")
+
+
+def test_gemm_f32_resid_rowscale_accumulate(ops):
+    M, N, K, rps = 256, 96, 384, 64
+    A, B, bias = bf(rnd(M, K)), bf(rnd(N, K, scale=0.05)), rnd(N, scale=0.1)
+    resid = rnd(M, N, seed=5)
+    rs = torch.tensor([0.0, 1.25, 1.0, 1.25], device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_RESID_F32, bias=bias, out=out, aux=resid, ldaux=N,
+             rowscale=rs, rows_per_sample=rps)
+    ref = resid + rs.repeat_interleave(rps)[:, None] * (A.float() @ B.float().t() + bias)
+    close(out, ref, 1e-5, 1e-4, "resid")
+    assert torch.equal(out[:rps], resid[:rps])               # dropped sample: exact pass-through
+    out2 = resid.clone()
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_F32, out=out2, accumulate=True)
+    close(out2, resid + A.float() @ B.float().t(), 1e-5, 1e-4, "f32 accumulate")
+
+
+def test_gemm_pixshuf2(ops):
+    Bn, H, W, C = 2, 4, 8, 96
+    M, N = Bn * H * W, 2 * C
+    A, Wt, bias = bf(rnd(M, C)), bf(rnd(N, C, scale=0.05)), rnd(N, scale=0.1)
+    out = torch.empty(Bn, 2 * H, 2 * W, C // 2, device=DEV)
+    ops.gemm(A, Wt, M, N, C, lda=C, ldb=C, epi=ops.EPI_PIXSHUF2_F32, bias=bias, out=out, psH=H, psW=W)
+    z = (A.float() @ Wt.float().t() + bias).reshape(Bn, H, W, N).permute(0, 3, 1, 2)
+    ref = F.pixel_shuffle(z, 2).permute(0, 2, 3, 1)
+    close(out, ref, 1e-5, 1e-4, "pixshuf2")
+
+
+@pytest.mark.parametrize("M,Nw,Kw", [(256, 288, 96), (200, 96, 48), (2048, 768, 3072), (32, 1536, 4608)])
+def test_gemm_dgrad_nn(ops, M, Nw, Kw):
+    dY, Wt = bf(rnd(M, Nw)), bf(rnd(Nw, Kw, scale=0.05))
+    dX = torch.empty(M, Kw, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dY, Wt, M, Kw, Nw, lda=Nw, ldb=Kw, b_trans=True, epi=ops.EPI_BF16, out=dX)
+    close(dX, dY.float() @ Wt.float(), 2 ** -7, 2e-3, "dgrad")
+
+
+@pytest.mark.parametrize("M,Nw,Kw,splits", [(256, 288, 96, 1), (4096, 288, 96, 16), (200, 96, 48, 3),
+                                            (512, 2304, 768, 2), (1000, 48, 144, 4)])
+def test_gemm_wgrad_tn_splitk(ops, M, Nw, Kw, splits):
+    if M % 8:
+        pytest.skip("token count is always a multiple of 16")
+    dY, X = bf(rnd(M, Nw)), bf(rnd(M, Kw, seed=7))
+    dW = torch.zeros(Nw, Kw, device=DEV)
+    ops.gemm(dY, X, Nw, Kw, M, lda=Nw, ldb=Kw, a_trans=True, b_trans=True, epi=ops.EPI_ATOMIC_F32, out=dW,
+             splits=splits)
+    close(dW, dY.float().t() @ X.float(), 1e-4, 2e-4, "wgrad")
+
+
+def test_gemm_strided_views(ops):
+    # skip-connection dgrad: two column halves of W through pointer offsets (ldb = 2C)
+    M, C = 128, 96
+    dY, Ws = bf(rnd(M, C)), bf(rnd(C, 2 * C, scale=0.05))
+    d0 = torch.zeros(M, C, device=DEV)
+    d1 = rnd(M, C, seed=9)
+    d1_0 = d1.clone()
+    ops.gemm(dY, Ws, M, C, C, lda=C, ldb=2 * C, b_trans=True, epi=ops.EPI_F32, out=d0)
+    ops.gemm(dY, Ws[:, C:], M, C, C, lda=C, ldb=2 * C, b_trans=True, epi=ops.EPI_F32, out=d1, accumulate=True)
+    full = dY.float() @ Ws.float()
+    close(d0, full[:, :C], 1e-5, 1e-4, "skip d0")
+    close(d1, d1_0 + full[:, C:], 1e-5, 1e-4, "skip d1")
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,C", [(64, 48), (1000, 96), (256, 192), (128, 384), (64, 768), (32, 1536), (16, 6144)])
+def test_layernorm_fwd_bwd(ops, rows, C):
+    x = rnd(rows, C) + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, 1e-6)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    close(y, ref, 2 ** -8, 1e-5, "ln fwd")
+    close(mean, x.mean(-1), 1e-5, 1e-6, "mean")
+    close(rstd, 1 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6), 1e-5, 1e-6, "rstd")
+    dy = bf(rnd(rows, C, seed=3))
+    dres = rnd(rows, C, seed=4)
+    ref.backward(dy.float())
+    dx = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C)
+    close(dx, dres + xr.grad, 1e-4, 1e-5, "ln dx")
+    dx2 = dres.clone()
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, dx2, dx2, rows, C)       # in-place accumulate
+    assert torch.equal(dx, dx2)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.layernorm_bwd_params(dy, x, mean, rstd, dg, db, rows, C)
+    close(dg, gr.grad, 1e-4, 1e-5, "dgamma")
+    close(db, br.grad, 1e-4, 1e-5, "dbeta")
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 4, 8, 48), (1, 16, 64, 96), (2, 2, 32, 384)])
+def test_layernorm_merge(ops, B, H, W, Cin):
+    x = rnd(B, H, W, Cin)
+    C = 4 * Cin
+    rows = B * (H // 2) * (W // 2)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, 1e-6, merge=True, B=B, H=H, W=W)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    cat = torch.cat([xr[:, 0::2, 0::2], xr[:, 1::2, 0::2], xr[:, 0::2, 1::2], xr[:, 1::2, 1::2]], -1)  # tulip.py:94-98
+    ref = F.layer_norm(cat, (C,), gr, br, 1e-6).reshape(rows, C)
+    close(y, ref, 2 ** -8, 1e-5, "merge ln fwd")
+    dy = bf(rnd(rows, C, seed=3))
+    ref.backward(dy.float())
+    dx = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, None, dx, rows, C, merge=True, B=B, H=H, W=W)
+    close(dx, xr.grad, 1e-4, 1e-5, "merge ln dx")
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.layernorm_bwd_params(dy, x, mean, rstd, dg, db, rows, C, merge=True, B=B, H=H, W=W)
+    close(dg, gr.grad, 1e-4, 1e-5, "merge dgamma")
+    close(db, br.grad, 1e-4, 1e-5, "merge dbeta")
+
+
+# ------------------------------------------------------------------ patch embedding
+@pytest.mark.parametrize("circular", [True, False])
+@pytest.mark.parametrize("E,Hin,Win", [(96, 16, 1024), (48, 8, 256)])
+def test_patch_embed(ops, circular, E, Hin, Win):
+    B = 2
+    cfg = O.TulipConfig(img_size=(Hin, Win), embed_dim=E, circular_padding=circular)
+    kw = 8 if circular else 4
+    img = torch.rand(B, 1, Hin, Win, device=DEV)
+    sd = {"patch_embed.proj.weight": (rnd(E, 1, 1, kw, scale=0.3)), "patch_embed.proj.bias": rnd(E, scale=0.1, seed=1),
+          "patch_embed.norm.weight": 1 + 0.1 * rnd(E, seed=2), "patch_embed.norm.bias": 0.1 * rnd(E, seed=3)}
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.patch_embed(O._Prec(False), sdr, cfg, img)
+    out = torch.empty(B, Hin, Win // 4, E, device=DEV)
+    ops.patch_embed_fwd(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], sd["patch_embed.norm.weight"],
+                        sd["patch_embed.norm.bias"], out, B, 1, Hin, Win, E, 1, 4, kw, circular, 1e-6)
+    close(out, ref, 1e-4, 2e-5, "patch embed fwd")
+    dout = rnd(B, Hin, Win // 4, E, seed=5)
+    ref.backward(dout)
+    dw, db = torch.zeros(E, 1, 1, kw, device=DEV), torch.zeros(E, device=DEV)
+    dg, dbe = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+    ops.patch_embed_bwd(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], sd["patch_embed.norm.weight"],
+                        dout, dw, db, dg, dbe, B, 1, Hin, Win, E, 1, 4, kw, circular, 1e-6)
+    close(dw, sdr["patch_embed.proj.weight"].grad, 2e-3, 2e-4, "embed dw")
+    close(db, sdr["patch_embed.proj.bias"].grad, 2e-3, 2e-4, "embed db")
+    close(dg, sdr["patch_embed.norm.weight"].grad, 2e-3, 2e-4, "embed dgamma")
+    close(dbe, sdr["patch_embed.norm.bias"].grad, 2e-3, 2e-4, "embed dbeta")
+
+
+# ------------------------------------------------------------------ window attention
+def attn_reference(qkv, table, rel_index, B, H, W, C, nh, shift):
+    """tulip.py:289-323 minus the Linears, on natural-order tokens, fp32 (P rounded to bf16)."""
+    win, sft = O.effective_window(H, (2, 8), shift)
+    L, P = 16, C // nh
+    idx = torch.from_numpy(O.window_token_index(H, W, win, sft)).to(qkv.device)
+    nW = idx.shape[0]
+    t = qkv.reshape(B, H * W, 3 * C)[:, idx.reshape(-1)].reshape(B * nW, L, 3, nh, P).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    attn = (q @ k.transpose(-2, -1)) * P ** -0.5
+    bias = table[rel_index.reshape(-1).long()].reshape(L, L, nh).permute(2, 0, 1)
+    attn = attn + bias[None]
+    if shift:
+        mask = torch.from_numpy(O.shift_attention_mask(H, W, win, sft)).to(qkv.device)
+        attn = (attn.reshape(B, nW, nh, L, L) + mask[None, :, None]).reshape(B * nW, nh, L, L)
+    p = O._BF16Round.apply(torch.softmax(attn, -1))
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, nW * L, C)
+    out = torch.zeros(B, H * W, C, device=qkv.device, dtype=o.dtype)
+    out[:, idx.reshape(-1)] = o
+    return out.reshape(B * H * W, C)
+
+
+@pytest.mark.parametrize("B,H,W,C,nh", [(2, 8, 64, 48, 3), (2, 4, 32, 96, 6), (1, 16, 256, 96, 3), (2, 2, 32, 768, 24),
+                                        (1, 1, 32, 1536, 48), (3, 4, 64, 384, 12)])
+@pytest.mark.parametrize("shift", [False, True])
+def test_window_attention_fwd_bwd(ops, B, H, W, C, nh, shift):
+    M = B * H * W
+    qkv = bf(rnd(M, 3 * C, scale=1.5))
+    table = rnd(45, nh, scale=0.5, seed=1)
+    rel = torch.from_numpy(O.relative_position_index(2, 8)).to(DEV)
+    rel32 = rel.to(torch.int32).contiguous()
+    win, sft = O.effective_window(H, (2, 8), shift)
+    out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.window_attn_fwd(qkv, table, rel32, out, B, H, W, C, nh, win, sft, shift)
+    qr = qkv.float().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    ref = attn_reference(qr, tr, rel, B, H, W, C, nh, shift)
+    close(out, ref, 2 ** -7, 3e-3, "attn fwd")
+    dout = bf(rnd(M, C, seed=3))
+    ref.backward(dout.float())
+    dqkv = torch.empty_like(qkv)
+    dense = torch.zeros(nh, 16, 16, device=DEV)
+    ops.window_attn_bwd(qkv, dout, table, rel32, dqkv, dense, B, H, W, C, nh, win, sft, shift)
+    close(dqkv, qr.grad, 2 ** -5, 6e-3, "attn dqkv")
+    dtab = torch.zeros(45, nh, device=DEV)
+    ops.bias_table_scatter(dense, rel32, dtab, nh, 16)
+    close(dtab, tr.grad, 2e-2, 5e-3, "attn dtable")
+
+
+# ------------------------------------------------------------------ casts / reductions
+def test_casts_concat_unshuffle_colsum(ops):
+    rows, cols, rps = 96, 192, 32
+    x = rnd(rows, cols)
+    rs = torch.tensor([1.0, 0.0, 1.1111], device=DEV)
+    y = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    ops.cast_f32_bf16(x, y, rows, cols, rs, rps)
+    assert torch.equal(y, bf(x * rs.repeat_interleave(rps)[:, None]))
+    ops.cast_f32_bf16(x, y, rows, cols)
+    assert torch.equal(y, bf(x))
+    a, b = rnd(rows, 96, seed=1), rnd(rows, 96, seed=2)
+    cat = torch.empty(rows, 192, dtype=torch.bfloat16, device=DEV)
+    ops.concat_cast(a, b, cat, rows, 96)
+    assert torch.equal(cat, bf(torch.cat([a, b], -1)))
+    Bn, H, W, C2 = 2, 2, 8, 48
+    dx = rnd(Bn, 2 * H, 2 * W, C2, seed=3)
+    dz = torch.empty(Bn * H * W, 4 * C2, dtype=torch.bfloat16, device=DEV)
+    ops.unshuffle2_cast(dx, dz, Bn, H, W, C2)
+    ref = F.pixel_unshuffle(dx.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(Bn * H * W, 4 * C2)
+    assert torch.equal(dz, bf(ref))
+    for (r, c) in [(1000, 144), (64, 4608), (4096, 96), (33, 8)]:
+        xb = bf(rnd(r, c, seed=4))
+        out = torch.zeros(c, device=DEV)
+        ops.colsum_bf16(xb, out, r, c)
+        close(out, xb.float().sum(0), 1e-4, 1e-5, "colsum")
+    n = 1000003
+    xf = rnd(n, seed=5)
+    yf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ops.cast_flat(xf, yf, n)
+    assert torch.equal(yf, bf(xf))
+
+
+# ------------------------------------------------------------------ fused head
+@pytest.mark.parametrize("B,H,W,E", [(2, 8, 64, 48), (1, 16, 256, 96), (1, 3, 24, 96)])
+def test_tail_fwd_bwd(ops, B, H, W, E):
+    M = B * H * W
+    cfg = O.TulipConfig(img_size=(H, W * 4), target_img_size=(4 * H, 4 * W), embed_dim=E)
+    assert cfg.upscale_factor == 4
+    xn = bf(rnd(M, E))
+    We, be, wd = bf(rnd(16 * E, E, scale=0.1, seed=1)), rnd(16 * E, scale=0.1, seed=2), rnd(E, scale=0.2, seed=3)
+    pred = torch.empty(B, 1, 4 * H, 4 * W, device=DEV)
+    ops.tail_fwd(xn, We, be, wd, pred, B, H, W, E)
+    sd = {"ps_head.conv_expand.0.weight": We.float().reshape(16 * E, E, 1, 1).requires_grad_(True),
+          "ps_head.conv_expand.0.bias": be.clone().requires_grad_(True),
+          "decoder_pred.weight": wd.reshape(1, E, 1, 1).clone().requires_grad_(True)}
+    xr = xn.float().reshape(B, H, W, E).requires_grad_(True)
+    ref = O.ps_head_and_pred(O._Prec(False), sd, cfg, xr)
+    close(pred, ref, 1e-4, 2e-5, "tail fwd")
+    dpred = rnd(B, 1, 4 * H, 4 * W, seed=4)
+    ref.backward(dpred)
+    dz = torch.empty(M, 16 * E, dtype=torch.bfloat16, device=DEV)
+    dwd = torch.zeros(E, device=DEV)
+    ops.tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E)
+    close(dwd, sd["decoder_pred.weight"].grad.reshape(E), 1e-3, 1e-4, "tail dwd")
+    # dz is d(loss)/d(expand pre-activation): check through its three consumers
+    dzf = dz.float()
+    close(dzf.sum(0), sd["ps_head.conv_expand.0.bias"].grad, 2e-2, 4e-3, "tail dbe (colsum dz)")
+    close(dzf @ We.float(), xr.grad.reshape(M, E), 2e-2, 4e-3, "tail dxn (dz.We)")
+    close(dzf.t() @ xn.float(), sd["ps_head.conv_expand.0.weight"].grad.reshape(16 * E, E), 2e-2, 4e-3, "tail dWe")
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("log_transform", [True, False])
+def test_l1_loss(ops, log_transform):
+    n = 2 * 64 * 1024
+    pred, tgt = torch.rand(n, device=DEV), torch.rand(n, device=DEV)
+    tgt[:100] = pred[:100]                                     # exact zeros -> sign(0) = 0
+    cfg = O.TulipConfig(log_transform=log_transform)
+    l, p = O.forward_loss(cfg, pred, tgt)
+    partials = torch.empty(2048, device=DEV)
+    losses = torch.empty(2, device=DEV)
+    ops.l1_loss_fwd(pred, tgt, partials, losses, n, log_transform)
+    assert abs(losses[0].item() - l.item()) <= 2e-6 * l.item()
+    assert abs(losses[1].item() - p.item()) <= 2e-6 * p.item()
+    dp = torch.empty(n, device=DEV)
+    ops.l1_loss_bwd(pred, tgt, None, 2.0, dp, n)
+    assert torch.equal(dp, 2.0 * torch.sign(pred - tgt) / n)
+
+
+# ------------------------------------------------------------------ optimizer
+def test_adamw_matches_torch(ops):
+    n = 4096 * 3
+    p0, g = rnd(n), rnd(n, seed=1)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01)
+    q, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    qb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 4):
+        p.grad = g * step
+        opt.step()
+        hyper = torch.tensor([5e-4, 0.9, 0.95, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.95 ** step, 1.0], device=DEV)
+        ops.adamw(q, (g * step).contiguous(), m, v, qb, n, hyper, 1.0)
+        close(q, p.detach(), 1e-5, 1e-6, f"adamw step {step}")
+        assert torch.equal(qb, bf(q))

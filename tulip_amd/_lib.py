@@ -1,0 +1,79 @@
+"""ctypes binding of libtulip_hip.so (the C ABI declared in include/tulip_hip.h).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent this module raises, so
+a GPU run can never silently execute anything but the hand-written gfx950 kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtulip_hip.so")
+
+P, I, F, L = c_void_p, c_int, c_float, c_int64
+
+# name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
+SIGNATURES = {
+    "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P],
+    "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
+    "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "tulip_layernorm_bwd_params": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],
+    "tulip_patch_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],
+    "tulip_window_attn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "tulip_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "tulip_bias_table_scatter": [P, P, P, I, I, P],
+    "tulip_cast_f32_bf16": [P, P, I, I, P, I, P],
+    "tulip_concat_cast": [P, P, P, I, I, P],
+    "tulip_unshuffle2_cast": [P, P, I, I, I, I, P],
+    "tulip_colsum_bf16": [P, P, I, I, P],
+    "tulip_cast_flat": [P, P, L, P],
+    "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],
+    "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
+    "tulip_l1_loss_fwd": [P, P, P, P, L, I, P],
+    "tulip_l1_loss_bwd": [P, P, P, F, P, L, P],
+    "tulip_adamw": [P, P, P, P, P, L, P, F, P],
+    "tulip_abi_version": [],
+    "tulip_build_arch": [],
+}
+
+EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, EPI_ATOMIC_F32 = range(7)
+
+_lib = None
+
+
+class TulipHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library (import torch first so it binds to torch's HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TulipHipError(
+            f"{LIB_PATH} not found: build it with `python -m tulip_amd.csrc.build` "
+            "(tulip_amd has no CPU or PyTorch fallback for the hot path)")
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TulipHipError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if name == "tulip_build_arch" else c_int
+    if lib.tulip_abi_version() != 1:
+        raise TulipHipError("libtulip_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        if rc == -1:
+            raise TulipHipError(f"{what}: unsupported argument combination (TULIP_ERR_ARG)")
+        raise TulipHipError(f"{what}: HIP launch failed (hipError_t {-rc - 1000})")

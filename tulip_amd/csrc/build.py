@@ -1,0 +1,55 @@
+"""Build libtulip_hip.so (gfx950) in-tree with hipcc.  `python -m tulip_amd.csrc.build [--force]`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "tail.hip"]
+LIB = os.path.join(PKG, "libtulip_hip.so")
+ARCH = "gfx950"
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"),
+                                                       os.path.join(ROOT, "include", "tulip_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, s.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+               "-I", os.path.join(ROOT, "include"), "-I", HERE, "-c", os.path.join(HERE, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(o)
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            print(f"---- {s} failed:\n{out}", file=sys.stderr)
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,264 @@
+// HBM-bound helpers: fp32->bf16 casts (with DropPath row scale / concat / inverse pixel shuffle),
+// column sums (bias gradients), L1 loss forward/backward, fused AdamW.   gfx950 only.
+#include "common.h"
+#include "tulip_hip.h"
+
+namespace {
+
+// y[r][c] = bf16(x[r][c] * rowscale[r / rows_per_sample]); 8 elements / thread
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8,
+                                                        int cols8, const float* __restrict__ rowscale,
+                                                        int rows_per_sample) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float s = 1.0f;
+        if (rowscale) s = rowscale[(int)(i / cols8) / rows_per_sample];
+        const float4 a = *(const float4*)(x + i * 8), b = *(const float4*)(x + i * 8 + 4);
+        *(uint4*)(y + i * 8) = make_uint4(pack_bf16x2(a.x * s, a.y * s), pack_bf16x2(a.z * s, a.w * s),
+                                          pack_bf16x2(b.x * s, b.y * s), pack_bf16x2(b.z * s, b.w * s));
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_flat_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = *(const float4*)(x + i * 4);
+        *(uint2*)(y + i * 4) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
+}
+
+// out[r][0:C] = a[r], out[r][C:2C] = b[r]
+__global__ __launch_bounds__(256) void concat_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          bf16_t* __restrict__ out, int64_t n4, int C4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (2 * C4);
+        const int c = (int)(i - r * 2 * C4);
+        const float* src = c < C4 ? a + (r * C4 + c) * 4 : b + (r * C4 + (c - C4)) * 4;
+        const float4 v = *(const float4*)src;
+        *(uint2*)(out + i * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+
+// dz[(b,h,w)][4c+2i+j] = bf16(dx[b,2h+i,2w+j,c]);  one thread per (token, c): 4 gathers, one 8-byte store
+__global__ __launch_bounds__(256) void unshuffle2_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dz, int B,
+                                                         int H, int W, int C2) {
+    const int64_t n = (int64_t)B * H * W * C2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C2);
+        const int64_t tok = i / C2;
+        const int w = (int)(tok % W);
+        const int64_t t2 = tok / W;
+        const int h = (int)(t2 % H), b = (int)(t2 / H);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = r >> 1, jj = r & 1;
+            v[r] = dx[(((int64_t)b * 2 * H + 2 * h + ii) * (2 * W) + 2 * w + jj) * C2 + c];
+        }
+        *(uint2*)(dz + tok * (4 * C2) + 4 * c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+}
+
+// out[c] += sum_r x[r][c]; thread = 8-column chunk, TPR chunks per row-slab, 256/TPR row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* out, int rows, int cols,
+                                                     int tpr_log2, int rows_per_block) {
+    __shared__ float red[8][256];
+    const int TPR = 1 << tpr_log2;
+    const int tx = threadIdx.x & (TPR - 1), ty = threadIdx.x >> tpr_log2;
+    const int RL = 256 >> tpr_log2;
+    const int c = blockIdx.x * TPR + tx;
+    const int nch = cols >> 3;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < nch) {
+        const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+        for (int r = r0 + ty; r < r1; r += RL) {
+            const uint4 v = *(const uint4*)(x + (size_t)r * cols + c * 8);
+            a[0] += bf2f((bf16_t)(v.x & 0xffff)); a[1] += bf2f((bf16_t)(v.x >> 16));
+            a[2] += bf2f((bf16_t)(v.y & 0xffff)); a[3] += bf2f((bf16_t)(v.y >> 16));
+            a[4] += bf2f((bf16_t)(v.z & 0xffff)); a[5] += bf2f((bf16_t)(v.z >> 16));
+            a[6] += bf2f((bf16_t)(v.w & 0xffff)); a[7] += bf2f((bf16_t)(v.w >> 16));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[i][threadIdx.x] = a[i];
+    __syncthreads();
+    if (ty == 0 && c < nch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < RL; ++k) s += red[i][(k << tpr_log2) + tx];
+            atomicAdd(out + c * 8 + i, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- loss (tulip.py:690-700)
+constexpr int LOSS_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                         float* __restrict__ partials, int64_t n, int log_transform) {
+    __shared__ float red[2][4];
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float p = pred[i], t = tgt[i];
+        s0 += fabsf(p - t);
+        if (log_transform) s1 += fabsf(expm1f(p) - expm1f(t));
+    }
+    s0 = group_sum<64>(s0);
+    s1 = group_sum<64>(s1);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ partials, float* __restrict__ losses,
+                                                       int nblocks, double inv_n, int log_transform) {
+    __shared__ double red[2][4];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { s0 += partials[i * 2]; s1 += partials[i * 2 + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        losses[0] = (float)(a * inv_n);
+        losses[1] = log_transform ? (float)(b * inv_n) : (float)(a * inv_n);
+    }
+}
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                     const float* __restrict__ gscale_dev, float gscale,
+                                                     float* __restrict__ dpred, int64_t n) {
+    const float g = (gscale_dev ? gscale_dev[0] : gscale) / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = pred[i] - tgt[i];
+        dpred[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------- AdamW
+// hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
+                                                    float wd_mult) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4] * wd_mult;
+    const float bc1 = hyper[5], bc2 = hyper[6], gs = hyper[7];
+    const float decay = 1.0f - lr * wd;
+    const float step = lr / bc1;
+    const float rbc2 = rsqrtf(bc2);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = *(float4*)(p + i * 4);
+        const float4 gg = *(const float4*)(g + i * 4);
+        float4 mm = *(float4*)(m + i * 4), vv = *(float4*)(v + i * 4);
+        float* P = (float*)&pp; const float* G = (const float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = G[k] * gs;
+            M[k] = b1 * M[k] + (1.0f - b1) * gr;
+            V[k] = b2 * V[k] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(V[k]) * rbc2 + eps;
+            P[k] = P[k] * decay - step * (M[k] / denom);
+        }
+        *(float4*)(p + i * 4) = pp; *(float4*)(m + i * 4) = mm; *(float4*)(v + i * 4) = vv;
+        if (pb) *(uint2*)(pb + i * 4) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
+    }
+}
+
+inline int grid_for(int64_t work, int cap = 256 * 8) {
+    int64_t b = (work + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int tulip_cast_f32_bf16(const float* x, uint16_t* y, int rows, int cols, const float* rowscale,
+                                   int rows_per_sample, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return TULIP_OK;
+    if (cols & 7) return TULIP_ERR_ARG;
+    if (rowscale && rows_per_sample <= 0) return TULIP_ERR_ARG;
+    const int64_t n8 = (int64_t)rows * cols / 8;
+    hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for(n8)), dim3(256), 0, stream, x, y, n8, cols / 8, rowscale,
+                       rows_per_sample);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_cast_flat(const float* x, uint16_t* y, int64_t n, hipStream_t stream) {
+    if (n <= 0) return TULIP_OK;
+    hipLaunchKernelGGL(cast_flat_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, y, n);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_concat_cast(const float* a, const float* b, uint16_t* out, int rows, int C, hipStream_t stream) {
+    if (rows <= 0 || C <= 0) return TULIP_OK;
+    if (C & 3) return TULIP_ERR_ARG;
+    const int64_t n4 = (int64_t)rows * 2 * C / 4;
+    hipLaunchKernelGGL(concat_cast_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, a, b, out, n4, C / 4);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_unshuffle2_cast(const float* dx, uint16_t* dz, int B, int H, int W, int C2, hipStream_t stream) {
+    const int64_t n = (int64_t)B * H * W * C2;
+    if (n <= 0) return TULIP_OK;
+    hipLaunchKernelGGL(unshuffle2_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dx, dz, B, H, W, C2);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return TULIP_OK;
+    if (cols & 7) return TULIP_ERR_ARG;
+    const int nch = cols >> 3;
+    int tpr_log2 = 3;
+    while ((1 << tpr_log2) < nch && tpr_log2 < 6) ++tpr_log2;
+    const int TPR = 1 << tpr_log2;
+    const int gx = (nch + TPR - 1) / TPR;
+    int gy = (rows + 63) / 64;
+    if (gy > 1024 / gx) gy = 1024 / gx;
+    if (gy < 1) gy = 1;
+    const int rows_per_block = (rows + gy - 1) / gy;
+    gy = (rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, x, out, rows, cols, tpr_log2, rows_per_block);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_l1_loss_fwd(const float* pred, const float* target, float* partials, float* losses, int64_t n,
+                                 int log_transform, hipStream_t stream) {
+    if (n <= 0) return TULIP_ERR_ARG;
+    const int nb = grid_for(n, LOSS_BLOCKS);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, stream, pred, target, partials, n, log_transform);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, stream, partials, losses, nb, 1.0 / (double)n,
+                       log_transform);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscale_dev, float gscale,
+                                 float* dpred, int64_t n, hipStream_t stream) {
+    if (n <= 0) return TULIP_ERR_ARG;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, pred, target, gscale_dev, gscale, dpred,
+                       n);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
+                           const float* hyper, float wd_mult, hipStream_t stream) {
+    if (n <= 0) return TULIP_OK;
+    if (n & 3) return TULIP_ERR_ARG;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, hyper,
+                       wd_mult);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_abi_version(void) { return 1; }
+extern "C" const char* tulip_build_arch(void) { return "gfx950"; }

@@ -1,0 +1,336 @@
+// bf16 MFMA GEMM for the TULIP linears / 1x1 convs, forward + dgrad + wgrad.   gfx950 only.
+//
+//   C[M,N] = opA[M,K] . opB[N,K]^T        (fp32 accumulate, v_mfma_f32_16x16x32_bf16)
+//
+// Operand layouts (runtime independent, compile-time template):
+//   A_T = false : A stored [M][lda], k contiguous   (activations in fwd / dgrad)
+//   A_T = true  : A stored [K][lda], m contiguous   (wgrad: dY^T without materialising it)
+//   B_T = false : B stored [N][ldb], k contiguous   (nn.Linear weight [out,in] in fwd)
+//   B_T = true  : B stored [K][ldb], n contiguous   (dgrad: W as is; wgrad: X as is)
+// k-contiguous tiles sit in LDS as [row][32 k] (64 B rows, 16-B chunk XOR swizzle, ds_read_b128
+// fragments); k-slow tiles sit as [32 k][rows] (288 B pitch, 32-B chunk XOR swizzle) and are read
+// with ds_read_b64_tr_b16, the CDNA4 LDS transpose read, so neither dgrad nor wgrad needs a
+// transposed copy of weights or activations in HBM.
+//
+// Tile: BM x 96 x 32 per 256-thread workgroup (4 waves as 2x2, wave tile BM/2 x 48), double
+// buffered LDS, register prefetch of the next k-tile.  The MFMA is issued "swapped"
+// (a := B fragment, b := A fragment) so each lane ends up with 4 consecutive output columns of
+// one row -> 8/16-byte epilogue loads and stores.
+//
+// Epilogues fuse: bias, exact-erf GELU (dual store), GELU backward, residual add with the
+// per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging), fp32 accumulate, and
+// split-K atomic accumulation (wgrad).
+#include "common.h"
+#include "tulip_hip.h"
+
+namespace {
+
+constexpr int BN = 96;
+constexpr int BK = 32;
+constexpr int T_PITCH = 288;            // bytes per k-row of a k-slow tile (128 rows * 2 B + 32 B pad)
+constexpr int TILE_BYTES = 32 * T_PITCH;  // 9216 >= 128 * 64 (k-contiguous tile)
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    int lda, ldb;
+    int M, N, K;
+    int kchunk;  // K range per blockIdx.z (multiple of 32)
+    int epi;
+    const float* bias;
+    void* out;
+    int ldo;
+    void* out2;
+    int ldo2;
+    const void* aux;
+    int ldaux;
+    const float* rowscale;
+    int rows_per_sample;
+    int accumulate;
+    int psH, psW;
+};
+
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+// ---- global -> registers (16 B chunks), zero fill out of range -------------------------------
+template <int ROWS, bool T>
+struct Stage {
+    static constexpr int NCHUNK = ROWS * 4;                 // 16-B chunks per 32-deep k tile
+    static constexpr int PER_THREAD = (NCHUNK + 255) / 256;
+    uint4 r[PER_THREAD];
+
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int nrows, int k0, int kend,
+                                         int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int c = tid + i * 256;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (NCHUNK % 256 == 0 || c < NCHUNK) {
+                if (!T) {
+                    int row = c >> 2, kc = c & 3;
+                    int gr = row0 + row, gk = k0 + kc * 8;
+                    if (gr < nrows && gk < kend) v = *(const uint4*)(base + (size_t)gr * ld + gk);
+                } else {
+                    constexpr int CPR = ROWS / 8;  // chunks per k row
+                    int k = c / CPR, mc = c % CPR;
+                    int gk = k0 + k, gr = row0 + mc * 8;
+                    if (gk < kend && gr < nrows) v = *(const uint4*)(base + (size_t)gk * ld + gr);
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int c = tid + i * 256;
+            if (NCHUNK % 256 == 0 || c < NCHUNK) {
+                int off;
+                if (!T) {
+                    int row = c >> 2, kc = c & 3;
+                    off = row * 64 + ((kc ^ swz4(row)) << 4);
+                } else {
+                    constexpr int CPR = ROWS / 8;
+                    int k = c / CPR, mc = c % CPR;
+                    off = k * T_PITCH + ((((mc >> 1) ^ (((k >> 3) & 1) << 2))) << 5) + ((mc & 1) << 4);
+                }
+                *(uint4*)(lds + off) = r[i];
+            }
+        }
+    }
+};
+
+// k-contiguous fragment: rows row0+(l&15), k slots (l>>4)*8 .. +7
+__device__ __forceinline__ bf16x8 frag_n(const unsigned char* lds, int row, int g) {
+    return *(const bf16x8*)(lds + row * 64 + ((g ^ swz4(row)) << 4));
+}
+
+// k-slow fragments through the LDS transpose read.  NF fragments (16 rows each, starting at 32-B
+// chunk c32_0 + f), one asm statement: 2*NF reads then a single lgkmcnt(0).
+template <int NF>
+__device__ __forceinline__ void frag_t(const unsigned char* lds, int c32_0, int lane, bf16x8* out) {
+    const int g = lane >> 4, i = lane & 15;
+    const int k = g * 8 + (i >> 2);
+    const int sw = (g & 1) << 2;
+    unsigned a[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+        a[f] = (unsigned)(uintptr_t)(lds + k * T_PITCH + (((c32_0 + f) ^ sw) << 5) + ((i & 3) << 3));
+    bf16x4 lo[NF], hi[NF];
+    if constexpr (NF == 2) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:1152\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1])
+            : "v"(a[0]), "v"(a[1])
+            : "memory");
+    } else if constexpr (NF == 3) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %2, %7\n\tds_read_b64_tr_b16 %3, %7 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:1152\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2])
+            : "memory");
+    } else {
+        static_assert(NF == 4, "NF");
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1152\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]),
+              "=&v"(hi[3])
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+            : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+        out[f] = __builtin_shufflevector(lo[f], hi[f], 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---- epilogue: 4 consecutive columns n..n+3 of row m ------------------------------------------
+__device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 acc) {
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (p.bias) {
+        float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    switch (p.epi) {
+        case TULIP_EPI_BF16: {
+            uint2 o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+        } break;
+        case TULIP_EPI_GELU_DUAL: {
+            bf16_t h[4];
+            float g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h[r] = f2bf(v[r]); g[r] = gelu_exact(bf2f(h[r])); }
+            *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) =
+                make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *(uint2*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) =
+                make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+        } break;
+        case TULIP_EPI_GELU_BWD: {
+            uint2 hh = *(const uint2*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
+            float h0 = bf2f((bf16_t)(hh.x & 0xffff)), h1 = bf2f((bf16_t)(hh.x >> 16));
+            float h2 = bf2f((bf16_t)(hh.y & 0xffff)), h3 = bf2f((bf16_t)(hh.y >> 16));
+            uint2 o = make_uint2(pack_bf16x2(v[0] * gelu_exact_grad(h0), v[1] * gelu_exact_grad(h1)),
+                                 pack_bf16x2(v[2] * gelu_exact_grad(h2), v[3] * gelu_exact_grad(h3)));
+            *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+        } break;
+        case TULIP_EPI_F32: {
+            float* o = (float*)p.out + (size_t)m * p.ldo + n;
+            float4 r = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.accumulate) { float4 q = *(float4*)o; r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+            *(float4*)o = r;
+        } break;
+        case TULIP_EPI_RESID_F32: {
+            float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+            float4 q = *(const float4*)((const float*)p.aux + (size_t)m * p.ldaux + n);
+            *(float4*)((float*)p.out + (size_t)m * p.ldo + n) =
+                make_float4(q.x + s * v[0], q.y + s * v[1], q.z + s * v[2], q.w + s * v[3]);
+        } break;
+        case TULIP_EPI_PIXSHUF2_F32: {
+            // token m=(b*H+h)*W+w, column n=4c+2i+j  ->  out[b, 2h+i, 2w+j, c], C_out = N/4
+            int w = m % p.psW, t = m / p.psW;
+            int h = t % p.psH, b = t / p.psH;
+            int co = p.N >> 2, c = n >> 2;
+            float* o = (float*)p.out;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int i = r >> 1, j = r & 1;
+                size_t idx = (((size_t)b * 2 * p.psH + 2 * h + i) * (2 * p.psW) + 2 * w + j) * co + c;
+                o[idx] = v[r];
+            }
+        } break;
+        case TULIP_EPI_ATOMIC_F32: {
+            float* o = (float*)p.out + (size_t)m * p.ldo + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(o + r, v[r]);
+        } break;
+        default: break;
+    }
+}
+
+template <int BM, bool A_T, bool B_T>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    constexpr int FM = BM / 32;  // 16-row fragments per wave in M
+    constexpr int FN = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+    auto ldsA = [&](int buf) -> unsigned char* { return smem + buf * (2 * TILE_BYTES); };
+    auto ldsB = [&](int buf) -> unsigned char* { return smem + buf * (2 * TILE_BYTES) + TILE_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    Stage<BM, A_T> sa;
+    Stage<BN, B_T> sb;
+    if (nt > 0) {
+        sa.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        sb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+        sa.store(ldsA(0), tid);
+        sb.store(ldsB(0), tid);
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, li = lane & 15;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            sa.load(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid);
+            sb.load(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid);
+        }
+        bf16x8 af[FM], bfr[FN];
+        if (!A_T) {
+#pragma unroll
+            for (int f = 0; f < FM; ++f) af[f] = frag_n(ldsA(cur), wm * (BM / 2) + f * 16 + li, g);
+        }
+        if (!B_T) {
+#pragma unroll
+            for (int f = 0; f < FN; ++f) bfr[f] = frag_n(ldsB(cur), wn * 48 + f * 16 + li, g);
+        }
+        if (A_T) frag_t<FM>(ldsA(cur), wm * (BM / 32), lane, af);
+        if (B_T) frag_t<FN>(ldsB(cur), wn * 3, lane, bfr);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if (t + 1 < nt) {
+            sa.store(ldsA(cur ^ 1), tid);
+            sb.store(ldsB(cur ^ 1), tid);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * 48 + j * 16 + g * 4;
+            if (n < p.N) epilogue(p, m, n, acc[i][j]);
+        }
+    }
+}
+
+template <bool A_T, bool B_T>
+int launch(const GemmArgs& p, int splits, hipStream_t stream) {
+    // pick BM=64 when BM=128 would leave most of the 256 CUs idle
+    const int gn = (p.N + BN - 1) / BN;
+    const bool small = ((p.M + 127) / 128) * gn * splits < 256 && p.M > 64;
+    if (small || p.M <= 64) {
+        dim3 grid(gn, (p.M + 63) / 64, splits);
+        hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T>), grid, dim3(256), 0, stream, p);
+    } else {
+        dim3 grid(gn, (p.M + 127) / 128, splits);
+        hipLaunchKernelGGL((gemm_kernel<128, A_T, B_T>), grid, dim3(256), 0, stream, p);
+    }
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+}  // namespace
+
+extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N,
+                               int K, int epi, const float* bias, void* out, int ldo, void* out2, int ldo2,
+                               const void* aux, int ldaux, const float* rowscale, int rows_per_sample, int accumulate,
+                               int psH, int psW, int splits, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return TULIP_OK;
+    if ((K & 7) || (N & 3) || (lda & 7) || (ldb & 7)) return TULIP_ERR_ARG;
+    if (a_trans && (M & 7)) return TULIP_ERR_ARG;
+    if (b_trans && (N & 7)) return TULIP_ERR_ARG;
+    if (splits < 1) splits = 1;
+    if (splits > 1 && epi != TULIP_EPI_ATOMIC_F32) return TULIP_ERR_ARG;
+    if ((epi == TULIP_EPI_RESID_F32 || epi == TULIP_EPI_GELU_BWD) && !aux) return TULIP_ERR_ARG;
+    if (epi == TULIP_EPI_GELU_DUAL && !out2) return TULIP_ERR_ARG;
+    GemmArgs p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb;
+    p.M = M; p.N = N; p.K = K;
+    int kchunk = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
+    p.kchunk = kchunk;
+    splits = (K + kchunk - 1) / kchunk;
+    p.epi = epi; p.bias = bias; p.out = out; p.ldo = ldo; p.out2 = out2; p.ldo2 = ldo2;
+    p.aux = aux; p.ldaux = ldaux; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+    p.accumulate = accumulate; p.psH = psH; p.psW = psW;
+    if (!a_trans && !b_trans) return launch<false, false>(p, splits, stream);
+    if (!a_trans && b_trans) return launch<false, true>(p, splits, stream);
+    if (a_trans && b_trans) return launch<true, true>(p, splits, stream);
+    return launch<true, false>(p, splits, stream);
+}

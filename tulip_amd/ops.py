@@ -1,0 +1,134 @@
+"""Tensor-level wrappers over the C ABI (tulip_amd/_lib.py).  Outputs are caller-allocated; every
+call is asynchronous on torch's current HIP stream (so it is captured by torch.cuda.graph)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL,  # noqa: F401
+                   EPI_PIXSHUF2_F32, EPI_RESID_F32, check)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name}: expected contiguous {dtype} device tensor, got {t.dtype} "
+                        f"{'cuda' if t.is_cuda else 'cpu'} contiguous={t.is_contiguous()}")
+
+
+def gemm(A, B, M, N, K, *, lda, ldb, a_trans=False, b_trans=False, epi=EPI_BF16, bias=None, out=None, ldo=None,
+         out2=None, ldo2=0, aux=None, ldaux=0, rowscale=None, rows_per_sample=1, accumulate=False, psH=0, psW=0,
+         splits=1):
+    """C[M,N] = opA . opB^T with a fused epilogue (see include/tulip_hip.h).  A/B/out may be views
+    with an element offset (row strides passed as lda/ldb/ldo)."""
+    lib = _lib.load()
+    rc = lib.tulip_gemm_bf16(_p(A), lda, int(a_trans), _p(B), ldb, int(b_trans), M, N, K, epi, _p(bias), _p(out),
+                             ldo if ldo is not None else N, _p(out2), ldo2, _p(aux), ldaux, _p(rowscale),
+                             rows_per_sample, int(accumulate), psH, psW, splits, _stream())
+    check(rc, "tulip_gemm_bf16")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, merge=False, B=0, H=0, W=0):
+    rc = _lib.load().tulip_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps,
+                                         int(merge), B, H, W, _stream())
+    check(rc, "tulip_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0, H=0, W=0):
+    rc = _lib.load().tulip_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), rows, C,
+                                         int(merge), B, H, W, _stream())
+    check(rc, "tulip_layernorm_bwd")
+
+
+def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False, B=0, H=0, W=0):
+    rc = _lib.load().tulip_layernorm_bwd_params(_p(dy), _p(x), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), rows, C,
+                                                int(merge), B, H, W, _stream())
+    check(rc, "tulip_layernorm_bwd_params")
+
+
+def patch_embed_fwd(img, w, b, gamma, beta, out, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps):
+    rc = _lib.load().tulip_patch_embed_fwd(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, Hin, Win, E,
+                                           p0, p1, kw, int(circular), eps, _stream())
+    check(rc, "tulip_patch_embed_fwd")
+
+
+def patch_embed_bwd(img, w, b, gamma, dout, dw, db, dgamma, dbeta, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps):
+    rc = _lib.load().tulip_patch_embed_bwd(_p(img), _p(w), _p(b), _p(gamma), _p(dout), _p(dw), _p(db), _p(dgamma),
+                                           _p(dbeta), B, Cin, Hin, Win, E, p0, p1, kw, int(circular), eps, _stream())
+    check(rc, "tulip_patch_embed_bwd")
+
+
+def window_attn_fwd(qkv, bias_table, rel_index, out, B, H, W, C, nh, win, shift, masked):
+    rc = _lib.load().tulip_window_attn_fwd(_p(qkv), _p(bias_table), _p(rel_index), _p(out), B, H, W, C, nh, win[0],
+                                           win[1], shift[0], shift[1], int(masked), _stream())
+    check(rc, "tulip_window_attn_fwd")
+
+
+def window_attn_bwd(qkv, dout, bias_table, rel_index, dqkv, dbias_dense, B, H, W, C, nh, win, shift, masked):
+    rc = _lib.load().tulip_window_attn_bwd(_p(qkv), _p(dout), _p(bias_table), _p(rel_index), _p(dqkv),
+                                           _p(dbias_dense), B, H, W, C, nh, win[0], win[1], shift[0], shift[1],
+                                           int(masked), _stream())
+    check(rc, "tulip_window_attn_bwd")
+
+
+def bias_table_scatter(dbias_dense, rel_index, dtable, nh, L):
+    check(_lib.load().tulip_bias_table_scatter(_p(dbias_dense), _p(rel_index), _p(dtable), nh, L, _stream()),
+          "tulip_bias_table_scatter")
+
+
+def cast_f32_bf16(x, y, rows, cols, rowscale=None, rows_per_sample=1):
+    check(_lib.load().tulip_cast_f32_bf16(_p(x), _p(y), rows, cols, _p(rowscale), rows_per_sample, _stream()),
+          "tulip_cast_f32_bf16")
+
+
+def concat_cast(a, b, out, rows, C):
+    check(_lib.load().tulip_concat_cast(_p(a), _p(b), _p(out), rows, C, _stream()), "tulip_concat_cast")
+
+
+def unshuffle2_cast(dx, dz, B, H, W, C2):
+    check(_lib.load().tulip_unshuffle2_cast(_p(dx), _p(dz), B, H, W, C2, _stream()), "tulip_unshuffle2_cast")
+
+
+def colsum_bf16(x, out, rows, cols):
+    check(_lib.load().tulip_colsum_bf16(_p(x), _p(out), rows, cols, _stream()), "tulip_colsum_bf16")
+
+
+def cast_flat(x, y, n):
+    check(_lib.load().tulip_cast_flat(_p(x), _p(y), n, _stream()), "tulip_cast_flat")
+
+
+def tail_fwd(xn, We, be, wd, pred, B, H, W, E):
+    check(_lib.load().tulip_tail_fwd(_p(xn), _p(We), _p(be), _p(wd), _p(pred), B, H, W, E, _stream()),
+          "tulip_tail_fwd")
+
+
+def tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E):
+    check(_lib.load().tulip_tail_bwd(_p(xn), _p(We), _p(be), _p(wd), _p(dpred), _p(dz), _p(dwd), B, H, W, E,
+                                     _stream()), "tulip_tail_bwd")
+
+
+def l1_loss_fwd(pred, target, partials, losses, n, log_transform):
+    check(_lib.load().tulip_l1_loss_fwd(_p(pred), _p(target), _p(partials), _p(losses), n, int(log_transform),
+                                        _stream()), "tulip_l1_loss_fwd")
+
+
+def l1_loss_bwd(pred, target, gscale_dev, gscale, dpred, n):
+    check(_lib.load().tulip_l1_loss_bwd(_p(pred), _p(target), _p(gscale_dev), float(gscale), _p(dpred), n,
+                                        _stream()), "tulip_l1_loss_bwd")
+
+
+def adamw(p, g, m, v, p_bf16, n, hyper, wd_mult):
+    check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), float(wd_mult), _stream()),
+          "tulip_adamw")
