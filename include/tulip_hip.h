@@ -120,11 +120,12 @@ int tulip_l1_loss_fwd(const float* pred, const float* target, float* partials, f
 int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscale_dev, float gscale, float* dpred,
                       int64_t n, hipStream_t stream);
 
-/* Fused AdamW over a flat parameter range (torch.optim.AdamW semantics, main_lidar_upsampling.py:283):
+/* Fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, main_lidar_upsampling.py:283):
  * hyper (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}.
- * Also refreshes the bf16 weight shadow. */
+ * decay_mask64[i/64] != 0 selects weight decay for elements of 64-float block i/64 (timm's grouping,
+ * main:282: decay only for ndim>1 parameters); NULL = decay everywhere.  Also refreshes the bf16 shadow. */
 int tulip_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
-                float wd_mult, hipStream_t stream);
+                const uint8_t* decay_mask64, hipStream_t stream);
 
 /* library self-description */
 int tulip_abi_version(void);

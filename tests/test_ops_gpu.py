@@ -356,6 +356,6 @@ def test_adamw_matches_torch(ops):
         p.grad = g * step
         opt.step()
         hyper = torch.tensor([5e-4, 0.9, 0.95, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.95 ** step, 1.0], device=DEV)
-        ops.adamw(q, (g * step).contiguous(), m, v, qb, n, hyper, 1.0)
+        ops.adamw(q, (g * step).contiguous(), m, v, qb, n, hyper, None)
         close(q, p.detach(), 1e-5, 1e-6, f"adamw step {step}")
         assert torch.equal(qb, bf(q))

@@ -34,7 +34,7 @@ SIGNATURES = {
     "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "tulip_l1_loss_fwd": [P, P, P, P, L, I, P],
     "tulip_l1_loss_bwd": [P, P, P, F, P, L, P],
-    "tulip_adamw": [P, P, P, P, P, L, P, F, P],
+    "tulip_adamw": [P, P, P, P, P, L, P, P, P],
     "tulip_abi_version": [],
     "tulip_build_arch": [],
 }

@@ -142,14 +142,15 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
-                                                    float wd_mult) {
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4] * wd_mult;
+                                                    const uint8_t* __restrict__ mask64) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
     const float bc1 = hyper[5], bc2 = hyper[6], gs = hyper[7];
-    const float decay = 1.0f - lr * wd;
+    const float decay_on = 1.0f - lr * wd;
     const float step = lr / bc1;
     const float rbc2 = rsqrtf(bc2);
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float decay = (!mask64 || mask64[i >> 4]) ? decay_on : 1.0f;
         float4 pp = *(float4*)(p + i * 4);
         const float4 gg = *(const float4*)(g + i * 4);
         float4 mm = *(float4*)(m + i * 4), vv = *(float4*)(v + i * 4);
@@ -251,11 +252,11 @@ extern "C" int tulip_l1_loss_bwd(const float* pred, const float* target, const f
 }
 
 extern "C" int tulip_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
-                           const float* hyper, float wd_mult, hipStream_t stream) {
+                           const float* hyper, const uint8_t* decay_mask64, hipStream_t stream) {
     if (n <= 0) return TULIP_OK;
     if (n & 3) return TULIP_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, hyper,
-                       wd_mult);
+                       decay_mask64);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

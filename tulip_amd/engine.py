@@ -1,0 +1,603 @@
+"""Host-side orchestration of the TULIP hot path on one MI355X.
+
+``TulipEngine`` owns, for one ``tulip_amd.model.tulip.TULIP`` module:
+
+* a **flat fp32 parameter buffer** (the module's nn.Parameters are re-pointed to views of it, so
+  ``state_dict`` / optimizers / DDP keep working), ordered by *backward completion* (head first,
+  patch embedding last) so gradient buckets can be all-reduced while the rest of the backward is
+  still running; a **bf16 shadow** of it feeds the MFMA GEMMs;
+* per-batch-size **plans**: statically allocated activation / gradient workspaces, so a whole
+  forward+backward(+AdamW) is a fixed launch sequence that is captured once into a HIP graph;
+* ``run_forward`` / ``run_backward``: the launch sequences (reference: TULIP.forward,
+  tulip.py:702-737, and its autograd backward) expressed purely as C-ABI kernel calls;
+* ``autograd_forward``: the ``loss.backward()``-compatible bridge used by ``TULIP.forward``.
+
+Nothing here computes on the CPU and nothing falls back to PyTorch ops for the hot path; PyTorch is
+used for device memory, streams, RNG draws for DropPath and graph capture.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32)
+
+ALIGN = 64  # floats; every parameter starts on a 256-byte boundary of the flat buffer
+
+
+def _ceil(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def effective_window(H: int, window, shift: bool):
+    """(window, shift) used for a grid of height H (tulip.py:284-287 backup window, :219-222)."""
+    wh, ww = int(window[0]), int(window[1])
+    L = wh * ww
+    if H < wh:
+        return (1, L), ((0, L // 2) if shift else (0, 0))
+    return (wh, ww), ((wh // 2, ww // 2) if shift else (0, 0))
+
+
+@dataclass
+class BlockSpec:
+    prefix: str
+    H: int
+    W: int
+    C: int
+    nh: int
+    shift: bool
+    rate: float
+    win: Tuple[int, int] = (2, 8)
+    sft: Tuple[int, int] = (0, 0)
+    slot: int = -1  # row in the DropPath scale table (-1: rate 0)
+
+
+class FlatParams:
+    """Flat fp32 master + bf16 shadow + address book, ordered by backward completion."""
+
+    def __init__(self, model, device):
+        self.device = device
+        named = dict(model.named_parameters())
+        order = self._completion_order(model, named)
+        assert sorted(order) == sorted(named.keys())
+        self.names: List[str] = order
+        self.offset: Dict[str, int] = {}
+        self.numel: Dict[str, int] = {}
+        self.shape: Dict[str, Tuple[int, ...]] = {}
+        off = 0
+        for n in order:
+            p = named[n]
+            self.offset[n], self.numel[n], self.shape[n] = off, p.numel(), tuple(p.shape)
+            off = _ceil(off + p.numel(), ALIGN)
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
+        mask = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
+        for n in order:
+            p = named[n]
+            self.flat[self.offset[n]:self.offset[n] + p.numel()].copy_(p.data.reshape(-1).float())
+            if p.ndim > 1:  # timm param groups (main_lidar_upsampling.py:282): decay only ndim > 1
+                mask[self.offset[n] // ALIGN:_ceil(self.offset[n] + p.numel(), ALIGN) // ALIGN] = 1
+        self.decay_mask = mask.to(device)
+        self.views: Dict[str, torch.Tensor] = {}
+        for n in order:
+            v = self.flat[self.offset[n]:self.offset[n] + self.numel[n]].view(self.shape[n])
+            self.views[n] = v
+            named[n].data = v
+        self.base32 = self.flat.data_ptr()
+        self.base16 = self.shadow.data_ptr()
+        self.shadow_dirty = True
+
+    @staticmethod
+    def _completion_order(model, named) -> List[str]:
+        nl = model.num_layers
+        order: List[str] = []
+
+        def add(prefix):
+            ks = [k for k in named if k.startswith(prefix)]
+            order.extend(k for k in ks if k not in order)
+
+        def blocks_rev(prefix, depth):
+            for b in reversed(range(depth)):
+                for sub in ("mlp.fc2", "mlp.fc1", "norm2", "attn.proj", "attn.relative_position_bias_table",
+                            "attn.qkv", "norm1"):
+                    add(f"{prefix}.blocks.{b}.{sub}")
+
+        add("decoder_pred."); add("ps_head."); add("norm_up.")
+        for i in reversed(range(nl - 1)):
+            add(f"layers_up.{i}.upsample.")
+            blocks_rev(f"layers_up.{i}", model.depths[nl - i - 2])
+            add(f"skip_connection_layers.{i}.")
+        add("first_patch_expanding.")
+        for s in reversed(range(nl)):
+            blocks_rev(f"layers.{s}", model.depths[s])
+            if s > 0:
+                add(f"layers.{s - 1}.downsample.")
+        add("patch_embed.")
+        return order
+
+    def p32(self, name: str) -> int:
+        return self.base32 + 4 * self.offset[name]
+
+    def p16(self, name: str) -> int:
+        return self.base16 + 2 * self.offset[name]
+
+    def still_bound(self, model) -> bool:
+        for n, p in model.named_parameters():
+            if p.data_ptr() != self.base32 + 4 * self.offset[n]:
+                return False
+        return True
+
+    def refresh_shadow(self):
+        ops.cast_flat(self.flat, self.shadow, self.total)
+        self.shadow_dirty = False
+
+
+class Plan:
+    """Static workspaces for one batch size."""
+
+    def __init__(self, eng: "TulipEngine", B: int):
+        self.B = B
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.generation = 0
+        dev = eng.device
+        m = eng.model
+        E, nl = m.embed_dim, m.num_layers
+        H0, W0 = eng.grid
+        self.f32 = lambda name, *shape: self._alloc(name, shape, torch.float32, dev)
+        self.b16 = lambda name, *shape: self._alloc(name, shape, torch.bfloat16, dev)
+        Hh, Wh = m.target_img_size
+        self.x_in = self.f32("x_in", B, m.in_chans, m.img_size[0], m.img_size[1])
+        self.target = self.f32("target", B, m.in_chans, Hh, Wh)
+        self.pred = self.f32("pred", B, m.in_chans, Hh, Wh)
+        self.dpred = self.f32("dpred", B, m.in_chans, Hh, Wh)
+        self.losses = self.f32("losses", 2)
+        self.partials = self.f32("partials", 2048)
+        self.gscale = self.f32("gscale", 1)
+        self.gscale.fill_(1.0)
+        nslots = max(1, eng.n_drop_slots)
+        self.drop_scale = self.f32("drop_scale", nslots, B)
+        self.drop_scale.fill_(1.0)
+        self.drop_u = self.f32("drop_u", nslots, B)
+        self.dense_bias = self.f32("dense_bias", max(m.num_heads), 16, 16)
+        maxM = B * H0 * W0
+        # per-level tensors
+        for s in range(nl):
+            Hs, Ws, Cs = H0 >> s, W0 >> s, E << s
+            Ms = B * Hs * Ws
+            self.f32(f"enc{s}.in", Ms, Cs)
+            self.f32(f"enc{s}.dx", Ms, Cs)
+            if s < nl - 1:
+                self.b16(f"enc{s}.xm", Ms // 4, 4 * Cs)
+                self.f32(f"enc{s}.mmean", Ms // 4)
+                self.f32(f"enc{s}.mrstd", Ms // 4)
+                self.f32(f"dec{s}.in", Ms, Cs)     # skip-linear output = decoder stage input
+                self.f32(f"dec{s}.xu", Ms, Cs)     # unmerged stream arriving from the coarser level
+                self.f32(f"dec{s}.dxu", Ms, Cs)
+                self.f32(f"dec{s}.dx", Ms, Cs)
+                self.b16(f"dec{s}.cat", Ms, 2 * Cs)
+                self.b16(f"dec{s}.dyskip", Ms, Cs)
+            self.b16(f"lvl{s}.xb", Ms, Cs)         # bf16 cast feeding a PatchUnmerging expand
+        for spec in eng.blocks:
+            M, C = B * spec.H * spec.W, spec.C
+            Hd = eng.hidden(C)
+            p = spec.prefix
+            self.b16(p + ".xn1", M, C); self.f32(p + ".mean1", M); self.f32(p + ".rstd1", M)
+            self.b16(p + ".qkv", M, 3 * C); self.b16(p + ".o", M, C); self.f32(p + ".x1", M, C)
+            self.b16(p + ".xn2", M, C); self.f32(p + ".mean2", M); self.f32(p + ".rstd2", M)
+            self.b16(p + ".h", M, Hd); self.b16(p + ".g", M, Hd); self.f32(p + ".out", M, C)
+        Cmax_tok = max(B * sp.H * sp.W * sp.C for sp in eng.blocks)
+        Hdmax_tok = max(B * sp.H * sp.W * eng.hidden(sp.C) for sp in eng.blocks)
+        self.b16("t.dyb", Cmax_tok); self.b16("t.dxn", Cmax_tok); self.b16("t.do", Cmax_tok)
+        self.b16("t.dh", Hdmax_tok); self.b16("t.dqkv", 3 * Cmax_tok)
+        big = max(4 * (B * (H0 >> s) * (W0 >> s) // 4) * (E << s) for s in range(nl))
+        self.b16("t.dxm", big)                     # dgrad of a merge reduction [M/4][4C]
+        self.b16("t.dz2", 2 * Cmax_tok)            # unshuffled grad of an unmerge [M][2C]
+        self.b16("tail.xn", maxM, E); self.f32("tail.mean", maxM); self.f32("tail.rstd", maxM)
+        self.b16("tail.dz", maxM, 16 * E)
+        self.b16("tail.dxn", maxM, E)
+
+    def _alloc(self, name, shape, dtype, dev):
+        t = torch.empty(*shape, dtype=dtype, device=dev)
+        self.bufs[name] = t
+        return t
+
+    def __getitem__(self, k):
+        return self.bufs[k]
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class TulipEngine:
+    def __init__(self, model):
+        self.model = model
+        self.device = None
+        self.params: Optional[FlatParams] = None
+        self.plans: Dict[int, Plan] = {}
+        m = model
+        if m.in_chans != 1:
+            raise NotImplementedError("tulip_amd fused head supports in_chans == 1 (range images)")
+        if m.upscale_factor != 4:
+            raise NotImplementedError("tulip_amd fused head supports upscale_factor == 4 (every BASELINE config)")
+        ws = m.window_size if isinstance(m.window_size, (tuple, list)) else (m.window_size, m.window_size)
+        self.window = (int(ws[0]), int(ws[1]))
+        if self.window[0] * self.window[1] != 16:
+            raise NotImplementedError("tulip_amd attention kernel supports 16-token windows (window_size 2 8)")
+        ph, pw = m.patch_size
+        if m.img_size[0] % ph or m.img_size[1] % pw:
+            raise NotImplementedError("img_size must be divisible by patch_size")
+        self.grid = (m.img_size[0] // ph, m.img_size[1] // pw)
+        self.eps = m._ln_eps
+        nl = m.num_layers
+        self.blocks: List[BlockSpec] = []
+        self.enc_blocks: List[List[BlockSpec]] = []
+        self.dec_blocks: List[List[BlockSpec]] = []
+        slot = 0
+
+        def mk(prefix, s, b, rate):
+            nonlocal slot
+            H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
+            win, sft = effective_window(H, self.window, b % 2 == 1)
+            if H % win[0] or W % win[1]:
+                raise NotImplementedError(f"token grid {H}x{W} not divisible by window {win}")
+            sp = BlockSpec(prefix, H, W, C, m.num_heads[s], b % 2 == 1, rate, win, sft)
+            if rate > 0.0:
+                sp.slot = slot
+                slot += 2
+            self.blocks.append(sp)
+            return sp
+
+        for s in range(nl):
+            mods = m.layers[s].blocks
+            self.enc_blocks.append([mk(f"layers.{s}.blocks.{b}", s, b, mods[b].drop_path_rate)
+                                    for b in range(m.depths[s])])
+        for i in range(nl - 1):
+            s = nl - i - 2
+            mods = m.layers_up[i].blocks
+            self.dec_blocks.append([mk(f"layers_up.{i}.blocks.{b}", s, b, mods[b].drop_path_rate)
+                                    for b in range(m.depths[s])])
+        self.n_drop_slots = slot
+        self._keep = None
+        self._graphs = {}
+        self._rel32 = None
+
+    # ------------------------------------------------------------------ parameters
+    def hidden(self, C: int) -> int:
+        return int(C * self.model.mlp_ratio)
+
+    def invalidate(self):
+        self.params = None
+        self.plans.clear()
+        self._graphs.clear()
+
+    def bind(self, device):
+        """(Re-)flatten the parameters on `device` if the module's storage moved."""
+        if self.params is not None and self.device == device and self.params.still_bound(self.model):
+            return
+        self.device = device
+        self.plans.clear()
+        self._graphs.clear()
+        self.params = FlatParams(self.model, device)
+        rel = self.model.layers[0].blocks[0].attn.relative_position_index
+        self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
+        rates = torch.ones(max(1, self.n_drop_slots), 1)
+        for sp in self.blocks:
+            if sp.slot >= 0:
+                rates[sp.slot] = rates[sp.slot + 1] = 1.0 - sp.rate
+        self._keep = rates.to(device)
+
+    def plan(self, B: int) -> Plan:
+        if B not in self.plans:
+            self.plans[B] = Plan(self, B)
+        return self.plans[B]
+
+    # ------------------------------------------------------------------ forward
+    def draw_drop_scales(self, P: Plan, train: bool, drop_u: Optional[torch.Tensor] = None):
+        """DropPath multipliers floor(keep+u)/keep per (block branch, sample) (tulip.py:25-29)."""
+        if not train or self.n_drop_slots == 0:
+            P.drop_scale.fill_(1.0)
+            return
+        if drop_u is not None:
+            P.drop_u.copy_(drop_u)
+        else:
+            P.drop_u.uniform_()
+        torch.floor(self._keep + P.drop_u, out=P.drop_scale)
+        P.drop_scale.div_(self._keep)
+
+    def _ds(self, P: Plan, sp: BlockSpec, branch: int):
+        if sp.slot < 0:
+            return None
+        return P.drop_scale.data_ptr() + 4 * (sp.slot + branch) * P.B
+
+    def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout):
+        W_ = self.params
+        p = sp.prefix
+        B, C, nh = P.B, sp.C, sp.nh
+        M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
+        ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
+                          P[p + ".mean1"], P[p + ".rstd1"], M, C, self.eps)
+        ops.gemm(P[p + ".xn1"], W_.p16(p + ".attn.qkv.weight"), M, 3 * C, C, lda=C, ldb=C, epi=EPI_BF16,
+                 bias=W_.p32(p + ".attn.qkv.bias"), out=P[p + ".qkv"])
+        ops.window_attn_fwd(P[p + ".qkv"], W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, P[p + ".o"],
+                            B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
+        ops.gemm(P[p + ".o"], W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, epi=EPI_RESID_F32,
+                 bias=W_.p32(p + ".attn.proj.bias"), out=P[p + ".x1"], aux=xin, ldaux=C,
+                 rowscale=self._ds(P, sp, 0), rows_per_sample=tok)
+        ops.layernorm_fwd(P[p + ".x1"], W_.p32(p + ".norm2.weight"), W_.p32(p + ".norm2.bias"), P[p + ".xn2"],
+                          P[p + ".mean2"], P[p + ".rstd2"], M, C, self.eps)
+        ops.gemm(P[p + ".xn2"], W_.p16(p + ".mlp.fc1.weight"), M, Hd, C, lda=C, ldb=C, epi=EPI_GELU_DUAL,
+                 bias=W_.p32(p + ".mlp.fc1.bias"), out=P[p + ".h"], out2=P[p + ".g"], ldo2=Hd)
+        ops.gemm(P[p + ".g"], W_.p16(p + ".mlp.fc2.weight"), M, C, Hd, lda=Hd, ldb=Hd, epi=EPI_RESID_F32,
+                 bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], ldaux=C,
+                 rowscale=self._ds(P, sp, 1), rows_per_sample=tok)
+
+    def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin):
+        x = xin
+        for sp in specs:
+            self._block_fwd(P, sp, x, P[sp.prefix + ".out"])
+            x = P[sp.prefix + ".out"]
+        return x
+
+    def _unmerge_fwd(self, P: Plan, prefix: str, s: int, x, out):
+        """PatchUnmerging (tulip.py:117-123) of level-s stream x -> level s-1 stream `out`."""
+        m, W_ = self.model, self.params
+        B = P.B
+        H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
+        M = B * H * W
+        ops.cast_f32_bf16(x, P[f"lvl{s}.xb"], M, C)
+        ops.gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
+                 bias=W_.p32(prefix + ".expand.bias"), out=out, psH=H, psW=W)
+
+    def run_forward(self, P: Plan, with_loss: bool = True):
+        """TULIP.forward (tulip.py:702-737) on P.x_in / P.target -> P.pred, P.losses."""
+        m, W_ = self.model, self.params
+        if W_.shadow_dirty:
+            W_.refresh_shadow()
+        B, E, nl = P.B, m.embed_dim, m.num_layers
+        H0, W0 = self.grid
+        kw = 8 if m.circular_padding else m.patch_size[1]
+        ops.patch_embed_fwd(P.x_in, W_.p32("patch_embed.proj.weight"), W_.p32("patch_embed.proj.bias"),
+                            W_.p32("patch_embed.norm.weight"), W_.p32("patch_embed.norm.bias"), P["enc0.in"], B,
+                            m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
+                            m.circular_padding, self.eps)
+        x = None
+        for s in range(nl):
+            x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"])
+            if s < nl - 1:  # PatchMerging (tulip.py:101-106)
+                Hs, Ws, Cs = H0 >> s, W0 >> s, E << s
+                rows = B * (Hs // 2) * (Ws // 2)
+                pre = f"layers.{s}.downsample"
+                ops.layernorm_fwd(x, W_.p32(pre + ".norm.weight"), W_.p32(pre + ".norm.bias"), P[f"enc{s}.xm"],
+                                  P[f"enc{s}.mmean"], P[f"enc{s}.mrstd"], rows, 4 * Cs, self.eps, merge=True, B=B,
+                                  H=Hs, W=Ws)
+                ops.gemm(P[f"enc{s}.xm"], W_.p16(pre + ".reduction.weight"), rows, 2 * Cs, 4 * Cs, lda=4 * Cs,
+                         ldb=4 * Cs, epi=EPI_F32, out=P[f"enc{s + 1}.in"])
+        self._unmerge_fwd(P, "first_patch_expanding", nl - 1, x, P[f"dec{nl - 2}.xu"])
+        for i in range(nl - 1):
+            s = nl - i - 2
+            Cs = E << s
+            Ms = B * (H0 >> s) * (W0 >> s)
+            pre = f"skip_connection_layers.{i}"
+            ops.concat_cast(P[f"dec{s}.xu"], P[f"enc{s}.in"], P[f"dec{s}.cat"], Ms, Cs)      # tulip.py:715
+            ops.gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
+                     bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"])
+            x = self._stage_fwd(P, self.dec_blocks[i], P[f"dec{s}.in"])
+            if i < nl - 2:
+                self._unmerge_fwd(P, f"layers_up.{i}.upsample", s, x, P[f"dec{s - 1}.xu"])
+        M0 = B * H0 * W0
+        ops.layernorm_fwd(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), P["tail.xn"], P["tail.mean"],
+                          P["tail.rstd"], M0, E, self.eps)
+        ops.tail_fwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
+                     W_.p32("decoder_pred.weight"), P.pred, B, H0, W0, E)
+        if with_loss:
+            ops.l1_loss_fwd(P.pred, P.target, P.partials, P.losses, P.pred.numel(), m.log_transform)
+        P.generation += 1
+        P.last_x = x
+
+    # ------------------------------------------------------------------ backward
+    @staticmethod
+    def _splits(Mout: int, Nout: int, K: int) -> int:
+        tiles = ((Mout + 127) // 128) * ((Nout + 95) // 96)
+        s = max(1, min(512 // max(tiles, 1), K // 256))
+        return max(1, s)
+
+    def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout):
+        """dW[Nw,Kw] += dY[Mtok,Nw]^T . X[Mtok,Kw] (fp32 atomics, split over tokens)."""
+        ops.gemm(dY, X, Nw, Kw, Mtok, lda=ldy, ldb=ldx, a_trans=True, b_trans=True, epi=EPI_ATOMIC_F32, out=gout,
+                 ldo=Kw, splits=self._splits(Nw, Kw, Mtok))
+
+    def _block_bwd(self, P: Plan, sp: BlockSpec, xin, dx, G):
+        """In-place: dx (grad w.r.t. block output) -> grad w.r.t. block input.  G(name) = grad address."""
+        W_ = self.params
+        p = sp.prefix
+        B, C, nh = P.B, sp.C, sp.nh
+        M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
+        dyb, dxn, dO, dh, dqkv = P["t.dyb"], P["t.dxn"], P["t.do"], P["t.dh"], P["t.dqkv"]
+        # ---- MLP branch (tulip.py:346-351)
+        ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
+        ops.gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
+                 ldo=Hd, aux=P[p + ".h"], ldaux=Hd)
+        self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"))
+        ops.colsum_bf16(dyb, G(p + ".mlp.fc2.bias"), M, C)
+        ops.gemm(dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, lda=Hd, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn,
+                 ldo=C)
+        self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"))
+        ops.colsum_bf16(dh, G(p + ".mlp.fc1.bias"), M, Hd)
+        ops.layernorm_bwd_params(dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], G(p + ".norm2.weight"),
+                                 G(p + ".norm2.bias"), M, C)
+        ops.layernorm_bwd(dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M,
+                          C)
+        # ---- attention branch (tulip.py:339-344)
+        ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 0), tok)
+        ops.gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
+                 ldo=C)
+        self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"))
+        ops.colsum_bf16(dyb, G(p + ".attn.proj.bias"), M, C)
+        dense = P.dense_bias
+        dense.zero_()
+        ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
+                            dense, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
+        ops.bias_table_scatter(dense, self._rel32, G(p + ".attn.relative_position_bias_table"), nh, 16)
+        ops.gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
+                 out=dxn, ldo=C)
+        self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"))
+        ops.colsum_bf16(dqkv, G(p + ".attn.qkv.bias"), M, 3 * C)
+        ops.layernorm_bwd_params(dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], G(p + ".norm1.weight"),
+                                 G(p + ".norm1.bias"), M, C)
+        ops.layernorm_bwd(dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C)
+
+    def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G):
+        for k in reversed(range(len(specs))):
+            xin = stage_in if k == 0 else P[specs[k - 1].prefix + ".out"]
+            self._block_bwd(P, specs[k], xin, dx, G)
+
+    def _unmerge_bwd(self, P: Plan, prefix: str, s: int, dfine, dx_out, G):
+        """Backward of PatchUnmerging from the fine-level grad `dfine` (level s-1 layout) into
+        dx_out (level s, fp32, overwritten)."""
+        m, W_ = self.model, self.params
+        B = P.B
+        H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
+        M = B * H * W
+        dz = P["t.dz2"]
+        ops.unshuffle2_cast(dfine, dz, B, H, W, C // 2)
+        ops.colsum_bf16(dz, G(prefix + ".expand.bias"), M, 2 * C)
+        self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"))
+        ops.gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
+                 out=dx_out, ldo=C)
+
+    def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None):
+        """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
+        (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
+        each parameter group has been *launched* (DDP overlap)."""
+        m, W_ = self.model, self.params
+        B, E, nl = P.B, m.embed_dim, m.num_layers
+        H0, W0 = self.grid
+        gbase = gflat.data_ptr()
+        G = lambda name: gbase + 4 * W_.offset[name]
+        hook = bucket_hook or (lambda tag: None)
+        M0 = B * H0 * W0
+        ops.l1_loss_bwd(P.pred, P.target, gscale_dev, gscale, P.dpred, P.pred.numel())
+        ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
+                     W_.p32("decoder_pred.weight"), P.dpred, P["tail.dz"], G("decoder_pred.weight"), B, H0, W0, E)
+        ops.colsum_bf16(P["tail.dz"], G("ps_head.conv_expand.0.bias"), M0, 16 * E)
+        self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"))
+        ops.gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
+                 epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
+        x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
+        dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
+        ops.layernorm_bwd_params(P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], G("norm_up.weight"),
+                                 G("norm_up.bias"), M0, E)
+        ops.layernorm_bwd(P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx,
+                          M0, E)
+        hook("head")
+        # ---- decoder, fine -> coarse
+        for i in reversed(range(nl - 1)):
+            s = nl - i - 2
+            Cs = E << s
+            Ms = B * (H0 >> s) * (W0 >> s)
+            dx = P[f"dec{s}.dx"]
+            if i < nl - 2:
+                # dx currently holds nothing for this level: pull the grad down from the finer level
+                self._unmerge_bwd(P, f"layers_up.{i}.upsample", s, P[f"dec{s - 1}.dxu"], dx, G)
+            self._stage_bwd(P, self.dec_blocks[i], P[f"dec{s}.in"], dx, G)
+            pre = f"skip_connection_layers.{i}"
+            dys = P[f"dec{s}.dyskip"]
+            ops.cast_f32_bf16(dx, dys, Ms, Cs)
+            ops.colsum_bf16(dys, G(pre + ".bias"), Ms, Cs)
+            self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"))
+            # grad w.r.t. the first concat half (the unmerged stream); the x_save half is deferred
+            ops.gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32,
+                     out=P[f"dec{s}.dxu"], ldo=Cs)
+            hook(f"dec{i}")
+        # ---- bottleneck unmerge
+        dx = P[f"enc{nl - 1}.dx"]
+        if nl > 1:
+            self._unmerge_bwd(P, "first_patch_expanding", nl - 1, P[f"dec{nl - 2}.dxu"], dx, G)
+        # ---- encoder, coarse -> fine
+        for s in reversed(range(nl)):
+            dx = P[f"enc{s}.dx"]
+            self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G)
+            if s < nl - 1:
+                # deferred skip-connection gradient w.r.t. x_save[s] (second concat half, tulip.py:715)
+                Cs = E << s
+                Ms = B * (H0 >> s) * (W0 >> s)
+                i = nl - s - 2
+                ops.gemm(P[f"dec{s}.dyskip"], W_.p16(f"skip_connection_layers.{i}.weight") + 2 * Cs, Ms, Cs, Cs,
+                         lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32, out=dx, ldo=Cs, accumulate=True)
+            if s > 0:
+                # PatchMerging backward of level s-1
+                Cp = E << (s - 1)
+                Hp, Wp = H0 >> (s - 1), W0 >> (s - 1)
+                rows = B * (Hp // 2) * (Wp // 2)
+                pre = f"layers.{s - 1}.downsample"
+                dyb, dxm = P["t.dyb"], P["t.dxm"]
+                ops.cast_f32_bf16(dx, dyb, rows, 2 * Cp)
+                self._wgrad(dyb, 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows,
+                            G(pre + ".reduction.weight"))
+                ops.gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,
+                         b_trans=True, epi=EPI_BF16, out=dxm, ldo=4 * Cp)
+                xprev = P[self.enc_blocks[s - 1][-1].prefix + ".out"]
+                ops.layernorm_bwd_params(dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"],
+                                         G(pre + ".norm.weight"), G(pre + ".norm.bias"), rows, 4 * Cp, merge=True,
+                                         B=B, H=Hp, W=Wp)
+                ops.layernorm_bwd(dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"],
+                                  W_.p32(pre + ".norm.weight"), None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, merge=True,
+                                  B=B, H=Hp, W=Wp)
+            hook(f"enc{s}")
+        kw = 8 if m.circular_padding else m.patch_size[1]
+        ops.patch_embed_bwd(P.x_in, W_.p32("patch_embed.proj.weight"), W_.p32("patch_embed.proj.bias"),
+                            W_.p32("patch_embed.norm.weight"), P["enc0.dx"], G("patch_embed.proj.weight"),
+                            G("patch_embed.proj.bias"), G("patch_embed.norm.weight"), G("patch_embed.norm.bias"), B,
+                            m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
+                            m.circular_padding, self.eps)
+        hook("embed")
+
+    # ------------------------------------------------------------------ autograd bridge
+    def autograd_forward(self, x, target, mc_drop: bool):
+        self.bind(x.device)
+        self.params.shadow_dirty = True  # parameters may have been updated by a foreign optimizer
+        B = x.shape[0]
+        P = self.plan(B)
+        P.x_in.copy_(x.reshape(P.x_in.shape).float())
+        if mc_drop or target is None:
+            self.draw_drop_scales(P, self.model.training)
+            self.run_forward(P, with_loss=False)
+            return P.pred.clone()
+        P.target.copy_(target.reshape(P.target.shape).float())
+        self.draw_drop_scales(P, self.model.training)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
+        if not need_grad:
+            self.run_forward(P)
+            return P.pred.clone(), P.losses[0].clone(), P.losses[1].clone()
+        params = [p for _, p in sorted(self.model.named_parameters(), key=lambda kv: self.params.offset[kv[0]])]
+        return _TulipFn.apply(self, P, *params)
+
+
+class _TulipFn(torch.autograd.Function):
+    """loss.backward() support: one autograd node for the whole network."""
+
+    @staticmethod
+    def forward(ctx, eng: TulipEngine, P: Plan, *params):
+        eng.run_forward(P)
+        ctx.eng, ctx.P, ctx.gen = eng, P, P.generation
+        pred = P.pred.clone()
+        ctx.mark_non_differentiable(pred)
+        return pred, P.losses[0].clone(), P.losses[1].clone()
+
+    @staticmethod
+    def backward(ctx, _dpred, dloss, _dpixel):
+        eng, P = ctx.eng, ctx.P
+        if ctx.gen != P.generation:
+            raise RuntimeError("tulip_amd: backward() must follow its own forward() (activation workspaces are "
+                               "reused by the next forward of the same batch size)")
+        W_ = eng.params
+        gflat = torch.zeros(W_.total, dtype=torch.float32, device=eng.device)
+        g = dloss.detach().float().reshape(1).contiguous() if dloss is not None else None
+        eng.run_backward(P, gflat, gscale_dev=g, gscale=1.0)
+        grads = tuple(gflat[W_.offset[n]:W_.offset[n] + W_.numel[n]].view(W_.shape[n]) for n in W_.names)
+        return (None, None) + grads

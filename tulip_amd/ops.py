@@ -14,8 +14,11 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
-def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+def _p(t):
+    """tensor -> device address; ints (precomputed addresses) and None pass through."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
 
 
 def _stream():
@@ -129,6 +132,6 @@ def l1_loss_bwd(pred, target, gscale_dev, gscale, dpred, n):
                                         _stream()), "tulip_l1_loss_bwd")
 
 
-def adamw(p, g, m, v, p_bf16, n, hyper, wd_mult):
-    check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), float(wd_mult), _stream()),
+def adamw(p, g, m, v, p_bf16, n, hyper, decay_mask64=None):
+    check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _p(decay_mask64), _stream()),
           "tulip_adamw")
