@@ -62,7 +62,7 @@ class FlatParams:
     def __init__(self, model, device):
         self.device = device
         named = dict(model.named_parameters())
-        order = self._completion_order(model, named)
+        order, marks = self._completion_order(model, named)
         assert sorted(order) == sorted(named.keys())
         self.names: List[str] = order
         self.offset: Dict[str, int] = {}
@@ -74,6 +74,10 @@ class FlatParams:
             self.offset[n], self.numel[n], self.shape[n] = off, p.numel(), tuple(p.shape)
             off = _ceil(off + p.numel(), ALIGN)
         self.total = off
+        # backward-completion groups: (tag, end offset) -- run_backward fires bucket_hook(tag) once every
+        # gradient in [previous end, end) has been launched
+        self.groups: List[Tuple[str, int]] = [
+            (tag, self.offset[order[cnt]] if cnt < len(order) else self.total) for tag, cnt in marks]
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
         mask = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
@@ -96,6 +100,7 @@ class FlatParams:
     def _completion_order(model, named) -> List[str]:
         nl = model.num_layers
         order: List[str] = []
+        marks: List[Tuple[str, int]] = []
 
         def add(prefix):
             ks = [k for k in named if k.startswith(prefix)]
@@ -108,17 +113,21 @@ class FlatParams:
                     add(f"{prefix}.blocks.{b}.{sub}")
 
         add("decoder_pred."); add("ps_head."); add("norm_up.")
+        marks.append(("head", len(order)))
         for i in reversed(range(nl - 1)):
             add(f"layers_up.{i}.upsample.")
             blocks_rev(f"layers_up.{i}", model.depths[nl - i - 2])
             add(f"skip_connection_layers.{i}.")
+            marks.append((f"dec{i}", len(order)))
         add("first_patch_expanding.")
         for s in reversed(range(nl)):
             blocks_rev(f"layers.{s}", model.depths[s])
             if s > 0:
                 add(f"layers.{s - 1}.downsample.")
+            marks.append((f"enc{s}", len(order)))
         add("patch_embed.")
-        return order
+        marks.append(("embed", len(order)))
+        return order, marks
 
     def p32(self, name: str) -> int:
         return self.base32 + 4 * self.offset[name]
