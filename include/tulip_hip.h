@@ -35,17 +35,35 @@ typedef struct ihipStream_t* hipStream_t;
 #define TULIP_EPI_F32 3          /* out_f32 (+)= acc + bias                                             */
 #define TULIP_EPI_RESID_F32 4    /* out_f32 = aux_f32 + rowscale[m/rows_per_sample]*(acc+bias) (tulip.py:343-344,350-351) */
 #define TULIP_EPI_PIXSHUF2_F32 5 /* PatchUnmerging scatter: PixelShuffle(2) + BCHW->BHWC (tulip.py:120-122) */
-#define TULIP_EPI_ATOMIC_F32 6   /* out_f32 += acc (split-K weight gradients)                           */
+#define TULIP_EPI_ATOMIC_F32 6   /* out_f32 += acc (split-K weight gradients, atomics)                  */
+#define TULIP_EPI_SPLIT_F32 7    /* out_f32[split][M][ldo] = acc : split-K partial slabs (deterministic) */
 
 /* C[M,N] = opA[M,K] . opB[N,K]^T, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
  * a_trans=0: A is [M][lda]; a_trans=1: A is [K][lda] (A^T stored).  Same for B ([N][ldb] / [K][ldb]).
  * Replaces nn.Linear / 1x1 nn.Conv2d forward (tulip.py:298,318,195,198,105,119,716,175) and their
  * autograd dgrad/wgrad.  Requirements: K%8==0, N%4==0, lda%8==0, ldb%8==0 (and M%8 / N%8 for the
- * transposed operands).  splits>1 only with TULIP_EPI_ATOMIC_F32. */
+ * transposed operands).  splits>1 only with TULIP_EPI_SPLIT_F32 / TULIP_EPI_ATOMIC_F32.
+ * Weight-gradient form (a_trans=1, epi SPLIT_F32 or F32): if out2 != NULL it additionally receives
+ * the row sums of opA, i.e. sum over tokens of dY = the bias gradient, as fp32 [splits][M] (SPLIT) or
+ * [M] (F32, += when accumulate) -- computed by one extra MFMA per fragment against an all-ones operand. */
 int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,
                     int epi, const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                     const float* rowscale, int rows_per_sample, int accumulate, int psH, int psW, int splits,
                     hipStream_t stream);
+
+/* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
+int tulip_gemm_effective_splits(int K, int splits);
+
+/* REDUCTIONS.  No kernel in this library funnels many workgroups into same-address atomics (on gfx950 a
+ * chain of same-address device-scope fp32 atomics costs ~0.1-0.5 us per link).  Every cross-workgroup sum
+ * (split-K weight gradients, bias / LayerNorm / relative-position-bias / patch-embed / decoder_pred
+ * gradients) is written as per-workgroup PARTIAL ROWS with plain stores and folded, deterministically, by:
+ *   out_r[i] += sum_{s<nrows} part_r[s*stride_r + i],  i < n_r,   for two regions r = 0,1 in one launch.
+ * n, stride multiples of 4; a region with n<=0 is skipped. */
+int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
+                       int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream);
+/* out[i] += sum_s slabs[s*n + i]  (= tulip_reduce_rows2 with one region of stride n) */
+int tulip_reduce_splits(const float* slabs, float* out, int64_t n, int splits, hipStream_t stream);
 
 /* LayerNorm over the last dim of an fp32 stream tensor -> bf16 (the next op is always a GEMM).
  * merge=0: x is [rows][C].  merge=1 (PatchMerging, tulip.py:92-105): x is (B,H,W,C/4) and row
@@ -55,12 +73,16 @@ int tulip_layernorm_fwd(const float* x, const float* gamma, const float* beta, u
                         int rows, int C, float eps, int merge, int B, int H, int W, hipStream_t stream);
 
 /* dx = dres + LayerNorm-backward(dy) in the layout of x (scatter for merge=1).  dres may be NULL
- * (treated as zero) or alias dx. */
+ * (treated as zero) or alias dx.  param_partials (may be NULL): receives
+ * tulip_layernorm_bwd_partial_rows(rows, C) partial rows of [dgamma[C] | dbeta[C]] (stride 2C), to be
+ * folded with tulip_reduce_rows2 -- the parameter gradients cost no second pass over dy and x. */
 int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, int rows, int C, int merge, int B, int H, int W,
-                        hipStream_t stream);
+                        float* param_partials, hipStream_t stream);
+/* partial rows tulip_layernorm_bwd writes for (rows, C); 0 if C is too wide for the fused form (C > 2048) */
+int tulip_layernorm_bwd_partial_rows(int rows, int C);
 
-/* dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy   (atomic accumulation into fp32) */
+/* stand-alone dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy (atomic; only for C > 2048) */
 int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, const float* mean, const float* rstd, float* dgamma,
                                float* dbeta, int rows, int C, int merge, int B, int H, int W, hipStream_t stream);
 
@@ -69,10 +91,13 @@ int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, const float* 
 int tulip_patch_embed_fwd(const float* img, const float* w, const float* b, const float* gamma, const float* beta,
                           float* out, int B, int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular,
                           float eps, hipStream_t stream);
-/* parameter gradients of the above (the input image needs no gradient); accumulates atomically. */
+/* parameter gradients of the above (the input image needs no gradient).  partial_stride > 0: dw/db/dgamma/
+ * dbeta point into row 0 of a [tulip_patch_embed_bwd_blocks(ntok)][partial_stride] partial buffer (plain
+ * stores; fold with tulip_reduce_rows2); partial_stride == 0: accumulate atomically into the gradients. */
 int tulip_patch_embed_bwd(const float* img, const float* w, const float* b, const float* gamma, const float* dout,
                           float* dw, float* db, float* dgamma, float* dbeta, int B, int Cin, int Hin, int Win, int E,
-                          int p0, int p1, int kw, int circular, float eps, hipStream_t stream);
+                          int p0, int p1, int kw, int circular, float eps, int partial_stride, hipStream_t stream);
+int tulip_patch_embed_bwd_blocks(int ntok);
 
 /* Shifted-window attention core (tulip.py:289-323 minus the two Linears): cyclic shift, window
  * partition, q*scale, QK^T, + relative-position bias gathered through rel_index, + shift mask
@@ -83,10 +108,13 @@ int tulip_patch_embed_bwd(const float* img, const float* w, const float* b, cons
  * masked!=0 for shifted blocks. */
 int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_table, const int32_t* rel_index, uint16_t* out, int B,
                           int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream);
-/* dqkv from dout; d(bias) accumulated densely into dbias_dense[nh][L][L] (fp32, atomic). */
+/* dqkv from dout.  d(bias) leaves as R = tulip_window_attn_bwd_partial_rows(...) partial rows per head:
+ * dbias_partials[(j*nh + h)*256 + i*16 + k], j < R  ==  a [R][nh*256] matrix whose column sums are the dense
+ * [nh][16][16] gradient (fold with tulip_reduce_rows2, then tulip_bias_table_scatter). */
 int tulip_window_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* bias_table, const int32_t* rel_index,
-                          uint16_t* dqkv, float* dbias_dense, int B, int H, int W, int C, int nh, int wh, int ww,
+                          uint16_t* dqkv, float* dbias_partials, int B, int H, int W, int C, int nh, int wh, int ww,
                           int sh, int sw, int masked, hipStream_t stream);
+int tulip_window_attn_bwd_partial_rows(int B, int H, int W, int nh, int wh, int ww);
 /* dtable[rel_index[i][j]][h] += dbias_dense[h][i][j]  (tulip.py:304-308 backward) */
 int tulip_bias_table_scatter(const float* dbias_dense, const int32_t* rel_index, float* dtable, int nh, int L,
                              hipStream_t stream);
@@ -98,6 +126,10 @@ int tulip_cast_f32_bf16(const float* x, uint16_t* y, int rows, int cols, const f
 int tulip_concat_cast(const float* a, const float* b, uint16_t* out, int rows, int C, hipStream_t stream);
 /* inverse of the PatchUnmerging scatter: dz[(b,h,w)][4c+2i+j] = bf16(dx[b,2h+i,2w+j,c]); dx is (B,2H,2W,C2) */
 int tulip_unshuffle2_cast(const float* dx, uint16_t* dz, int B, int H, int W, int C2, hipStream_t stream);
+/* y = bf16(x*rowscale) as tulip_cast_f32_bf16 AND colsum[c] += sum_rows x[r][c]*rowscale  (bias gradient of
+ * the residual-branch Linears: the cast of the stream gradient and its column sum in one pass) */
+int tulip_cast_colsum(const float* x, uint16_t* y, float* colsum, int rows, int cols, const float* rowscale,
+                      int rows_per_sample, hipStream_t stream);
 /* out[c] += sum_rows x[r][c]   (bias gradients) */
 int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream);
 /* flat fp32 -> bf16 copy (weight shadow refresh) */
@@ -108,9 +140,11 @@ int tulip_cast_flat(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
  * (B,16E,H,W) intermediate (100 MB at B=8) is never materialised.  upscale factor 4, in_chans 1. */
 int tulip_tail_fwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, float* pred, int B, int H,
                    int W, int E, hipStream_t stream);
-/* backward of the head w.r.t. the expand pre-activation: dz[B*H*W][16E] (bf16) and dwd[E] (+=). */
+/* backward of the head w.r.t. the expand pre-activation: dz[B*H*W][16E] (bf16), and decoder_pred's weight
+ * gradient as ceil(B*H*W/128) partial rows dwd_partials[row][128] (first E valid; fold with
+ * tulip_reduce_rows2). */
 int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
-                   uint16_t* dz, float* dwd, int B, int H, int W, int E, hipStream_t stream);
+                   uint16_t* dz, float* dwd_partials, int B, int H, int W, int E, hipStream_t stream);
 
 /* forward_loss (tulip.py:690-700): losses[0]=mean|pred-target|, losses[1]=mean|expm1(pred)-expm1(target)|
  * (or a copy of losses[0] when log_transform==0).  partials: scratch of 2*1024 floats. Deterministic. */

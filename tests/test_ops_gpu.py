@@ -120,6 +120,45 @@ def test_gemm_wgrad_tn_splitk(ops, M, Nw, Kw, splits):
     close(dW, dY.float().t() @ X.float(), 1e-4, 2e-4, "wgrad")
 
 
+@pytest.mark.parametrize("M,Nw,Kw,splits", [(4096, 288, 96, 16), (32768, 96, 192, 128), (512, 2304, 768, 2),
+                                            (1000, 48, 144, 4)])
+def test_gemm_wgrad_split_slabs(ops, M, Nw, Kw, splits):
+    """deterministic split-K: partial slabs + tulip_reduce_splits accumulate into an existing gradient"""
+    dY, X = bf(rnd(M, Nw)), bf(rnd(M, Kw, seed=7))
+    eff = ops.gemm_effective_splits(M, splits)
+    assert 1 <= eff <= splits and ops.gemm_effective_splits(M, eff) == eff
+    ws = torch.full((eff, Nw, Kw), float("nan"), device=DEV)
+    ops.gemm(dY, X, Nw, Kw, M, lda=Nw, ldb=Kw, a_trans=True, b_trans=True, epi=ops.EPI_SPLIT_F32, out=ws, ldo=Kw,
+             splits=eff)
+    assert torch.isfinite(ws).all()                              # every slab fully written
+    g0 = rnd(Nw, Kw, seed=11)
+    g = g0.clone()
+    ops.reduce_splits(ws, g, Nw * Kw, eff)
+    close(g, g0 + dY.float().t() @ X.float(), 1e-4, 2e-4, "wgrad slabs")
+    g2 = g0.clone()
+    ops.gemm(dY, X, Nw, Kw, M, lda=Nw, ldb=Kw, a_trans=True, b_trans=True, epi=ops.EPI_SPLIT_F32, out=ws, ldo=Kw,
+             splits=eff)
+    ops.reduce_splits(ws, g2, Nw * Kw, eff)
+    assert torch.equal(g, g2)                                    # bit-reproducible
+
+
+def test_cast_colsum(ops):
+    for (rows, cols, rps) in [(96, 192, 32), (32768, 96, 4096), (512, 768, 64), (40, 48, 8)]:
+        x = rnd(rows, cols)
+        rs = (torch.arange(rows // rps, device=DEV) % 3).float() * 0.625
+        y = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+        cs0 = rnd(cols, seed=3)
+        cs = cs0.clone()
+        ops.cast_colsum(x, y, cs, rows, cols, rs, rps)
+        xs = x * rs.repeat_interleave(rps)[:, None]
+        assert torch.equal(y, bf(xs))
+        close(cs, cs0 + xs.sum(0), 1e-4, 1e-5, "cast_colsum")
+        cs = torch.zeros(cols, device=DEV)
+        ops.cast_colsum(x, y, cs, rows, cols)
+        assert torch.equal(y, bf(x))
+        close(cs, x.sum(0), 1e-4, 1e-5, "cast_colsum noscale")
+
+
 def test_gemm_strided_views(ops):
     # skip-connection dgrad: two column halves of W through pointer offsets (ldb = 2C)
     M, C = 128, 96
@@ -211,6 +250,20 @@ def test_patch_embed(ops, circular, E, Hin, Win):
     ops.patch_embed_bwd(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], sd["patch_embed.norm.weight"],
                         dout, dw, db, dg, dbe, B, 1, Hin, Win, E, 1, 4, kw, circular, 1e-6)
     close(dw, sdr["patch_embed.proj.weight"].grad, 2e-3, 2e-4, "embed dw")
+    # partial-row mode: rows laid out [w | b | gamma | beta], folded by reduce_rows2
+    ntok = B * Hin * (Win // 4)
+    nb, stride = ops.patch_embed_bwd_blocks(ntok), E * kw + 3 * E
+    part = torch.zeros(nb, stride, device=DEV)
+    base = part.data_ptr()
+    ops.patch_embed_bwd(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], sd["patch_embed.norm.weight"],
+                        dout, base, base + 4 * E * kw, base + 4 * (E * kw + E), base + 4 * (E * kw + 2 * E), B, 1, Hin,
+                        Win, E, 1, 4, kw, circular, 1e-6, partial_stride=stride)
+    tot = torch.zeros(stride, device=DEV)
+    ops.reduce_rows2(part, stride, tot, stride, None, 0, None, 0, nb)
+    close(tot[:E * kw], sdr["patch_embed.proj.weight"].grad.reshape(-1), 2e-3, 2e-4, "embed dw (partials)")
+    close(tot[E * kw:E * kw + E], sdr["patch_embed.proj.bias"].grad, 2e-3, 2e-4, "embed db (partials)")
+    close(tot[E * kw + E:E * kw + 2 * E], sdr["patch_embed.norm.weight"].grad, 2e-3, 2e-4, "embed dgamma (partials)")
+    close(tot[E * kw + 2 * E:], sdr["patch_embed.norm.bias"].grad, 2e-3, 2e-4, "embed dbeta (partials)")
     close(db, sdr["patch_embed.proj.bias"].grad, 2e-3, 2e-4, "embed db")
     close(dg, sdr["patch_embed.norm.weight"].grad, 2e-3, 2e-4, "embed dgamma")
     close(dbe, sdr["patch_embed.norm.bias"].grad, 2e-3, 2e-4, "embed dbeta")
@@ -257,12 +310,62 @@ def test_window_attention_fwd_bwd(ops, B, H, W, C, nh, shift):
     dout = bf(rnd(M, C, seed=3))
     ref.backward(dout.float())
     dqkv = torch.empty_like(qkv)
-    dense = torch.zeros(nh, 16, 16, device=DEV)
-    ops.window_attn_bwd(qkv, dout, table, rel32, dqkv, dense, B, H, W, C, nh, win, sft, shift)
+    R = ops.window_attn_bwd_partial_rows(B, H, W, nh, win)
+    part = torch.full((R * nh, 256), float("nan"), device=DEV)
+    ops.window_attn_bwd(qkv, dout, table, rel32, dqkv, part, B, H, W, C, nh, win, sft, shift)
     close(dqkv, qr.grad, 2 ** -5, 6e-3, "attn dqkv")
+    assert torch.isfinite(part).all()
+    dense = torch.zeros(nh, 16, 16, device=DEV)
+    ops.reduce_rows2(part, nh * 256, dense, nh * 256, None, 0, None, 0, R)
+    close(dense.reshape(-1), part.view(R, nh * 256).sum(0), 1e-5, 1e-6, "bias partial fold")
     dtab = torch.zeros(45, nh, device=DEV)
     ops.bias_table_scatter(dense, rel32, dtab, nh, 16)
     close(dtab, tr.grad, 2e-2, 5e-3, "attn dtable")
+
+
+def test_layernorm_bwd_fused_param_partials(ops):
+    for (rows, C) in [(1000, 96), (32768, 96), (2048, 384), (512, 768), (64, 1536), (40, 48)]:
+        x = rnd(rows, C) + 0.3
+        gamma = 1 + 0.1 * rnd(C, seed=1)
+        y = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+        mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        ops.layernorm_fwd(x, gamma, torch.zeros(C, device=DEV), y, mean, rstd, rows, C, 1e-6)
+        dy = bf(rnd(rows, C, seed=3))
+        nrows = ops.layernorm_bwd_partial_rows(rows, C)
+        assert 0 < nrows <= 512
+        part = torch.full((nrows, 2 * C), float("nan"), device=DEV)
+        dx = torch.empty_like(x)
+        ops.layernorm_bwd(dy, x, mean, rstd, gamma, None, dx, rows, C, param_partials=part)
+        dx_ref = torch.empty_like(x)
+        ops.layernorm_bwd(dy, x, mean, rstd, gamma, None, dx_ref, rows, C)
+        assert torch.equal(dx, dx_ref) and torch.isfinite(part).all()
+        dg, db = rnd(C, seed=5), rnd(C, seed=6)
+        dg0, db0 = dg.clone(), db.clone()
+        ops.reduce_rows2(part, 2 * C, dg, C, part[:, C:], 2 * C, db, C, nrows)
+        xh = (x - mean[:, None]) * rstd[:, None]
+        close(dg, dg0 + (dy.float() * xh).sum(0), 1e-4, 1e-5, "fused dgamma")
+        close(db, db0 + dy.float().sum(0), 1e-4, 1e-5, "fused dbeta")
+    assert ops.layernorm_bwd_partial_rows(16, 6144) == 0
+
+
+@pytest.mark.parametrize("M,Nw,Kw,splits", [(4096, 288, 96, 16), (256, 96, 96, 1), (32768, 1536, 96, 40), (1000, 48, 144, 4)])
+def test_gemm_wgrad_bias_rowsum(ops, M, Nw, Kw, splits):
+    dY, X = bf(rnd(M, Nw)), bf(rnd(M, Kw, seed=7))
+    eff = ops.gemm_effective_splits(M, splits)
+    gw, gb = rnd(Nw, Kw, seed=1), rnd(Nw, seed=2)
+    gw0, gb0 = gw.clone(), gb.clone()
+    if eff == 1:
+        ops.gemm(dY, X, Nw, Kw, M, lda=Nw, ldb=Kw, a_trans=True, b_trans=True, epi=ops.EPI_F32, out=gw, ldo=Kw,
+                 accumulate=True, out2=gb)
+    else:
+        ws = torch.full((eff * Nw * Kw + eff * Nw,), float("nan"), device=DEV)
+        wsb = ws[eff * Nw * Kw:]
+        ops.gemm(dY, X, Nw, Kw, M, lda=Nw, ldb=Kw, a_trans=True, b_trans=True, epi=ops.EPI_SPLIT_F32, out=ws, ldo=Kw,
+                 splits=eff, out2=wsb)
+        assert torch.isfinite(ws).all()
+        ops.reduce_rows2(ws, Nw * Kw, gw, Nw * Kw, wsb, Nw, gb, Nw, eff)
+    close(gw, gw0 + dY.float().t() @ X.float(), 1e-4, 2e-4, "wgrad")
+    close(gb, gb0 + dY.float().sum(0), 1e-4, 2e-4, "bias grad from wgrad")
 
 
 # ------------------------------------------------------------------ casts / reductions
@@ -316,8 +419,10 @@ def test_tail_fwd_bwd(ops, B, H, W, E):
     dpred = rnd(B, 1, 4 * H, 4 * W, seed=4)
     ref.backward(dpred)
     dz = torch.empty(M, 16 * E, dtype=torch.bfloat16, device=DEV)
+    dpart = torch.full(((M + 127) // 128, 128), float("nan"), device=DEV)
+    ops.tail_bwd(xn, We, be, wd, dpred, dz, dpart, B, H, W, E)
     dwd = torch.zeros(E, device=DEV)
-    ops.tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E)
+    ops.reduce_rows2(dpart, 128, dwd, E, None, 0, None, 0, dpart.shape[0])
     close(dwd, sd["decoder_pred.weight"].grad.reshape(E), 1e-3, 1e-4, "tail dwd")
     # dz is d(loss)/d(expand pre-activation): check through its three consumers
     dzf = dz.float()

@@ -18,17 +18,24 @@ P, I, F, L = c_void_p, c_int, c_float, c_int64
 SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
-    "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P],
+    "tulip_layernorm_bwd_partial_rows": [I, I],
     "tulip_layernorm_bwd_params": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],
-    "tulip_patch_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],
+    "tulip_patch_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
+    "tulip_patch_embed_bwd_blocks": [I],
     "tulip_window_attn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "tulip_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "tulip_window_attn_bwd_partial_rows": [I, I, I, I, I, I],
     "tulip_bias_table_scatter": [P, P, P, I, I, P],
     "tulip_cast_f32_bf16": [P, P, I, I, P, I, P],
     "tulip_concat_cast": [P, P, P, I, I, P],
     "tulip_unshuffle2_cast": [P, P, I, I, I, I, P],
     "tulip_colsum_bf16": [P, P, I, I, P],
+    "tulip_cast_colsum": [P, P, P, I, I, P, I, P],
+    "tulip_reduce_splits": [P, P, L, I, P],
+    "tulip_reduce_rows2": [P, L, P, L, P, L, P, L, I, P],
+    "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],
     "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
@@ -39,7 +46,8 @@ SIGNATURES = {
     "tulip_build_arch": [],
 }
 
-EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, EPI_ATOMIC_F32 = range(7)
+(EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, EPI_ATOMIC_F32,
+ EPI_SPLIT_F32) = range(8)
 
 _lib = None
 

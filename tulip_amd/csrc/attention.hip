@@ -135,16 +135,21 @@ template <int P>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                        const float* __restrict__ bias_table,
                                                        const int* __restrict__ rel_index, bf16_t* __restrict__ dqkv,
-                                                       float* dbias_dense, AttnGeom g, int ngrp) {
+                                                       float* dbias_part, AttnGeom g, int ngrp) {
+    // All 4 waves of a workgroup serve the SAME head (blockIdx.x % nh), so d(bias) is summed over the
+    // workgroup in LDS and leaves as one plain 256-float partial row per workgroup:
+    // dbias_part[blockIdx.x][i*16+j].  Rows of one head are nh apart -> viewed as [gridDim.x/nh][nh*256]
+    // the partials fold into the dense [nh][16][16] gradient with a single row reduction.
     constexpr int TILE = 16 * P * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 3 * TILE];
-    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4;
-    unsigned char* ldsQ = smem + (threadIdx.x >> 6) * (3 * TILE);
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4, wid = threadIdx.x >> 6;
+    unsigned char* ldsQ = smem + wid * (3 * TILE);
     unsigned char* ldsK = ldsQ + TILE;
     unsigned char* ldsD = ldsK + TILE;
-    const WaveMap wm = wave_map(g.nh, ngrp);
-    if (wm.grp >= ngrp) return;
-    const int h = wm.h;
+    const int h = blockIdx.x % g.nh;
+    WaveMap wm;
+    wm.h = h; wm.grp = (blockIdx.x / g.nh) * 4 + wid; wm.ngrp = ngrp;
     const int nW = g.nWy * g.nWx, total = g.B * nW;
     const bool dvalid = gq * 8 < P;
     const int C3 = 3 * g.C;
@@ -235,9 +240,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
             store4(dst + 2 * g.C + dc * 16, dv, 1.0f);
         }
     }
-    float* db = dbias_dense + (size_t)h * 256 + li * 16 + gq * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(db + r, dbacc[r]);
+    for (int r = 0; r < 4; ++r) red[wid][li * 16 + gq * 4 + r] = dbacc[r];
+    __syncthreads();
+    dbias_part[(size_t)blockIdx.x * 256 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void bias_scatter_kernel(const float* __restrict__ dense, const int* __restrict__ rel_index, float* dtable,
@@ -261,7 +268,7 @@ bool make_geom(AttnGeom& g, int B, int H, int W, int C, int nh, int wh, int ww, 
 
 int pick_groups(const AttnGeom& g) {
     const int total = g.B * g.nWy * g.nWx;
-    int ngrp = (256 * 8 + g.nh - 1) / g.nh;  // ~8 waves per CU
+    int ngrp = (256 * 16 + g.nh - 1) / g.nh;  // ~16 waves per CU
     if (ngrp > total) ngrp = total;
     if (ngrp < 1) ngrp = 1;
     return ngrp;
@@ -287,20 +294,34 @@ extern "C" int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_tabl
     return TULIP_OK;
 }
 
+// workgroups per head of the backward launch (each emits one 256-float d(bias) partial row)
+static int bwd_blocks_per_head(int windows_total, int nh) {
+    int ngrp = (256 * 8 + nh - 1) / nh;  // ~8 waves per CU
+    if (ngrp > windows_total) ngrp = windows_total;
+    if (ngrp < 1) ngrp = 1;
+    return (ngrp + 3) / 4;
+}
+
+extern "C" int tulip_window_attn_bwd_partial_rows(int B, int H, int W, int nh, int wh, int ww) {
+    if (B <= 0 || nh <= 0 || wh <= 0 || ww <= 0) return 0;
+    return bwd_blocks_per_head(B * (H / wh) * (W / ww), nh);
+}
+
 extern "C" int tulip_window_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* bias_table,
-                                     const int32_t* rel_index, uint16_t* dqkv, float* dbias_dense, int B, int H, int W,
-                                     int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream) {
+                                     const int32_t* rel_index, uint16_t* dqkv, float* dbias_partials, int B, int H,
+                                     int W, int C, int nh, int wh, int ww, int sh, int sw, int masked,
+                                     hipStream_t stream) {
     AttnGeom g;
     if (!make_geom(g, B, H, W, C, nh, wh, ww, sh, sw, masked)) return TULIP_ERR_ARG;
     if (B <= 0) return TULIP_OK;
-    const int ngrp = pick_groups(g);
-    const int blocks = (ngrp * nh + 3) / 4;
+    const int bph = bwd_blocks_per_head(g.B * g.nWy * g.nWx, nh);
+    const int blocks = bph * nh, ngrp = bph * 4;
     if (C / nh == 32)
         hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(blocks), dim3(256), 0, stream, qkv, dout, bias_table, rel_index,
-                           dqkv, dbias_dense, g, ngrp);
+                           dqkv, dbias_partials, g, ngrp);
     else
         hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(blocks), dim3(256), 0, stream, qkv, dout, bias_table, rel_index,
-                           dqkv, dbias_dense, g, ngrp);
+                           dqkv, dbias_partials, g, ngrp);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

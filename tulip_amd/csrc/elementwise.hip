@@ -59,9 +59,16 @@ __global__ __launch_bounds__(256) void unshuffle2_kernel(const float* __restrict
     }
 }
 
-// out[c] += sum_r x[r][c]; thread = 8-column chunk, TPR chunks per row-slab, 256/TPR row lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* out, int rows, int cols,
-                                                     int tpr_log2, int rows_per_block) {
+// Column sums.  thread = one 8-column chunk (tx) x one row lane (ty); each thread keeps UNR
+// independent 16/32-byte loads in flight (the loop is latency-bound otherwise), block-level LDS
+// reduce over the row lanes, one atomicAdd per column per block.
+// F32IN: x is fp32 [rows][cols], optionally scaled per sample, and is ALSO written out as bf16 (the
+// stream-gradient cast feeding the residual-branch dgrad/wgrad GEMMs).
+template <bool F32IN>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ xin, bf16_t* __restrict__ y, float* out,
+                                                     int rows, int cols, int tpr_log2, int rows_per_block,
+                                                     const float* __restrict__ rowscale, int rows_per_sample) {
+    constexpr int UNR = 4;
     __shared__ float red[8][256];
     const int TPR = 1 << tpr_log2;
     const int tx = threadIdx.x & (TPR - 1), ty = threadIdx.x >> tpr_log2;
@@ -71,12 +78,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < nch) {
         const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-        for (int r = r0 + ty; r < r1; r += RL) {
-            const uint4 v = *(const uint4*)(x + (size_t)r * cols + c * 8);
-            a[0] += bf2f((bf16_t)(v.x & 0xffff)); a[1] += bf2f((bf16_t)(v.x >> 16));
-            a[2] += bf2f((bf16_t)(v.y & 0xffff)); a[3] += bf2f((bf16_t)(v.y >> 16));
-            a[4] += bf2f((bf16_t)(v.z & 0xffff)); a[5] += bf2f((bf16_t)(v.z >> 16));
-            a[6] += bf2f((bf16_t)(v.w & 0xffff)); a[7] += bf2f((bf16_t)(v.w >> 16));
+        for (int rb = r0 + ty; rb < r1; rb += RL * UNR) {
+            if (F32IN) {
+                float4 lo[UNR], hi[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int r = rb + u * RL;
+                    if (r < r1) {
+                        const float* px = (const float*)xin + (size_t)r * cols + c * 8;
+                        lo[u] = *(const float4*)px; hi[u] = *(const float4*)(px + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int r = rb + u * RL;
+                    if (r < r1) {
+                        const float sc = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
+                        const float v[8] = {lo[u].x * sc, lo[u].y * sc, lo[u].z * sc, lo[u].w * sc,
+                                            hi[u].x * sc, hi[u].y * sc, hi[u].z * sc, hi[u].w * sc};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) a[i] += v[i];
+                        *(uint4*)(y + (size_t)r * cols + c * 8) =
+                            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                       pack_bf16x2(v[6], v[7]));
+                    }
+                }
+            } else {
+                uint4 v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int r = rb + u * RL;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    if (r < r1) v[u] = *(const uint4*)((const bf16_t*)xin + (size_t)r * cols + c * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    a[0] += bf2f((bf16_t)(v[u].x & 0xffff)); a[1] += bf2f((bf16_t)(v[u].x >> 16));
+                    a[2] += bf2f((bf16_t)(v[u].y & 0xffff)); a[3] += bf2f((bf16_t)(v[u].y >> 16));
+                    a[4] += bf2f((bf16_t)(v[u].z & 0xffff)); a[5] += bf2f((bf16_t)(v[u].z >> 16));
+                    a[6] += bf2f((bf16_t)(v[u].w & 0xffff)); a[7] += bf2f((bf16_t)(v[u].w >> 16));
+                }
+            }
         }
     }
 #pragma unroll
@@ -85,10 +127,61 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     if (ty == 0 && c < nch) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float s = 0.f;
-            for (int k = 0; k < RL; ++k) s += red[i][(k << tpr_log2) + tx];
-            atomicAdd(out + c * 8 + i, s);
+            float sum = 0.f;
+            for (int k = 0; k < RL; ++k) sum += red[i][(k << tpr_log2) + tx];
+            atomicAdd(out + c * 8 + i, sum);
         }
+    }
+}
+
+// Deterministic fold of per-workgroup partial rows (no atomics anywhere on this path: on gfx950 a chain
+// of same-address device-scope fp32 atomics costs ~0.1-0.5 us per link, which dominated the first
+// version of every reduction here):   out_r[i] += sum_{s<S} part_r[s*stride_r + i]   for two regions r.
+// Block = (256/RL) float4 column-threads x RL row lanes, 4 independent loads in flight per thread.
+struct ReduceRegion {
+    const float* part;
+    float* out;
+    int64_t stride;  // floats between partial rows
+    int64_t n4;      // float4 columns
+    int nblocks;
+};
+template <int RL>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(ReduceRegion r0, ReduceRegion r1, int S) {
+    constexpr int CT = 256 / RL;
+    __shared__ float4 red[RL > 1 ? 256 : 1];
+    const bool first = (int)blockIdx.x < r0.nblocks;
+    const ReduceRegion& r = first ? r0 : r1;
+    const int blk = first ? blockIdx.x : blockIdx.x - r0.nblocks;
+    const int ct = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int64_t col = (int64_t)blk * CT + ct;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < r.n4) {
+        const float* base = r.part + col * 4;
+        for (int s = rl; s < S; s += RL * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ss = s + u * RL;
+                v[u] = ss < S ? *(const float4*)(base + (int64_t)ss * r.stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    if (RL > 1) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0 && col < r.n4) {
+            for (int k = 1; k < RL; ++k) {
+                const float4 v = red[k * CT + ct];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    if (rl == 0 && col < r.n4) {
+        float4 o = *(const float4*)(r.out + col * 4);
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *(float4*)(r.out + col * 4) = o;
     }
 }
 
@@ -213,22 +306,65 @@ extern "C" int tulip_unshuffle2_cast(const float* dx, uint16_t* dz, int B, int H
     return TULIP_OK;
 }
 
-extern "C" int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream) {
-    if (rows <= 0 || cols <= 0) return TULIP_OK;
-    if (cols & 7) return TULIP_ERR_ARG;
+static void colsum_grid(int rows, int cols, int& tpr_log2, dim3& grid, int& rows_per_block) {
     const int nch = cols >> 3;
-    int tpr_log2 = 3;
+    tpr_log2 = 3;
     while ((1 << tpr_log2) < nch && tpr_log2 < 6) ++tpr_log2;
     const int TPR = 1 << tpr_log2;
     const int gx = (nch + TPR - 1) / TPR;
-    int gy = (rows + 63) / 64;
-    if (gy > 1024 / gx) gy = 1024 / gx;
+    const int RL = 256 >> tpr_log2;
+    int gy = (rows + RL * 4 - 1) / (RL * 4);      // >= one 4-deep unrolled pass per thread
+    if (gy > 2048 / gx) gy = 2048 / gx;
     if (gy < 1) gy = 1;
-    const int rows_per_block = (rows + gy - 1) / gy;
+    rows_per_block = (rows + gy - 1) / gy;
     gy = (rows + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, x, out, rows, cols, tpr_log2, rows_per_block);
+    grid = dim3(gx, gy);
+}
+
+extern "C" int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return TULIP_OK;
+    if (cols & 7) return TULIP_ERR_ARG;
+    int tpr_log2, rpb; dim3 grid;
+    colsum_grid(rows, cols, tpr_log2, grid, rpb);
+    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, stream, (const void*)x, (bf16_t*)nullptr, out, rows,
+                       cols, tpr_log2, rpb, (const float*)nullptr, 1);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
+}
+
+extern "C" int tulip_cast_colsum(const float* x, uint16_t* y, float* colsum, int rows, int cols, const float* rowscale,
+                                 int rows_per_sample, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return TULIP_OK;
+    if (cols & 7) return TULIP_ERR_ARG;
+    if (rowscale && rows_per_sample <= 0) return TULIP_ERR_ARG;
+    int tpr_log2, rpb; dim3 grid;
+    colsum_grid(rows, cols, tpr_log2, grid, rpb);
+    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, stream, (const void*)x, y, colsum, rows, cols, tpr_log2,
+                       rpb, rowscale, rows_per_sample > 0 ? rows_per_sample : 1);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
+                                  int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream) {
+    if (nrows <= 0 || (n0 <= 0 && n1 <= 0)) return TULIP_OK;
+    if ((n0 & 3) || (n1 & 3) || (stride0 & 3) || (stride1 & 3)) return TULIP_ERR_ARG;
+    if (n0 < 0) n0 = 0;
+    if (n1 < 0) n1 = 0;
+    // few columns -> spread the partial rows over 16 row lanes; many columns -> one thread per column
+    const bool wide = (n0 + n1) / 4 >= 8192;
+    const int CT = wide ? 256 : 16;
+    ReduceRegion r0{part0, out0, stride0, n0 / 4, (int)((n0 / 4 + CT - 1) / CT)};
+    ReduceRegion r1{part1, out1, stride1, n1 / 4, (int)((n1 / 4 + CT - 1) / CT)};
+    const dim3 grid(r0.nblocks + r1.nblocks);
+    if (wide) hipLaunchKernelGGL(reduce_rows_kernel<1>, grid, dim3(256), 0, stream, r0, r1, nrows);
+    else hipLaunchKernelGGL(reduce_rows_kernel<16>, grid, dim3(256), 0, stream, r0, r1, nrows);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_reduce_splits(const float* slabs, float* out, int64_t n, int splits, hipStream_t stream) {
+    return tulip_reduce_rows2(slabs, n, out, n, nullptr, 0, nullptr, 0, splits, stream);
 }
 
 extern "C" int tulip_l1_loss_fwd(const float* pred, const float* target, float* partials, float* losses, int64_t n,

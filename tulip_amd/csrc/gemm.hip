@@ -208,6 +208,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
                 o[idx] = v[r];
             }
         } break;
+        case TULIP_EPI_SPLIT_F32: {
+            // split-K partial slab: out is [splits][M][ldo], reduced by tulip_reduce_splits
+            float* o = (float*)p.out + ((size_t)blockIdx.z * p.M + m) * p.ldo + n;
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        } break;
         case TULIP_EPI_ATOMIC_F32: {
             float* o = (float*)p.out + (size_t)m * p.ldo + n;
 #pragma unroll
@@ -249,6 +254,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     __syncthreads();
 
     const int g = lane >> 4, li = lane & 15;
+    // wgrad only: row sums of opA (= bias gradient, sum over tokens of dY) from one extra MFMA per
+    // fragment against an all-ones operand, in the first column-tile's wn==0 waves.
+    const bool do_rowsum = A_T && p.out2 != nullptr && blockIdx.x == 0 && wn == 0 &&
+                           (p.epi == TULIP_EPI_SPLIT_F32 || p.epi == TULIP_EPI_F32);
+    f32x4 rsum[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const short one = (short)0x3F80;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
@@ -271,6 +285,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if (A_T && do_rowsum) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], rsum[i], 0, 0, 0);
+        }
         if (t + 1 < nt) {
             sa.store(ldsA(cur ^ 1), tid);
             sb.store(ldsB(cur ^ 1), tid);
@@ -286,6 +305,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wn * 48 + j * 16 + g * 4;
             if (n < p.N) epilogue(p, m, n, acc[i][j]);
+        }
+    }
+    if (A_T && do_rowsum && g == 0) {
+        float* rs = (float*)p.out2;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + li;
+            if (m >= p.M) continue;
+            if (p.epi == TULIP_EPI_SPLIT_F32) rs[(size_t)blockIdx.z * p.M + m] = rsum[i][0];
+            else if (p.accumulate) rs[m] += rsum[i][0];
+            else rs[m] = rsum[i][0];
         }
     }
 }
@@ -308,6 +338,14 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
 
 }  // namespace
 
+static int effective_splits(int K, int splits) {
+    if (splits < 1) splits = 1;
+    const int kchunk = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
+    return (K + kchunk - 1) / kchunk;
+}
+
+extern "C" int tulip_gemm_effective_splits(int K, int splits) { return K > 0 ? effective_splits(K, splits) : 1; }
+
 extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N,
                                int K, int epi, const float* bias, void* out, int ldo, void* out2, int ldo2,
                                const void* aux, int ldaux, const float* rowscale, int rows_per_sample, int accumulate,
@@ -317,7 +355,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     if (a_trans && (M & 7)) return TULIP_ERR_ARG;
     if (b_trans && (N & 7)) return TULIP_ERR_ARG;
     if (splits < 1) splits = 1;
-    if (splits > 1 && epi != TULIP_EPI_ATOMIC_F32) return TULIP_ERR_ARG;
+    if (splits > 1 && epi != TULIP_EPI_ATOMIC_F32 && epi != TULIP_EPI_SPLIT_F32) return TULIP_ERR_ARG;
     if ((epi == TULIP_EPI_RESID_F32 || epi == TULIP_EPI_GELU_BWD) && !aux) return TULIP_ERR_ARG;
     if (epi == TULIP_EPI_GELU_DUAL && !out2) return TULIP_ERR_ARG;
     GemmArgs p;

@@ -1,6 +1,8 @@
 // LayerNorm forward/backward over the fp32 residual stream (optionally through the PatchMerging
 // 2x2 gather) and the PatchEmbedding conv+LN.  All HBM-bound: one pass over x, 16-byte accesses,
 // wave shuffles for the row statistics.   gfx950 only.
+#include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -79,11 +81,18 @@ template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx,
-                                                     int rows, RowGeom g) {
+                                                     int rows, RowGeom g, float* __restrict__ ppart) {
+    // PARTS: also accumulate d(gamma)=sum dy*xhat and d(beta)=sum dy over this block's rows and emit one
+    // partial row [2C] per block (folded later by tulip_reduce_rows2) -- no second pass over dy / x.
+    constexpr bool PARTS = NCH <= 8;
+    extern __shared__ __attribute__((aligned(16))) float lds_part[];  // [256/LPR][2C]
     const int lane = threadIdx.x % LPR;
     const int rpb = 256 / LPR;
     const int nch = g.C >> 2;
     const float invC = 1.0f / (float)g.C;
+    float4 pg[PARTS ? NCH : 1], pb[PARTS ? NCH : 1];
+#pragma unroll
+    for (int i = 0; i < (PARTS ? NCH : 1); ++i) { pg[i] = make_float4(0, 0, 0, 0); pb[i] = make_float4(0, 0, 0, 0); }
     for (int row = blockIdx.x * rpb + threadIdx.x / LPR; row < rows; row += gridDim.x * rpb) {
         const float mu = mean[row], rs = rstd[row];
         float4 xh[NCH], gy[NCH];
@@ -96,8 +105,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 const uint2 d = *(const uint2*)(dy + (size_t)row * g.C + c * 4);
                 const float4 ga = *(const float4*)(gamma + c * 4);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                gy[i] = make_float4(bf2f((bf16_t)(d.x & 0xffff)) * ga.x, bf2f((bf16_t)(d.x >> 16)) * ga.y,
-                                    bf2f((bf16_t)(d.y & 0xffff)) * ga.z, bf2f((bf16_t)(d.y >> 16)) * ga.w);
+                const float d0 = bf2f((bf16_t)(d.x & 0xffff)), d1 = bf2f((bf16_t)(d.x >> 16));
+                const float d2 = bf2f((bf16_t)(d.y & 0xffff)), d3 = bf2f((bf16_t)(d.y >> 16));
+                if (PARTS) {
+                    pg[i].x += d0 * xh[i].x; pg[i].y += d1 * xh[i].y; pg[i].z += d2 * xh[i].z; pg[i].w += d3 * xh[i].w;
+                    pb[i].x += d0; pb[i].y += d1; pb[i].z += d2; pb[i].w += d3;
+                }
+                gy[i] = make_float4(d0 * ga.x, d1 * ga.y, d2 * ga.z, d3 * ga.w);
                 s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
                 s2 += (gy[i].x * xh[i].x + gy[i].y * xh[i].y) + (gy[i].z * xh[i].z + gy[i].w * xh[i].w);
             }
@@ -119,6 +133,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             }
         }
     }
+    if (PARTS && ppart) {
+        const int C2 = 2 * g.C;
+        float* mine = lds_part + (threadIdx.x / LPR) * C2;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + i * LPR;
+            if (c < nch) {
+                *(float4*)(mine + c * 4) = pg[i];
+                *(float4*)(mine + g.C + c * 4) = pb[i];
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < C2; idx += 256) {
+            float s = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < rpb; ++k) s += lds_part[k * C2 + idx];
+            ppart[(size_t)blockIdx.x * C2 + idx] = s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ backward (dgamma, dbeta)
@@ -137,15 +170,27 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const bf16_t* __rest
     if (c < nch) {
         const int r0 = blockIdx.y * rows_per_block;
         const int r1 = min(rows, r0 + rows_per_block);
-        for (int row = r0 + ty; row < r1; row += RL) {
-            const float mu = mean[row], rs = rstd[row];
-            const float4 xv = *(const float4*)(x + src_off(g, row, c * 4));
-            const uint2 d = *(const uint2*)(dy + (size_t)row * g.C + c * 4);
-            const float d0 = bf2f((bf16_t)(d.x & 0xffff)), d1 = bf2f((bf16_t)(d.x >> 16));
-            const float d2 = bf2f((bf16_t)(d.y & 0xffff)), d3 = bf2f((bf16_t)(d.y >> 16));
-            a[0] += d0 * (xv.x - mu) * rs; a[1] += d1 * (xv.y - mu) * rs;
-            a[2] += d2 * (xv.z - mu) * rs; a[3] += d3 * (xv.w - mu) * rs;
-            a[4] += d0; a[5] += d1; a[6] += d2; a[7] += d3;
+        constexpr int UNR = 4;
+        for (int rb = r0 + ty; rb < r1; rb += RL * UNR) {
+            float4 xv[UNR]; uint2 d[UNR]; float mu[UNR], rs[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int row = rb + u * RL;
+                xv[u] = make_float4(0, 0, 0, 0); d[u] = make_uint2(0, 0); mu[u] = 0.f; rs[u] = 0.f;
+                if (row < r1) {
+                    mu[u] = mean[row]; rs[u] = rstd[row];
+                    xv[u] = *(const float4*)(x + src_off(g, row, c * 4));
+                    d[u] = *(const uint2*)(dy + (size_t)row * g.C + c * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const float d0 = bf2f((bf16_t)(d[u].x & 0xffff)), d1 = bf2f((bf16_t)(d[u].x >> 16));
+                const float d2 = bf2f((bf16_t)(d[u].y & 0xffff)), d3 = bf2f((bf16_t)(d[u].y >> 16));
+                a[0] += d0 * (xv[u].x - mu[u]) * rs[u]; a[1] += d1 * (xv[u].y - mu[u]) * rs[u];
+                a[2] += d2 * (xv[u].z - mu[u]) * rs[u]; a[3] += d3 * (xv[u].w - mu[u]) * rs[u];
+                a[4] += d0; a[5] += d1; a[6] += d2; a[7] += d3;
+            }
         }
     }
 #pragma unroll
@@ -197,7 +242,18 @@ __device__ __forceinline__ float embed_tap(const float* __restrict__ img, const 
     return img[(((size_t)b * g.Cin + ic) * g.Hin + (g.p0 * h + i)) * g.Win + col];
 }
 
-// one wave per token (grid-stride), lane owns channels lane and lane+64 (E <= 128)
+constexpr int EMB_MAXT = 16;  // taps held in registers: (1,4) patches (4 or 8 taps) and (4,4) patches (16)
+
+// all taps of one token into registers with independent loads (taps <= EMB_MAXT)
+__device__ __forceinline__ void embed_taps(const float* __restrict__ img, const EmbedGeom& g, int b, int h, int w,
+                                           float (&xt)[EMB_MAXT]) {
+#pragma unroll
+    for (int t = 0; t < EMB_MAXT; ++t) xt[t] = (t < g.taps) ? embed_tap(img, g, b, h, w, t) : 0.f;
+}
+
+// one wave per token (grid-stride), lane owns channels lane and lane+64 (E <= 128); conv weights of the
+// lane's two channels live in registers for the whole kernel.
+template <bool INREG>
 __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ img,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ gamma,
@@ -209,69 +265,95 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
     const int c0 = lane, c1 = lane + 64;
     const bool v0 = c0 < g.E, v1 = c1 < g.E;
     const float invE = 1.0f / (float)g.E;
+    float w0[EMB_MAXT], w1[EMB_MAXT];
+#pragma unroll
+    for (int t = 0; t < EMB_MAXT; ++t) {
+        w0[t] = (INREG && v0 && t < g.taps) ? w[c0 * g.taps + t] : 0.f;
+        w1[t] = (INREG && v1 && t < g.taps) ? w[c1 * g.taps + t] : 0.f;
+    }
+    const float b0 = v0 ? bias[c0] : 0.f, b1 = v1 ? bias[c1] : 0.f;
+    const float ga0 = v0 ? gamma[c0] : 0.f, ga1 = v1 ? gamma[c1] : 0.f;
+    const float be0 = v0 ? beta[c0] : 0.f, be1 = v1 ? beta[c1] : 0.f;
     for (int tok = wave; tok < ntok; tok += nwaves) {
         const int wq = tok % g.Wo, t2 = tok / g.Wo;
         const int h = t2 % g.Ho, b = t2 / g.Ho;
-        float a0 = v0 ? bias[c0] : 0.f, a1 = v1 ? bias[c1] : 0.f;
-        for (int t = 0; t < g.taps; ++t) {
-            const float xv = embed_tap(img, g, b, h, wq, t);
-            if (v0) a0 += w[c0 * g.taps + t] * xv;
-            if (v1) a1 += w[c1 * g.taps + t] * xv;
+        float a0 = b0, a1 = b1;
+        if (INREG) {
+            float xt[EMB_MAXT];
+            embed_taps(img, g, b, h, wq, xt);
+#pragma unroll
+            for (int t = 0; t < EMB_MAXT; ++t) { a0 += w0[t] * xt[t]; a1 += w1[t] * xt[t]; }
+        } else {
+            for (int t = 0; t < g.taps; ++t) {
+                const float xv = embed_tap(img, g, b, h, wq, t);
+                if (v0) a0 += w[c0 * g.taps + t] * xv;
+                if (v1) a1 += w[c1 * g.taps + t] * xv;
+            }
         }
         const float mu = group_sum<64>((v0 ? a0 : 0.f) + (v1 ? a1 : 0.f)) * invE;
         const float d0 = v0 ? a0 - mu : 0.f, d1 = v1 ? a1 - mu : 0.f;
         const float rs = rsqrtf(group_sum<64>(d0 * d0 + d1 * d1) * invE + eps);
-        if (v0) out[(size_t)tok * g.E + c0] = d0 * rs * gamma[c0] + beta[c0];
-        if (v1) out[(size_t)tok * g.E + c1] = d1 * rs * gamma[c1] + beta[c1];
+        if (v0) out[(size_t)tok * g.E + c0] = d0 * rs * ga0 + be0;
+        if (v1) out[(size_t)tok * g.E + c1] = d1 * rs * ga1 + be1;
     }
 }
 
-constexpr int EMB_MAXT = 8;
+template <bool INREG>
 __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ img,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ dout, float* dw, float* db,
-                                                              float* dgamma, float* dbeta, EmbedGeom g, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+                                                              float* dgamma, float* dbeta, EmbedGeom g, float eps,
+                                                              int pstride) {
+    // pstride > 0: dw/db/dgamma/dbeta address row 0 of a [gridDim.x][pstride] partial buffer (plain stores,
+    // folded by tulip_reduce_rows2); pstride == 0: accumulate atomically into the gradients themselves.
+    __shared__ float red[4][64][2 * (EMB_MAXT + 3)];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
     const int ntok = g.B * g.Ho * g.Wo;
     const int c0 = lane, c1 = lane + 64;
     const bool v0 = c0 < g.E, v1 = c1 < g.E;
     const float invE = 1.0f / (float)g.E;
-    const bool inreg = g.taps <= EMB_MAXT;
-    float aw0[EMB_MAXT], aw1[EMB_MAXT];
+    float w0[EMB_MAXT], w1[EMB_MAXT], aw0[EMB_MAXT], aw1[EMB_MAXT];
 #pragma unroll
-    for (int t = 0; t < EMB_MAXT; ++t) { aw0[t] = 0.f; aw1[t] = 0.f; }
+    for (int t = 0; t < EMB_MAXT; ++t) {
+        w0[t] = (INREG && v0 && t < g.taps) ? w[c0 * g.taps + t] : 0.f;
+        w1[t] = (INREG && v1 && t < g.taps) ? w[c1 * g.taps + t] : 0.f;
+        aw0[t] = 0.f; aw1[t] = 0.f;
+    }
     float ab0 = 0.f, ab1 = 0.f, ag0 = 0.f, ag1 = 0.f, abe0 = 0.f, abe1 = 0.f;
+    const float b0 = v0 ? bias[c0] : 0.f, b1 = v1 ? bias[c1] : 0.f;
     const float ga0 = v0 ? gamma[c0] : 0.f, ga1 = v1 ? gamma[c1] : 0.f;
     for (int tok = wave; tok < ntok; tok += nwaves) {
         const int wq = tok % g.Wo, t2 = tok / g.Wo;
         const int h = t2 % g.Ho, b = t2 / g.Ho;
-        float a0 = v0 ? bias[c0] : 0.f, a1 = v1 ? bias[c1] : 0.f;
-        for (int t = 0; t < g.taps; ++t) {
-            const float xv = embed_tap(img, g, b, h, wq, t);
-            if (v0) a0 += w[c0 * g.taps + t] * xv;
-            if (v1) a1 += w[c1 * g.taps + t] * xv;
+        const float dy0 = v0 ? dout[(size_t)tok * g.E + c0] : 0.f, dy1 = v1 ? dout[(size_t)tok * g.E + c1] : 0.f;
+        float xt[EMB_MAXT];
+        float a0 = b0, a1 = b1;
+        if (INREG) {
+            embed_taps(img, g, b, h, wq, xt);
+#pragma unroll
+            for (int t = 0; t < EMB_MAXT; ++t) { a0 += w0[t] * xt[t]; a1 += w1[t] * xt[t]; }
+        } else {
+            for (int t = 0; t < g.taps; ++t) {
+                const float xv = embed_tap(img, g, b, h, wq, t);
+                if (v0) a0 += w[c0 * g.taps + t] * xv;
+                if (v1) a1 += w[c1 * g.taps + t] * xv;
+            }
         }
         const float mu = group_sum<64>((v0 ? a0 : 0.f) + (v1 ? a1 : 0.f)) * invE;
         const float d0 = v0 ? a0 - mu : 0.f, d1 = v1 ? a1 - mu : 0.f;
         const float rs = rsqrtf(group_sum<64>(d0 * d0 + d1 * d1) * invE + eps);
         const float xh0 = d0 * rs, xh1 = d1 * rs;
-        const float dy0 = v0 ? dout[(size_t)tok * g.E + c0] : 0.f, dy1 = v1 ? dout[(size_t)tok * g.E + c1] : 0.f;
         ag0 += dy0 * xh0; ag1 += dy1 * xh1; abe0 += dy0; abe1 += dy1;
         const float gy0 = dy0 * ga0, gy1 = dy1 * ga1;
         const float m1 = group_sum<64>(gy0 + gy1) * invE;
         const float m2 = group_sum<64>(gy0 * xh0 + gy1 * xh1) * invE;
         const float dc0 = v0 ? rs * (gy0 - m1 - xh0 * m2) : 0.f, dc1 = v1 ? rs * (gy1 - m1 - xh1 * m2) : 0.f;
         ab0 += dc0; ab1 += dc1;
-        if (inreg) {
+        if (INREG) {
 #pragma unroll
-            for (int t = 0; t < EMB_MAXT; ++t) {
-                if (t < g.taps) {
-                    const float xv = embed_tap(img, g, b, h, wq, t);
-                    aw0[t] += dc0 * xv; aw1[t] += dc1 * xv;
-                }
-            }
+            for (int t = 0; t < EMB_MAXT; ++t) { aw0[t] += dc0 * xt[t]; aw1[t] += dc1 * xt[t]; }
         } else {
             for (int t = 0; t < g.taps; ++t) {
                 const float xv = embed_tap(img, g, b, h, wq, t);
@@ -280,18 +362,38 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
             }
         }
     }
-    if (v0) {
-        atomicAdd(db + c0, ab0); atomicAdd(dgamma + c0, ag0); atomicAdd(dbeta + c0, abe0);
-        if (inreg) {
+    // block-level reduce over the 4 waves, then one atomic per value per block
+    float* r = red[wid][lane];
 #pragma unroll
-            for (int t = 0; t < EMB_MAXT; ++t) if (t < g.taps) atomicAdd(dw + c0 * g.taps + t, aw0[t]);
-        }
-    }
-    if (v1) {
-        atomicAdd(db + c1, ab1); atomicAdd(dgamma + c1, ag1); atomicAdd(dbeta + c1, abe1);
-        if (inreg) {
+    for (int t = 0; t < EMB_MAXT; ++t) { r[t] = aw0[t]; r[EMB_MAXT + 3 + t] = aw1[t]; }
+    r[EMB_MAXT] = ab0; r[EMB_MAXT + 1] = ag0; r[EMB_MAXT + 2] = abe0;
+    r[2 * EMB_MAXT + 3] = ab1; r[2 * EMB_MAXT + 4] = ag1; r[2 * EMB_MAXT + 5] = abe1;
+    __syncthreads();
+    if (wid == 0) {
 #pragma unroll
-            for (int t = 0; t < EMB_MAXT; ++t) if (t < g.taps) atomicAdd(dw + c1 * g.taps + t, aw1[t]);
+        for (int half = 0; half < 2; ++half) {
+            const int c = half ? c1 : c0;
+            if (c >= g.E) continue;
+            const int o = half * (EMB_MAXT + 3);
+            float acc[EMB_MAXT + 3];
+#pragma unroll
+            for (int k = 0; k < EMB_MAXT + 3; ++k)
+                acc[k] = (red[0][lane][o + k] + red[1][lane][o + k]) + (red[2][lane][o + k] + red[3][lane][o + k]);
+            if (pstride > 0) {
+                const size_t ro = (size_t)blockIdx.x * pstride;
+                if (INREG) {
+#pragma unroll
+                    for (int t = 0; t < EMB_MAXT; ++t) if (t < g.taps) dw[ro + c * g.taps + t] = acc[t];
+                }
+                db[ro + c] = acc[EMB_MAXT]; dgamma[ro + c] = acc[EMB_MAXT + 1]; dbeta[ro + c] = acc[EMB_MAXT + 2];
+            } else {
+                if (INREG) {
+#pragma unroll
+                    for (int t = 0; t < EMB_MAXT; ++t) if (t < g.taps) atomicAdd(dw + c * g.taps + t, acc[t]);
+                }
+                atomicAdd(db + c, acc[EMB_MAXT]); atomicAdd(dgamma + c, acc[EMB_MAXT + 1]);
+                atomicAdd(dbeta + c, acc[EMB_MAXT + 2]);
+            }
         }
     }
 }
@@ -316,7 +418,7 @@ extern "C" int tulip_layernorm_fwd(const float* x, const float* gamma, const flo
     return dispatch_ln(C, [&](auto lpr, auto nch) {
         constexpr int LPR = decltype(lpr)::value, NCH = decltype(nch)::value;
         const int rpb = 256 / LPR;
-        const int grid = min((rows + rpb - 1) / rpb, 256 * 16);
+        const int grid = std::min((rows + rpb - 1) / rpb, 256 * 16);
         hipLaunchKernelGGL((ln_fwd_kernel<LPR, NCH>), dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd,
                            rows, g, eps);
         TULIP_CHECK_LAUNCH();
@@ -324,18 +426,30 @@ extern "C" int tulip_layernorm_fwd(const float* x, const float* gamma, const flo
     });
 }
 
+// partial rows ([2C] each) tulip_layernorm_bwd emits for (rows, C); 0 = fused parameter partials unsupported
+static int ln_bwd_part_rows(int rows, int C) {
+    const int nch = C >> 2;
+    if (nch > 64 * 8) return 0;
+    const int rpb = nch <= 64 ? 16 : 4;
+    return std::max(1, std::min((rows + rpb - 1) / rpb, 512));
+}
+
+extern "C" int tulip_layernorm_bwd_partial_rows(int rows, int C) { return rows > 0 ? ln_bwd_part_rows(rows, C) : 0; }
+
 extern "C" int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd,
                                    const float* gamma, const float* dres, float* dx, int rows, int C, int merge, int B,
-                                   int H, int W, hipStream_t stream) {
+                                   int H, int W, float* param_partials, hipStream_t stream) {
     if (rows <= 0) return TULIP_OK;
     if (!geom_ok(rows, C, merge, B, H, W)) return TULIP_ERR_ARG;
+    if (param_partials && ln_bwd_part_rows(rows, C) == 0) return TULIP_ERR_ARG;
     RowGeom g{C, merge, B, H, W};
     return dispatch_ln(C, [&](auto lpr, auto nch) {
         constexpr int LPR = decltype(lpr)::value, NCH = decltype(nch)::value;
         const int rpb = 256 / LPR;
-        const int grid = min((rows + rpb - 1) / rpb, 256 * 16);
-        hipLaunchKernelGGL((ln_bwd_kernel<LPR, NCH>), dim3(grid), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres,
-                           dx, rows, g);
+        const int grid = param_partials ? ln_bwd_part_rows(rows, C) : std::min((rows + rpb - 1) / rpb, 256 * 16);
+        const size_t lds = param_partials ? (size_t)rpb * 2 * C * sizeof(float) : 0;
+        hipLaunchKernelGGL((ln_bwd_kernel<LPR, NCH>), dim3(grid), dim3(256), lds, stream, dy, x, mean, rstd, gamma,
+                           dres, dx, rows, g, param_partials);
         TULIP_CHECK_LAUNCH();
         return TULIP_OK;
     });
@@ -352,7 +466,8 @@ extern "C" int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, co
     while ((1 << tpr_log2) < nch && tpr_log2 < 6) ++tpr_log2;
     const int TPR = 1 << tpr_log2;
     const int gx = (nch + TPR - 1) / TPR;
-    int gy = max(1, min((rows + 63) / 64, 1024 / gx));
+    const int RLh = 256 >> tpr_log2;
+    int gy = std::max(1, std::min((rows + RLh * 4 - 1) / (RLh * 4), 2048 / gx));
     const int rows_per_block = (rows + gy - 1) / gy;
     gy = (rows + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(gx, gy), dim3(256), 0, stream, dy, x, mean, rstd, dgamma, dbeta, rows,
@@ -368,23 +483,35 @@ extern "C" int tulip_patch_embed_fwd(const float* img, const float* w, const flo
     if (!embed_geom(g, B, Cin, Hin, Win, E, p0, p1, kw, circular)) return TULIP_ERR_ARG;
     const int ntok = g.B * g.Ho * g.Wo;
     if (ntok <= 0) return TULIP_OK;
-    const int grid = min((ntok + 3) / 4, 256 * 8);
-    hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, beta, out, g, eps);
+    const int grid = std::min((ntok + 3) / 4, 256 * 8);
+    if (g.taps <= EMB_MAXT)
+        hipLaunchKernelGGL(patch_embed_fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, beta, out,
+                           g, eps);
+    else
+        hipLaunchKernelGGL(patch_embed_fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, beta, out,
+                           g, eps);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }
 
+extern "C" int tulip_patch_embed_bwd_blocks(int ntok) { return std::max(1, std::min((ntok + 3) / 4, 512)); }
+
 extern "C" int tulip_patch_embed_bwd(const float* img, const float* w, const float* b, const float* gamma,
                                      const float* dout, float* dw, float* db, float* dgamma, float* dbeta, int B,
                                      int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular, float eps,
-                                     hipStream_t stream) {
+                                     int partial_stride, hipStream_t stream) {
     EmbedGeom g;
     if (!embed_geom(g, B, Cin, Hin, Win, E, p0, p1, kw, circular)) return TULIP_ERR_ARG;
     const int ntok = g.B * g.Ho * g.Wo;
     if (ntok <= 0) return TULIP_OK;
-    const int grid = min((ntok + 3) / 4, 256);
-    hipLaunchKernelGGL(patch_embed_bwd_kernel, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, dout, dw, db, dgamma,
-                       dbeta, g, eps);
+    if (partial_stride > 0 && g.taps > EMB_MAXT) return TULIP_ERR_ARG;
+    const int grid = tulip_patch_embed_bwd_blocks(ntok);
+    if (g.taps <= EMB_MAXT)
+        hipLaunchKernelGGL(patch_embed_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, dout, dw,
+                           db, dgamma, dbeta, g, eps, partial_stride);
+    else
+        hipLaunchKernelGGL(patch_embed_bwd_kernel<false>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, dout, dw,
+                           db, dgamma, dbeta, g, eps, 0);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

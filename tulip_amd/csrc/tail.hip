@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const bf16_t* __restrict_
         }
     }
     __syncthreads();
-    if (threadIdx.x < g.E) atomicAdd(dwd + threadIdx.x, lds_dwd[threadIdx.x]);
+    // one plain partial row per workgroup: dwd[blockIdx.x][128] (folded by tulip_reduce_rows2)
+    if (threadIdx.x < 128) dwd[(size_t)blockIdx.x * 128 + threadIdx.x] = threadIdx.x < g.E ? lds_dwd[threadIdx.x] : 0.f;
 }
 
 }  // namespace

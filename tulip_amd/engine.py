@@ -24,7 +24,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32)
+from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32,
+                   EPI_SPLIT_F32)
 
 ALIGN = 64  # floats; every parameter starts on a 256-byte boundary of the flat buffer
 
@@ -209,6 +210,18 @@ class Plan:
         self.b16("tail.xn", maxM, E); self.f32("tail.mean", maxM); self.f32("tail.rstd", maxM)
         self.b16("tail.dz", maxM, 16 * E)
         self.b16("tail.dxn", maxM, E)
+        # partial-row workspaces of the atomic-free reductions
+        self.f32("tail.dwd_part", (maxM + 127) // 128, 128)
+        self.ln_part_ptr = self.f32("ln_part", 512, 4096).data_ptr()           # <=512 rows x 2C (C <= 2048)
+        rmax = max(ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, sp.nh, sp.win) * sp.nh for sp in eng.blocks)
+        self.attn_part_ptr = self.f32("attn_part", rmax, 256).data_ptr()
+        W_ = eng.params
+        o0 = W_.offset["patch_embed.proj.weight"]
+        last = "patch_embed.norm.bias" if "patch_embed.norm.bias" in W_.offset else "patch_embed.proj.bias"
+        self.embed_stride = _ceil(W_.offset[last] + W_.numel[last], ALIGN) - o0
+        ep = torch.zeros(ops.patch_embed_bwd_blocks(maxM), self.embed_stride, dtype=torch.float32, device=dev)
+        self.bufs["embed_part"] = ep                                          # padding columns stay zero forever
+        self.embed_part_ptr = ep.data_ptr()
 
     def _alloc(self, name, shape, dtype, dev):
         t = torch.empty(*shape, dtype=dtype, device=dev)
@@ -303,6 +316,9 @@ class TulipEngine:
     def plan(self, B: int) -> Plan:
         if B not in self.plans:
             self.plans[B] = Plan(self, B)
+        if getattr(self, "_ws", None) is None or self._ws.device != self.device:
+            self._ws = torch.empty(self.WS_ELEMS + (1 << 20), dtype=torch.float32, device=self.device)
+            self._ws_ptr = self._ws.data_ptr()
         return self.plans[B]
 
     # ------------------------------------------------------------------ forward
@@ -409,16 +425,45 @@ class TulipEngine:
         P.last_x = x
 
     # ------------------------------------------------------------------ backward
-    @staticmethod
-    def _splits(Mout: int, Nout: int, K: int) -> int:
-        tiles = ((Mout + 127) // 128) * ((Nout + 95) // 96)
-        s = max(1, min(512 // max(tiles, 1), K // 256))
-        return max(1, s)
+    WS_ELEMS = 16 << 20  # fp32 elements of split-K slab workspace (64 MiB) (+ bias slabs behind it)
 
-    def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout):
-        """dW[Nw,Kw] += dY[Mtok,Nw]^T . X[Mtok,Kw] (fp32 atomics, split over tokens)."""
-        ops.gemm(dY, X, Nw, Kw, Mtok, lda=ldy, ldb=ldx, a_trans=True, b_trans=True, epi=EPI_ATOMIC_F32, out=gout,
-                 ldo=Kw, splits=self._splits(Nw, Kw, Mtok))
+    @classmethod
+    def _splits(cls, Mout: int, Nout: int, K: int) -> int:
+        tiles = ((Mout + 127) // 128) * ((Nout + 95) // 96)
+        s = max(1, min(512 // max(tiles, 1), K // 256, cls.WS_ELEMS // (Mout * Nout)))
+        while True:  # the kernel cuts K in multiples of 32: iterate to the split count it really launches
+            e = ops.gemm_effective_splits(K, s)
+            if e == s:
+                return s
+            s = e
+
+    def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
+        """dW[Nw,Kw] += dY[Mtok,Nw]^T . X[Mtok,Kw]  and, for free, db[Nw] += sum_tokens dY (row sums of the
+        transposed operand via one extra all-ones MFMA per fragment).  The token dimension is split over
+        workgroups to fill the chip; partials go to fp32 slabs that one reduce kernel folds into both
+        gradients (deterministic, no atomics)."""
+        splits = self._splits(Nw, Kw, Mtok)
+        if splits == 1:
+            ops.gemm(dY, X, Nw, Kw, Mtok, lda=ldy, ldb=ldx, a_trans=True, b_trans=True, epi=EPI_F32, out=gout, ldo=Kw,
+                     accumulate=True, out2=gbias)
+            return
+        ws = self._ws_ptr
+        wsb = ws + 4 * splits * Nw * Kw if gbias is not None else None
+        ops.gemm(dY, X, Nw, Kw, Mtok, lda=ldy, ldb=ldx, a_trans=True, b_trans=True, epi=EPI_SPLIT_F32, out=ws, ldo=Kw,
+                 splits=splits, out2=wsb)
+        ops.reduce_rows2(ws, Nw * Kw, gout, Nw * Kw, wsb, Nw, gbias, Nw if gbias is not None else 0, splits)
+
+    def _ln_bwd(self, P: Plan, dy, x, mean, rstd, gamma, dres, dx, rows, C, gw, gb, merge=False, H=0, W=0):
+        """LayerNorm backward: dx (+= dres) and the affine gradients via per-workgroup partial rows."""
+        nrows = ops.layernorm_bwd_partial_rows(rows, C)
+        if nrows == 0:  # C > 2048 (tulip_large's deepest PatchMerging norm): stand-alone parameter pass
+            ops.layernorm_bwd_params(dy, x, mean, rstd, gw, gb, rows, C, merge=merge, B=P.B, H=H, W=W)
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W)
+            return
+        part = P.ln_part_ptr
+        ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
+                          param_partials=part)
+        ops.reduce_rows2(part, 2 * C, gw, C, part + 4 * C, 2 * C, gb, C, nrows)
 
     def _block_bwd(self, P: Plan, sp: BlockSpec, xin, dx, G):
         """In-place: dx (grad w.r.t. block output) -> grad w.r.t. block input.  G(name) = grad address."""
@@ -431,34 +476,29 @@ class TulipEngine:
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
         ops.gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
                  ldo=Hd, aux=P[p + ".h"], ldaux=Hd)
-        self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"))
-        ops.colsum_bf16(dyb, G(p + ".mlp.fc2.bias"), M, C)
+        self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
         ops.gemm(dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, lda=Hd, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn,
                  ldo=C)
-        self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"))
-        ops.colsum_bf16(dh, G(p + ".mlp.fc1.bias"), M, Hd)
-        ops.layernorm_bwd_params(dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], G(p + ".norm2.weight"),
-                                 G(p + ".norm2.bias"), M, C)
-        ops.layernorm_bwd(dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M,
-                          C)
+        self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
+        self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
+                     G(p + ".norm2.weight"), G(p + ".norm2.bias"))
         # ---- attention branch (tulip.py:339-344)
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 0), tok)
         ops.gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
                  ldo=C)
-        self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"))
-        ops.colsum_bf16(dyb, G(p + ".attn.proj.bias"), M, C)
-        dense = P.dense_bias
+        self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
+        dense, apart = P.dense_bias, P.attn_part_ptr
         dense.zero_()
         ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
-                            dense, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
+                            apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
+        ops.reduce_rows2(apart, nh * 256, dense, nh * 256, None, 0, None, 0,
+                         ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, nh, sp.win))
         ops.bias_table_scatter(dense, self._rel32, G(p + ".attn.relative_position_bias_table"), nh, 16)
         ops.gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
                  out=dxn, ldo=C)
-        self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"))
-        ops.colsum_bf16(dqkv, G(p + ".attn.qkv.bias"), M, 3 * C)
-        ops.layernorm_bwd_params(dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], G(p + ".norm1.weight"),
-                                 G(p + ".norm1.bias"), M, C)
-        ops.layernorm_bwd(dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C)
+        self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
+        self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
+                     G(p + ".norm1.weight"), G(p + ".norm1.bias"))
 
     def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G):
         for k in reversed(range(len(specs))):
@@ -474,8 +514,7 @@ class TulipEngine:
         M = B * H * W
         dz = P["t.dz2"]
         ops.unshuffle2_cast(dfine, dz, B, H, W, C // 2)
-        ops.colsum_bf16(dz, G(prefix + ".expand.bias"), M, 2 * C)
-        self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"))
+        self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), G(prefix + ".expand.bias"))
         ops.gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
                  out=dx_out, ldo=C)
 
@@ -491,18 +530,18 @@ class TulipEngine:
         hook = bucket_hook or (lambda tag: None)
         M0 = B * H0 * W0
         ops.l1_loss_bwd(P.pred, P.target, gscale_dev, gscale, P.dpred, P.pred.numel())
+        tpart = P["tail.dwd_part"]
         ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
-                     W_.p32("decoder_pred.weight"), P.dpred, P["tail.dz"], G("decoder_pred.weight"), B, H0, W0, E)
-        ops.colsum_bf16(P["tail.dz"], G("ps_head.conv_expand.0.bias"), M0, 16 * E)
-        self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"))
+                     W_.p32("decoder_pred.weight"), P.dpred, P["tail.dz"], tpart, B, H0, W0, E)
+        ops.reduce_rows2(tpart, 128, G("decoder_pred.weight"), E, None, 0, None, 0, (M0 + 127) // 128)
+        self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),
+                    G("ps_head.conv_expand.0.bias"))
         ops.gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
                  epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
-        ops.layernorm_bwd_params(P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], G("norm_up.weight"),
-                                 G("norm_up.bias"), M0, E)
-        ops.layernorm_bwd(P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx,
-                          M0, E)
+        self._ln_bwd(P, P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx, M0,
+                     E, G("norm_up.weight"), G("norm_up.bias"))
         hook("head")
         # ---- decoder, fine -> coarse
         for i in reversed(range(nl - 1)):
@@ -517,8 +556,7 @@ class TulipEngine:
             pre = f"skip_connection_layers.{i}"
             dys = P[f"dec{s}.dyskip"]
             ops.cast_f32_bf16(dx, dys, Ms, Cs)
-            ops.colsum_bf16(dys, G(pre + ".bias"), Ms, Cs)
-            self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"))
+            self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
             # grad w.r.t. the first concat half (the unmerged stream); the x_save half is deferred
             ops.gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32,
                      out=P[f"dec{s}.dxu"], ldo=Cs)
@@ -551,19 +589,23 @@ class TulipEngine:
                 ops.gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,
                          b_trans=True, epi=EPI_BF16, out=dxm, ldo=4 * Cp)
                 xprev = P[self.enc_blocks[s - 1][-1].prefix + ".out"]
-                ops.layernorm_bwd_params(dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"],
-                                         G(pre + ".norm.weight"), G(pre + ".norm.bias"), rows, 4 * Cp, merge=True,
-                                         B=B, H=Hp, W=Wp)
-                ops.layernorm_bwd(dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"],
-                                  W_.p32(pre + ".norm.weight"), None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, merge=True,
-                                  B=B, H=Hp, W=Wp)
+                self._ln_bwd(P, dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"], W_.p32(pre + ".norm.weight"),
+                             None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, G(pre + ".norm.weight"), G(pre + ".norm.bias"),
+                             merge=True, H=Hp, W=Wp)
             hook(f"enc{s}")
         kw = 8 if m.circular_padding else m.patch_size[1]
+        # patch-embed parameter gradients: partial rows laid out like the flat gradient slice
+        # [proj.weight | proj.bias | norm.weight | norm.bias] so ONE reduction folds all four tensors
+        o0 = W_.offset["patch_embed.proj.weight"]
+        rel = lambda n: 4 * (W_.offset[n] - o0)
+        ep = P.embed_part_ptr
         ops.patch_embed_bwd(P.x_in, W_.p32("patch_embed.proj.weight"), W_.p32("patch_embed.proj.bias"),
-                            W_.p32("patch_embed.norm.weight"), P["enc0.dx"], G("patch_embed.proj.weight"),
-                            G("patch_embed.proj.bias"), G("patch_embed.norm.weight"), G("patch_embed.norm.bias"), B,
-                            m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
-                            m.circular_padding, self.eps)
+                            W_.p32("patch_embed.norm.weight"), P["enc0.dx"], ep, ep + rel("patch_embed.proj.bias"),
+                            ep + rel("patch_embed.norm.weight"), ep + rel("patch_embed.norm.bias"), B, m.in_chans,
+                            m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
+                            self.eps, partial_stride=P.embed_stride)
+        ops.reduce_rows2(ep, P.embed_stride, G("patch_embed.proj.weight"), P.embed_stride, None, 0, None, 0,
+                         ops.patch_embed_bwd_blocks(B * H0 * W0))
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge

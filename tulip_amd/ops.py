@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL,  # noqa: F401
-                   EPI_PIXSHUF2_F32, EPI_RESID_F32, check)
+                   EPI_PIXSHUF2_F32, EPI_RESID_F32, EPI_SPLIT_F32, check)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -49,10 +49,19 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, merge=False, B=0,
     check(rc, "tulip_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0, H=0, W=0):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0, H=0, W=0, param_partials=None):
     rc = _lib.load().tulip_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), rows, C,
-                                         int(merge), B, H, W, _stream())
+                                         int(merge), B, H, W, _p(param_partials), _stream())
     check(rc, "tulip_layernorm_bwd")
+
+
+def layernorm_bwd_partial_rows(rows, C):
+    return _lib.load().tulip_layernorm_bwd_partial_rows(rows, C)
+
+
+def reduce_rows2(part0, stride0, out0, n0, part1, stride1, out1, n1, nrows):
+    check(_lib.load().tulip_reduce_rows2(_p(part0), stride0, _p(out0), n0, _p(part1), stride1, _p(out1), n1, nrows,
+                                         _stream()), "tulip_reduce_rows2")
 
 
 def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False, B=0, H=0, W=0):
@@ -67,10 +76,20 @@ def patch_embed_fwd(img, w, b, gamma, beta, out, B, Cin, Hin, Win, E, p0, p1, kw
     check(rc, "tulip_patch_embed_fwd")
 
 
-def patch_embed_bwd(img, w, b, gamma, dout, dw, db, dgamma, dbeta, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps):
+def patch_embed_bwd(img, w, b, gamma, dout, dw, db, dgamma, dbeta, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps,
+                    partial_stride=0):
     rc = _lib.load().tulip_patch_embed_bwd(_p(img), _p(w), _p(b), _p(gamma), _p(dout), _p(dw), _p(db), _p(dgamma),
-                                           _p(dbeta), B, Cin, Hin, Win, E, p0, p1, kw, int(circular), eps, _stream())
+                                           _p(dbeta), B, Cin, Hin, Win, E, p0, p1, kw, int(circular), eps,
+                                           partial_stride, _stream())
     check(rc, "tulip_patch_embed_bwd")
+
+
+def patch_embed_bwd_blocks(ntok):
+    return _lib.load().tulip_patch_embed_bwd_blocks(ntok)
+
+
+def window_attn_bwd_partial_rows(B, H, W, nh, win):
+    return _lib.load().tulip_window_attn_bwd_partial_rows(B, H, W, nh, win[0], win[1])
 
 
 def window_attn_fwd(qkv, bias_table, rel_index, out, B, H, W, C, nh, win, shift, masked):
@@ -102,6 +121,19 @@ def concat_cast(a, b, out, rows, C):
 
 def unshuffle2_cast(dx, dz, B, H, W, C2):
     check(_lib.load().tulip_unshuffle2_cast(_p(dx), _p(dz), B, H, W, C2, _stream()), "tulip_unshuffle2_cast")
+
+
+def cast_colsum(x, y, colsum, rows, cols, rowscale=None, rows_per_sample=1):
+    check(_lib.load().tulip_cast_colsum(_p(x), _p(y), _p(colsum), rows, cols, _p(rowscale), rows_per_sample,
+                                        _stream()), "tulip_cast_colsum")
+
+
+def reduce_splits(slabs, out, n, splits):
+    check(_lib.load().tulip_reduce_splits(_p(slabs), _p(out), n, splits, _stream()), "tulip_reduce_splits")
+
+
+def gemm_effective_splits(K, splits):
+    return _lib.load().tulip_gemm_effective_splits(K, splits)
 
 
 def colsum_bf16(x, out, rows, cols):
