@@ -271,6 +271,7 @@ def main():
     T = import_reference()
     golden_index(T)
     golden_lr(T)
+    golden_init(T)
     tiny = O.tiny_config()
     golden_model(T, "g3_tiny_fp32", tiny, batch=2, seed=0, with_grads=True)
     golden_model(T, "g3_tiny_droppath", tiny, batch=4, seed=1, with_grads=True, drop_path=True)
@@ -282,5 +283,30 @@ def main():
     print("done")
 
 
+
+
+def golden_init(T):
+    """Seeded-initialisation fingerprints of the reference modules (torch.manual_seed(0))."""
+    out = {}
+    for name, cfg, fac in [("tiny", O.tiny_config(), None), ("base", O.tulip_base_config(), "tulip_base")]:
+        torch.manual_seed(0)
+        if fac:
+            m = getattr(T, fac)(img_size=cfg.img_size, target_img_size=cfg.target_img_size, patch_size=cfg.patch_size,
+                                in_chans=1, window_size=[2, 8], pixel_shuffle=True, circular_padding=True,
+                                log_transform=True, patch_unmerging=True)
+        else:
+            m = ref_model(T, cfg, drop_path_rate=0.1)
+        sd = m.state_dict()
+        out[f"{name}_keys"] = np.array(list(sd.keys()))
+        out[f"{name}_sum"] = np.array([v.double().sum().item() for v in sd.values()])
+        out[f"{name}_abssum"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        out[f"{name}_numel"] = np.array([v.numel() for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, "g0_init.npz"), **out)
+    print("init fingerprints written")
+
+
 if __name__ == "__main__":
-    main()
+    if "--init-only" in sys.argv:
+        golden_init(import_reference())
+    else:
+        main()

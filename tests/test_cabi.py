@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/tulip_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+
+from tulip_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "tulip_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(tulip_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else args.count(",") + 1
+        out[name] = n
+    return out
+
+
+def test_library_builds_and_loads():
+    from tulip_amd.csrc.build import build
+    path = build(force=False, verbose=False)
+    assert os.path.exists(path)
+    lib = _lib.load()
+    assert lib.tulip_abi_version() == 1
+    assert lib.tulip_build_arch() == b"gfx950"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    decl = _header_functions()
+    assert len(decl) >= 25
+    lib = _lib.load()
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), f"{name} declared in tulip_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
+    for name in _lib.SIGNATURES:
+        assert name in decl, f"{name} bound in _lib.py but not declared in the header"
+
+
+def test_pure_host_entry_points():
+    lib = _lib.load()
+    # K is cut in multiples of 32; the reported split count is what the kernel launches
+    assert lib.tulip_gemm_effective_splits(32768, 128) == 128
+    assert lib.tulip_gemm_effective_splits(100, 3) == 2
+    assert lib.tulip_gemm_effective_splits(512, 1) == 1
+    assert lib.tulip_layernorm_bwd_partial_rows(32768, 96) == 512
+    assert lib.tulip_layernorm_bwd_partial_rows(64, 1536) == 16
+    assert lib.tulip_layernorm_bwd_partial_rows(16, 6144) == 0
+    assert lib.tulip_patch_embed_bwd_blocks(32768) == 512
+    r = lib.tulip_window_attn_bwd_partial_rows(8, 16, 256, 3, 2, 8)
+    assert 1 <= r <= 2048 // 3 + 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.load()
+    except _lib.TulipHipError as e:
+        assert "no CPU or PyTorch fallback" in str(e)
+    else:
+        raise AssertionError("loading a missing library must raise")

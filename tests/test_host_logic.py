@@ -1,0 +1,127 @@
+"""CPU: host-side logic of the drop-in module and engine (no kernels are launched)."""
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import tulip_oracle as O
+from tulip_amd.ddp import plan_buckets
+from tulip_amd.engine import ALIGN, FlatParams, TulipEngine, effective_window
+from tulip_amd.model import tulip as T
+from tulip_amd.trainer import cosine_lr
+
+KW = dict(patch_size=(1, 4), in_chans=1, window_size=[2, 8], pixel_shuffle=True, circular_padding=True,
+          log_transform=True, patch_unmerging=True)
+
+
+def tiny():
+    cfg = O.tiny_config()
+    return cfg, T.TULIP(img_size=cfg.img_size, target_img_size=cfg.target_img_size, depths=cfg.depths,
+                        embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, norm_layer=partial(nn.LayerNorm, eps=1e-6), **KW)
+
+
+def test_factories_and_state_dict_match_reference_contract(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g0_init.npz"))
+    for name, build, cfg in [
+        ("tiny", lambda: tiny()[1], O.tiny_config()),
+        ("base", lambda: T.tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), **KW), O.tulip_base_config()),
+    ]:
+        torch.manual_seed(0)
+        m = build()
+        sd = m.state_dict()
+        assert list(sd.keys()) == z[f"{name}_keys"].tolist() == list(O.state_dict_spec(cfg).keys())
+        for k, s, a, n in zip(sd, z[f"{name}_sum"], z[f"{name}_abssum"], z[f"{name}_numel"]):
+            v = sd[k]
+            assert v.numel() == n and tuple(v.shape) == O.state_dict_spec(cfg)[k][0]
+            # same registration + init order as the reference => same seeded weights
+            assert abs(v.double().sum().item() - s) <= 1e-9 * max(1.0, a), k
+            assert abs(v.double().abs().sum().item() - a) <= 1e-9 * max(1.0, a), k
+        assert sd["layers.0.blocks.0.attn.relative_position_index"].dtype == torch.int64
+        # engine_upsampling.enable_dropout relies on nn.Dropout* modules being present (engine:39-43)
+        assert any(type(x).__name__.startswith("Dropout") for x in m.modules())
+    assert sum(p.numel() for p in T.tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), **KW).parameters()) \
+        == 27_149_076
+
+
+def test_constructor_quirks():
+    with pytest.raises(AttributeError):          # the reference's swin_v2 branch crashes the same way
+        T.TULIP(swin_v2=True, **{k: v for k, v in KW.items()})
+    with pytest.raises(NotImplementedError):
+        T.TULIP(pixel_shuffle=False, patch_unmerging=True)
+    m = T.tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), **KW)
+    assert m.upscale_factor == 4 and m.drop_path == 0.1
+    rates = [b.drop_path_rate for s in m.layers for b in s.blocks]
+    enc, _ = O.drop_path_rates(O.tulip_base_config())
+    assert rates == [r for s in enc for r in s]
+    assert [b.drop_path_rate for b in m.layers_up[0].blocks] == enc[2]   # decoder reuses encoder slices
+
+
+def test_cpu_forward_is_refused():
+    cfg, m = tiny()
+    lo, hi = O.synthetic_batch(cfg, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(lo, hi)
+
+
+def test_effective_window_matches_oracle():
+    for H in (1, 2, 4, 16):
+        for shift in (False, True):
+            assert effective_window(H, (2, 8), shift) == O.effective_window(H, (2, 8), shift)
+
+
+def test_flat_params_layout_groups_and_decay_mask():
+    cfg, m = tiny()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fp = FlatParams(m, torch.device("cpu"))
+    # parameters are now views of the flat buffer, values unchanged, state_dict intact
+    for k, p in m.named_parameters():
+        assert p.data_ptr() == fp.p32(k) and torch.equal(p.detach(), before[k])
+        assert fp.offset[k] % ALIGN == 0
+    assert fp.still_bound(m)
+    assert list(m.state_dict().keys()) == list(before.keys())
+    # completion order: head first, patch embedding last, groups end on parameter boundaries and cover all
+    assert fp.names[0].startswith("decoder_pred") and fp.names[-1].startswith("patch_embed")
+    tags = [t for t, _ in fp.groups]
+    assert tags[0] == "head" and tags[-1] == "embed" and fp.groups[-1][1] == fp.total
+    ends = [e for _, e in fp.groups]
+    assert ends == sorted(ends)
+    # decay mask: ndim>1 parameters only (timm grouping, main_lidar_upsampling.py:282)
+    mask = fp.decay_mask
+    for k, p in m.named_parameters():
+        blk = mask[fp.offset[k] // ALIGN:(fp.offset[k] + p.numel() + ALIGN - 1) // ALIGN]
+        assert bool(blk.all()) == (p.ndim > 1) and bool(blk.any()) == (p.ndim > 1), k
+    # moving the module invalidates the binding
+    m.double()
+    assert not fp.still_bound(m)
+
+
+def test_bucket_plan_covers_buffer_once():
+    m = T.tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), **KW)
+    fp = FlatParams(m, torch.device("cpu"))
+    for mb in (0.001, 1.0, 16.0, 1000.0):
+        b = plan_buckets(fp.groups, fp.total, int(mb * (1 << 20) / 4))
+        assert b[0][1] == 0 and b[-1][2] == fp.total
+        for (_, _, e0), (_, s1, _) in zip(b, b[1:]):
+            assert e0 == s1
+        assert all(e > s for _, s, e in b)
+    assert len(plan_buckets(fp.groups, fp.total, 1 << 40)) == 1
+
+
+def test_engine_block_specs():
+    m = T.tulip_large(img_size=(16, 2048), target_img_size=(64, 2048), **KW)
+    eng = TulipEngine(m)
+    assert len(eng.blocks) == 10 + 8
+    deep = eng.enc_blocks[4]
+    assert (deep[0].H, deep[0].W, deep[0].C, deep[0].nh) == (1, 32, 1536, 48)
+    assert deep[0].win == (1, 16) and deep[0].sft == (0, 0) and deep[1].sft == (0, 8)     # backup window
+    assert eng.enc_blocks[0][1].sft == (1, 4)
+    assert eng.blocks[0].slot == -1 and eng.n_drop_slots == 2 * (len(eng.blocks) - 2)     # rate 0 twice (enc0.0, dec last.0)
+
+
+def test_cosine_lr_table(golden_dir):
+    t = np.load(os.path.join(golden_dir, "g_lr_sched.npz"))["table"]
+    for row in t:
+        assert abs(cosine_lr(row[0], row[1], row[2], row[3], row[4]) - row[5]) <= 1e-12 * max(1.0, abs(row[5]))
