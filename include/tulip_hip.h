@@ -42,14 +42,17 @@ typedef struct ihipStream_t* hipStream_t;
  * a_trans=0: A is [M][lda]; a_trans=1: A is [K][lda] (A^T stored).  Same for B ([N][ldb] / [K][ldb]).
  * Replaces nn.Linear / 1x1 nn.Conv2d forward (tulip.py:298,318,195,198,105,119,716,175) and their
  * autograd dgrad/wgrad.  Requirements: K%8==0, N%4==0, lda%8==0, ldb%8==0 (and M%8 / N%8 for the
- * transposed operands).  splits>1 only with TULIP_EPI_SPLIT_F32 / TULIP_EPI_ATOMIC_F32.
+ * transposed operands).  splits>1: the K range is cut across workgroups (for launches too small to fill 256
+ * CUs).  With TULIP_EPI_SPLIT_F32 / TULIP_EPI_ATOMIC_F32 the raw partials go to `out`; with any other epilogue
+ * the partial slabs go to `workspace` (>= effective_splits*M*N*4 bytes) and a second kernel folds them and
+ * applies the epilogue.  workspace may be NULL when splits == 1.
  * Weight-gradient form (a_trans=1, epi SPLIT_F32 or F32): if out2 != NULL it additionally receives
  * the row sums of opA, i.e. sum over tokens of dY = the bias gradient, as fp32 [splits][M] (SPLIT) or
  * [M] (F32, += when accumulate) -- computed by one extra MFMA per fragment against an all-ones operand. */
 int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,
                     int epi, const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                     const float* rowscale, int rows_per_sample, int accumulate, int psH, int psW, int splits,
-                    hipStream_t stream);
+                    void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);

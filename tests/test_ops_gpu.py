@@ -142,6 +142,36 @@ def test_gemm_wgrad_split_slabs(ops, M, Nw, Kw, splits):
     assert torch.equal(g, g2)                                    # bit-reproducible
 
 
+def test_gemm_splitk_with_fused_epilogue(ops):
+    """under-filled launches: K split across workgroups, epilogue applied by the folding kernel"""
+    M, N, K = 512, 768, 3072
+    A, B, bias = bf(rnd(M, K)), bf(rnd(N, K, scale=0.02)), rnd(N, scale=0.1)
+    ws = torch.empty(16 * M * N, device=DEV)
+    ref = A.float() @ B.float().t() + bias
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_BF16, bias=bias, out=out, splits=4, workspace=ws,
+             workspace_bytes=ws.numel() * 4)
+    close(out, ref, 2 ** -7, 2e-3, "split-k bf16")
+    resid, rs = rnd(M, N, seed=5), torch.tensor([1.0, 0.0, 1.25, 1.0], device=DEV)
+    o32 = torch.empty(M, N, device=DEV)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_RESID_F32, bias=bias, out=o32, aux=resid, ldaux=N, rowscale=rs,
+             rows_per_sample=128, splits=8, workspace=ws, workspace_bytes=ws.numel() * 4)
+    close(o32, resid + rs.repeat_interleave(128)[:, None] * ref, 1e-4, 2e-4, "split-k resid")
+    # dgrad form with the GELU' epilogue
+    dY, W2 = bf(rnd(M, 768, seed=3)), bf(rnd(768, 3072, scale=0.05, seed=4))
+    h = bf(rnd(M, 3072, seed=6))
+    dh = torch.empty(M, 3072, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dY, W2, M, 3072, 768, lda=768, ldb=3072, b_trans=True, epi=ops.EPI_GELU_BWD, out=dh, aux=h, ldaux=3072,
+             splits=3, workspace=ws, workspace_bytes=ws.numel() * 4)
+    hh = h.float().requires_grad_(True)
+    F.gelu(hh).backward(dY.float() @ W2.float())
+    close(dh, hh.grad, 2 ** -6, 3e-3, "split-k gelu bwd")
+    # a workspace that is too small is refused, not silently truncated
+    with pytest.raises(Exception):
+        ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_BF16, bias=bias, out=out, splits=4, workspace=ws,
+                 workspace_bytes=1024)
+
+
 def test_cast_colsum(ops):
     for (rows, cols, rps) in [(96, 192, 32), (32768, 96, 4096), (512, 768, 64), (40, 48, 8)]:
         x = rnd(rows, cols)

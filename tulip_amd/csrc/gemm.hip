@@ -20,6 +20,7 @@
 // Epilogues fuse: bias, exact-erf GELU (dual store), GELU backward, residual add with the
 // per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging), fp32 accumulate, and
 // split-K atomic accumulation (wgrad).
+#include <algorithm>
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -53,48 +54,58 @@ struct GemmArgs {
 __device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
 // ---- global -> registers (16 B chunks), zero fill out of range -------------------------------
-template <int ROWS, bool T>
+template <int ROWS, bool T, int KSUB>
 struct Stage {
-    static constexpr int NCHUNK = ROWS * 4;                 // 16-B chunks per 32-deep k tile
+    static constexpr int NCHUNK = ROWS * 4;                 // 16-B chunks per 32-deep k sub-tile
     static constexpr int PER_THREAD = (NCHUNK + 255) / 256;
-    uint4 r[PER_THREAD];
+    static constexpr int SUB_BYTES = T ? 32 * T_PITCH : ROWS * 64;   // LDS bytes of one sub-tile
+    uint4 r[KSUB][PER_THREAD];
 
+    // KSUB sub-tiles of 32 k each: all their 16-B loads are issued back to back (memory-level
+    // parallelism is what the small-M / large-K launches of the deep stages are starved of)
     __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int nrows, int k0, int kend,
                                          int tid) {
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            int c = tid + i * 256;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (NCHUNK % 256 == 0 || c < NCHUNK) {
-                if (!T) {
-                    int row = c >> 2, kc = c & 3;
-                    int gr = row0 + row, gk = k0 + kc * 8;
-                    if (gr < nrows && gk < kend) v = *(const uint4*)(base + (size_t)gr * ld + gk);
-                } else {
-                    constexpr int CPR = ROWS / 8;  // chunks per k row
-                    int k = c / CPR, mc = c % CPR;
-                    int gk = k0 + k, gr = row0 + mc * 8;
-                    if (gk < kend && gr < nrows) v = *(const uint4*)(base + (size_t)gk * ld + gr);
+        for (int sidx = 0; sidx < KSUB; ++sidx) {
+            const int ks = k0 + sidx * 32;
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                int c = tid + i * 256;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (NCHUNK % 256 == 0 || c < NCHUNK) {
+                    if (!T) {
+                        int row = c >> 2, kc = c & 3;
+                        int gr = row0 + row, gk = ks + kc * 8;
+                        if (gr < nrows && gk < kend) v = *(const uint4*)(base + (size_t)gr * ld + gk);
+                    } else {
+                        constexpr int CPR = ROWS / 8;  // chunks per k row
+                        int k = c / CPR, mc = c % CPR;
+                        int gk = ks + k, gr = row0 + mc * 8;
+                        if (gk < kend && gr < nrows) v = *(const uint4*)(base + (size_t)gk * ld + gr);
+                    }
                 }
+                r[sidx][i] = v;
             }
-            r[i] = v;
         }
     }
     __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            int c = tid + i * 256;
-            if (NCHUNK % 256 == 0 || c < NCHUNK) {
-                int off;
-                if (!T) {
-                    int row = c >> 2, kc = c & 3;
-                    off = row * 64 + ((kc ^ swz4(row)) << 4);
-                } else {
-                    constexpr int CPR = ROWS / 8;
-                    int k = c / CPR, mc = c % CPR;
-                    off = k * T_PITCH + ((((mc >> 1) ^ (((k >> 3) & 1) << 2))) << 5) + ((mc & 1) << 4);
+        for (int sidx = 0; sidx < KSUB; ++sidx) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                int c = tid + i * 256;
+                if (NCHUNK % 256 == 0 || c < NCHUNK) {
+                    int off;
+                    if (!T) {
+                        int row = c >> 2, kc = c & 3;
+                        off = row * 64 + ((kc ^ swz4(row)) << 4);
+                    } else {
+                        constexpr int CPR = ROWS / 8;
+                        int k = c / CPR, mc = c % CPR;
+                        off = k * T_PITCH + ((((mc >> 1) ^ (((k >> 3) & 1) << 2))) << 5) + ((mc & 1) << 4);
+                    }
+                    *(uint4*)(lds + sidx * SUB_BYTES + off) = r[sidx][i];
                 }
-                *(uint4*)(lds + off) = r[i];
             }
         }
     }
@@ -222,20 +233,24 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
     }
 }
 
-template <int BM, bool A_T, bool B_T>
+template <int BM, bool A_T, bool B_T, int KSUB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int FM = BM / 32;  // 16-row fragments per wave in M
     constexpr int FN = 3;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
-    auto ldsA = [&](int buf) -> unsigned char* { return smem + buf * (2 * TILE_BYTES); };
-    auto ldsB = [&](int buf) -> unsigned char* { return smem + buf * (2 * TILE_BYTES) + TILE_BYTES; };
+    using SA = Stage<BM, A_T, KSUB>;
+    using SB = Stage<BN, B_T, KSUB>;
+    constexpr int A_BYTES = KSUB * SA::SUB_BYTES, B_BYTES = KSUB * SB::SUB_BYTES;
+    constexpr int BKS = BK * KSUB;  // k depth of one pipeline stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    auto ldsA = [&](int buf) -> unsigned char* { return smem + buf * (A_BYTES + B_BYTES); };
+    auto ldsB = [&](int buf) -> unsigned char* { return smem + buf * (A_BYTES + B_BYTES) + A_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
-    const int nt = (kend - kbeg + BK - 1) / BK;
+    const int nt = (kend - kbeg + BKS - 1) / BKS;
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -243,8 +258,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    Stage<BM, A_T> sa;
-    Stage<BN, B_T> sb;
+    SA sa;
+    SB sb;
     if (nt > 0) {
         sa.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
         sb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
@@ -266,29 +281,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            sa.load(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid);
-            sb.load(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid);
+            sa.load(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BKS, kend, tid);
+            sb.load(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BKS, kend, tid);
         }
-        bf16x8 af[FM], bfr[FN];
-        if (!A_T) {
+        const int ksub_valid = min(KSUB, (kend - (kbeg + t * BKS) + BK - 1) / BK);  // block-uniform
 #pragma unroll
-            for (int f = 0; f < FM; ++f) af[f] = frag_n(ldsA(cur), wm * (BM / 2) + f * 16 + li, g);
-        }
-        if (!B_T) {
+        for (int sidx = 0; sidx < KSUB; ++sidx) {
+            if (KSUB > 1 && sidx >= ksub_valid) break;
+            const unsigned char* la = ldsA(cur) + sidx * SA::SUB_BYTES;
+            const unsigned char* lb = ldsB(cur) + sidx * SB::SUB_BYTES;
+            bf16x8 af[FM], bfr[FN];
+            if (!A_T) {
 #pragma unroll
-            for (int f = 0; f < FN; ++f) bfr[f] = frag_n(ldsB(cur), wn * 48 + f * 16 + li, g);
-        }
-        if (A_T) frag_t<FM>(ldsA(cur), wm * (BM / 32), lane, af);
-        if (B_T) frag_t<FN>(ldsB(cur), wn * 3, lane, bfr);
+                for (int f = 0; f < FM; ++f) af[f] = frag_n(la, wm * (BM / 2) + f * 16 + li, g);
+            }
+            if (!B_T) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        if (A_T && do_rowsum) {
+                for (int f = 0; f < FN; ++f) bfr[f] = frag_n(lb, wn * 48 + f * 16 + li, g);
+            }
+            if (A_T) frag_t<FM>(la, wm * (BM / 32), lane, af);
+            if (B_T) frag_t<FN>(lb, wn * 3, lane, bfr);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], rsum[i], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (A_T && do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], rsum[i], 0, 0, 0);
+            }
         }
         if (t + 1 < nt) {
             sa.store(ldsA(cur ^ 1), tid);
@@ -320,17 +342,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+// split-K for the ordinary epilogues: the GEMM wrote raw fp32 partial slabs [splits][M][N]; fold them
+// and apply the fused epilogue (bias / GELU / residual / ...) once.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, const float* __restrict__ slabs,
+                                                              int splits) {
+    const int n4 = p.N >> 2;
+    const int64_t total = (int64_t)p.M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float4 v = *(const float4*)(slabs + ((size_t)sidx * p.M + m) * p.N + n);
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        }
+        epilogue(p, m, n, acc);
+    }
+}
+
 template <bool A_T, bool B_T>
 int launch(const GemmArgs& p, int splits, hipStream_t stream) {
-    // pick BM=64 when BM=128 would leave most of the 256 CUs idle
+    // BM=64 (with 128-deep k stages: 4 sub-tiles of loads in flight per thread) when BM=128 would leave
+    // most of the 256 CUs idle -- the small-M / large-K GEMMs of the deep stages are load-latency bound
     const int gn = (p.N + BN - 1) / BN;
     const bool small = ((p.M + 127) / 128) * gn * splits < 256 && p.M > 64;
     if (small || p.M <= 64) {
         dim3 grid(gn, (p.M + 63) / 64, splits);
-        hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T>), grid, dim3(256), 0, stream, p);
+        // 1 workgroup/CU (deep stages, 80-150 KB LDS) only pays when the grid cannot fill the chip anyway
+        if ((int)(grid.x * grid.y * grid.z) <= 192 && p.kchunk >= 256)
+            hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 4>), grid, dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
     } else {
         dim3 grid(gn, (p.M + 127) / 128, splits);
-        hipLaunchKernelGGL((gemm_kernel<128, A_T, B_T>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_kernel<128, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
     }
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
@@ -349,13 +393,18 @@ extern "C" int tulip_gemm_effective_splits(int K, int splits) { return K > 0 ? e
 extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N,
                                int K, int epi, const float* bias, void* out, int ldo, void* out2, int ldo2,
                                const void* aux, int ldaux, const float* rowscale, int rows_per_sample, int accumulate,
-                               int psH, int psW, int splits, hipStream_t stream) {
+                               int psH, int psW, int splits, void* workspace, int64_t workspace_bytes,
+                               hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return TULIP_OK;
     if ((K & 7) || (N & 3) || (lda & 7) || (ldb & 7)) return TULIP_ERR_ARG;
     if (a_trans && (M & 7)) return TULIP_ERR_ARG;
     if (b_trans && (N & 7)) return TULIP_ERR_ARG;
     if (splits < 1) splits = 1;
-    if (splits > 1 && epi != TULIP_EPI_ATOMIC_F32 && epi != TULIP_EPI_SPLIT_F32) return TULIP_ERR_ARG;
+    const bool raw_split = epi == TULIP_EPI_ATOMIC_F32 || epi == TULIP_EPI_SPLIT_F32;
+    if (splits > 1 && !raw_split) {
+        splits = effective_splits(K, splits);
+        if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4)) return TULIP_ERR_ARG;
+    }
     if ((epi == TULIP_EPI_RESID_F32 || epi == TULIP_EPI_GELU_BWD) && !aux) return TULIP_ERR_ARG;
     if (epi == TULIP_EPI_GELU_DUAL && !out2) return TULIP_ERR_ARG;
     GemmArgs p;
@@ -367,8 +416,20 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     p.epi = epi; p.bias = bias; p.out = out; p.ldo = ldo; p.out2 = out2; p.ldo2 = ldo2;
     p.aux = aux; p.ldaux = ldaux; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
     p.accumulate = accumulate; p.psH = psH; p.psW = psW;
-    if (!a_trans && !b_trans) return launch<false, false>(p, splits, stream);
-    if (!a_trans && b_trans) return launch<false, true>(p, splits, stream);
-    if (a_trans && b_trans) return launch<true, true>(p, splits, stream);
-    return launch<true, false>(p, splits, stream);
+    GemmArgs q = p;  // what the GEMM kernel itself does
+    const bool fold = splits > 1 && !raw_split;
+    if (fold) {
+        q.epi = TULIP_EPI_SPLIT_F32; q.bias = nullptr; q.out = workspace; q.ldo = N; q.out2 = nullptr;
+    }
+    int rc;
+    if (!a_trans && !b_trans) rc = launch<false, false>(q, splits, stream);
+    else if (!a_trans && b_trans) rc = launch<false, true>(q, splits, stream);
+    else if (a_trans && b_trans) rc = launch<true, true>(q, splits, stream);
+    else rc = launch<true, false>(q, splits, stream);
+    if (rc != TULIP_OK || !fold) return rc;
+    const int64_t work = (int64_t)M * (N >> 2);
+    const int grid = (int)std::min<int64_t>((work + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, p, (const float*)workspace, splits);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
 }

@@ -346,18 +346,18 @@ class TulipEngine:
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
         ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
                           P[p + ".mean1"], P[p + ".rstd1"], M, C, self.eps)
-        ops.gemm(P[p + ".xn1"], W_.p16(p + ".attn.qkv.weight"), M, 3 * C, C, lda=C, ldb=C, epi=EPI_BF16,
+        self._gemm(P[p + ".xn1"], W_.p16(p + ".attn.qkv.weight"), M, 3 * C, C, lda=C, ldb=C, epi=EPI_BF16,
                  bias=W_.p32(p + ".attn.qkv.bias"), out=P[p + ".qkv"])
         ops.window_attn_fwd(P[p + ".qkv"], W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, P[p + ".o"],
                             B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
-        ops.gemm(P[p + ".o"], W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, epi=EPI_RESID_F32,
+        self._gemm(P[p + ".o"], W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, epi=EPI_RESID_F32,
                  bias=W_.p32(p + ".attn.proj.bias"), out=P[p + ".x1"], aux=xin, ldaux=C,
                  rowscale=self._ds(P, sp, 0), rows_per_sample=tok)
         ops.layernorm_fwd(P[p + ".x1"], W_.p32(p + ".norm2.weight"), W_.p32(p + ".norm2.bias"), P[p + ".xn2"],
                           P[p + ".mean2"], P[p + ".rstd2"], M, C, self.eps)
-        ops.gemm(P[p + ".xn2"], W_.p16(p + ".mlp.fc1.weight"), M, Hd, C, lda=C, ldb=C, epi=EPI_GELU_DUAL,
+        self._gemm(P[p + ".xn2"], W_.p16(p + ".mlp.fc1.weight"), M, Hd, C, lda=C, ldb=C, epi=EPI_GELU_DUAL,
                  bias=W_.p32(p + ".mlp.fc1.bias"), out=P[p + ".h"], out2=P[p + ".g"], ldo2=Hd)
-        ops.gemm(P[p + ".g"], W_.p16(p + ".mlp.fc2.weight"), M, C, Hd, lda=Hd, ldb=Hd, epi=EPI_RESID_F32,
+        self._gemm(P[p + ".g"], W_.p16(p + ".mlp.fc2.weight"), M, C, Hd, lda=Hd, ldb=Hd, epi=EPI_RESID_F32,
                  bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], ldaux=C,
                  rowscale=self._ds(P, sp, 1), rows_per_sample=tok)
 
@@ -375,7 +375,7 @@ class TulipEngine:
         H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
         M = B * H * W
         ops.cast_f32_bf16(x, P[f"lvl{s}.xb"], M, C)
-        ops.gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
+        self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=out, psH=H, psW=W)
 
     def run_forward(self, P: Plan, with_loss: bool = True):
@@ -400,7 +400,7 @@ class TulipEngine:
                 ops.layernorm_fwd(x, W_.p32(pre + ".norm.weight"), W_.p32(pre + ".norm.bias"), P[f"enc{s}.xm"],
                                   P[f"enc{s}.mmean"], P[f"enc{s}.mrstd"], rows, 4 * Cs, self.eps, merge=True, B=B,
                                   H=Hs, W=Ws)
-                ops.gemm(P[f"enc{s}.xm"], W_.p16(pre + ".reduction.weight"), rows, 2 * Cs, 4 * Cs, lda=4 * Cs,
+                self._gemm(P[f"enc{s}.xm"], W_.p16(pre + ".reduction.weight"), rows, 2 * Cs, 4 * Cs, lda=4 * Cs,
                          ldb=4 * Cs, epi=EPI_F32, out=P[f"enc{s + 1}.in"])
         self._unmerge_fwd(P, "first_patch_expanding", nl - 1, x, P[f"dec{nl - 2}.xu"])
         for i in range(nl - 1):
@@ -409,7 +409,7 @@ class TulipEngine:
             Ms = B * (H0 >> s) * (W0 >> s)
             pre = f"skip_connection_layers.{i}"
             ops.concat_cast(P[f"dec{s}.xu"], P[f"enc{s}.in"], P[f"dec{s}.cat"], Ms, Cs)      # tulip.py:715
-            ops.gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
+            self._gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
                      bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"])
             x = self._stage_fwd(P, self.dec_blocks[i], P[f"dec{s}.in"])
             if i < nl - 2:
@@ -436,6 +436,19 @@ class TulipEngine:
             if e == s:
                 return s
             s = e
+
+    def _gemm(self, A, B, M, N, K, **kw):
+        """Forward / dgrad GEMM.  Launches that cannot fill the chip and have a deep K (the M=512..2048 GEMMs
+        of stages 2-3 stream megabytes of weights through a few dozen workgroups) are split along K; the
+        library folds the partial slabs and applies the fused epilogue in a second kernel."""
+        gn = (N + 95) // 96
+        blocks = ((M + 63) // 64) * gn if ((M + 127) // 128) * gn < 256 else ((M + 127) // 128) * gn
+        if blocks <= 96 and K >= 768:
+            s = max(1, min(256 // blocks, K // 256, (self.WS_ELEMS * 4) // (M * N * 4)))
+            if s > 1:
+                ops.gemm(A, B, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, **kw)
+                return
+        ops.gemm(A, B, M, N, K, **kw)
 
     def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
         """dW[Nw,Kw] += dY[Mtok,Nw]^T . X[Mtok,Kw]  and, for free, db[Nw] += sum_tokens dY (row sums of the
@@ -474,17 +487,17 @@ class TulipEngine:
         dyb, dxn, dO, dh, dqkv = P["t.dyb"], P["t.dxn"], P["t.do"], P["t.dh"], P["t.dqkv"]
         # ---- MLP branch (tulip.py:346-351)
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
-        ops.gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
+        self._gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
                  ldo=Hd, aux=P[p + ".h"], ldaux=Hd)
         self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
-        ops.gemm(dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, lda=Hd, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn,
+        self._gemm(dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, lda=Hd, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn,
                  ldo=C)
         self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
         self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
                      G(p + ".norm2.weight"), G(p + ".norm2.bias"))
         # ---- attention branch (tulip.py:339-344)
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 0), tok)
-        ops.gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
+        self._gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
                  ldo=C)
         self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
         dense, apart = P.dense_bias, P.attn_part_ptr
@@ -494,7 +507,7 @@ class TulipEngine:
         ops.reduce_rows2(apart, nh * 256, dense, nh * 256, None, 0, None, 0,
                          ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, nh, sp.win))
         ops.bias_table_scatter(dense, self._rel32, G(p + ".attn.relative_position_bias_table"), nh, 16)
-        ops.gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
+        self._gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
                  out=dxn, ldo=C)
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
         self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
@@ -515,7 +528,7 @@ class TulipEngine:
         dz = P["t.dz2"]
         ops.unshuffle2_cast(dfine, dz, B, H, W, C // 2)
         self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), G(prefix + ".expand.bias"))
-        ops.gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
+        self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
                  out=dx_out, ldo=C)
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None):
@@ -536,7 +549,7 @@ class TulipEngine:
         ops.reduce_rows2(tpart, 128, G("decoder_pred.weight"), E, None, 0, None, 0, (M0 + 127) // 128)
         self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),
                     G("ps_head.conv_expand.0.bias"))
-        ops.gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
+        self._gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
                  epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
@@ -558,7 +571,7 @@ class TulipEngine:
             ops.cast_f32_bf16(dx, dys, Ms, Cs)
             self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
             # grad w.r.t. the first concat half (the unmerged stream); the x_save half is deferred
-            ops.gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32,
+            self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32,
                      out=P[f"dec{s}.dxu"], ldo=Cs)
             hook(f"dec{i}")
         # ---- bottleneck unmerge
@@ -574,7 +587,7 @@ class TulipEngine:
                 Cs = E << s
                 Ms = B * (H0 >> s) * (W0 >> s)
                 i = nl - s - 2
-                ops.gemm(P[f"dec{s}.dyskip"], W_.p16(f"skip_connection_layers.{i}.weight") + 2 * Cs, Ms, Cs, Cs,
+                self._gemm(P[f"dec{s}.dyskip"], W_.p16(f"skip_connection_layers.{i}.weight") + 2 * Cs, Ms, Cs, Cs,
                          lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32, out=dx, ldo=Cs, accumulate=True)
             if s > 0:
                 # PatchMerging backward of level s-1
@@ -586,7 +599,7 @@ class TulipEngine:
                 ops.cast_f32_bf16(dx, dyb, rows, 2 * Cp)
                 self._wgrad(dyb, 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows,
                             G(pre + ".reduction.weight"))
-                ops.gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,
+                self._gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,
                          b_trans=True, epi=EPI_BF16, out=dxm, ldo=4 * Cp)
                 xprev = P[self.enc_blocks[s - 1][-1].prefix + ".out"]
                 self._ln_bwd(P, dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"], W_.p32(pre + ".norm.weight"),

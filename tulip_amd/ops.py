@@ -33,13 +33,14 @@ def _chk(t: torch.Tensor, dtype, name: str):
 
 def gemm(A, B, M, N, K, *, lda, ldb, a_trans=False, b_trans=False, epi=EPI_BF16, bias=None, out=None, ldo=None,
          out2=None, ldo2=0, aux=None, ldaux=0, rowscale=None, rows_per_sample=1, accumulate=False, psH=0, psW=0,
-         splits=1):
+         splits=1, workspace=None, workspace_bytes=0):
     """C[M,N] = opA . opB^T with a fused epilogue (see include/tulip_hip.h).  A/B/out may be views
     with an element offset (row strides passed as lda/ldb/ldo)."""
     lib = _lib.load()
     rc = lib.tulip_gemm_bf16(_p(A), lda, int(a_trans), _p(B), ldb, int(b_trans), M, N, K, epi, _p(bias), _p(out),
                              ldo if ldo is not None else N, _p(out2), ldo2, _p(aux), ldaux, _p(rowscale),
-                             rows_per_sample, int(accumulate), psH, psW, splits, _stream())
+                             rows_per_sample, int(accumulate), psH, psW, splits, _p(workspace), workspace_bytes,
+                             _stream())
     check(rc, "tulip_gemm_bf16")
 
 
