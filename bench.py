@@ -49,45 +49,82 @@ def synthetic(args, rank, device):
     return lo.to(device), hi.to(device)
 
 
-def gemm_roofline(trainer):
-    """Eager pass with a HIP-event pair around every GEMM launch (same stream)."""
+def _gemm_instance(M, N, K, a_trans, b_trans, splits):
+    """which gemm_kernel<BM,A_T,B_T,KSUB> tulip_gemm_bf16 launches (mirrors csrc/gemm.hip launch())"""
     from tulip_amd import ops
-    rec = []
+    eff = ops.gemm_effective_splits(K, splits)
+    kchunk = -(-(-(-K // eff)) // 32) * 32
+    gn = -(-N // 96)
+    if (-(-M // 128) * gn * eff < 256 and M > 64) or M <= 64:
+        grid = gn * -(-M // 64) * eff
+        ksub = 4 if (grid <= 192 and kchunk >= 256) else 1
+        bm = 64
+    else:
+        bm, ksub = 128, 1
+    t = lambda f: "true" if f else "false"
+    return f"gemm_kernel<{bm}, {t(a_trans)}, {t(b_trans)}, {ksub}>"
+
+
+def gemm_roofline(trainer, reps=5):
+    """Roofline of the dominant kernel family (the bf16 MFMA GEMM: 98.7 % of the step's FLOPs).
+    The ~200 GEMM launches of one step are recorded in an eager pass, then each is re-issued `reps`
+    times back to back between ONE HIP-event pair on the launch stream (graph nodes cannot be
+    instrumented, and eager launches would include host gaps).  achieved = sum(algorithmic FLOPs) /
+    sum(mean duration); per-instantiation mean durations are listed for comparison with rocprofv3."""
+    from tulip_amd import ops
+    calls = []
     real = ops.gemm
 
-    def timed(A, B, M, N, K, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    def record(A, B, M, N, K, **kw):
+        calls.append((A, B, M, N, K, kw))
         real(A, B, M, N, K, **kw)
-        e1.record()
-        kind = ("wgrad" if kw.get("a_trans") else ("dgrad" if kw.get("b_trans") else "fwd"))
-        rec.append((e0, e1, 2.0 * M * N * K, kind, (M, N, K)))
 
-    ops.gemm = timed
+    ops.gemm = record
     try:
-        for _ in range(2):
-            rec.clear()
-            trainer._fwd_bwd(lambda tag: None)
-            torch.cuda.synchronize()
+        trainer._fwd_bwd(lambda tag: None)
+        torch.cuda.synchronize()
     finally:
         ops.gemm = real
-    tot_t = sum(a.elapsed_time(b) for a, b, *_ in rec) * 1e-3
-    tot_f = sum(r[2] for r in rec)
-    by = {}
-    for a, b, f, kind, _ in rec:
-        t, ff, n = by.get(kind, (0.0, 0.0, 0))
-        by[kind] = (t + a.elapsed_time(b) * 1e-3, ff + f, n + 1)
-    detail = {k: {"launches": n, "ms": round(t * 1e3, 3), "tflops": round(ff / t / 1e12, 1)} for k, (t, ff, n) in by.items()}
-    return {"bound": "mfma", "kernel": "gemm_kernel<BM,A_T,B_T> (all linears / 1x1 convs, fwd+dgrad+wgrad)",
+    by_inst, tot_t, tot_f = {}, 0.0, 0.0
+    for A, B, M, N, K, kw in calls:
+        real(A, B, M, N, K, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            real(A, B, M, N, K, **kw)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        f = 2.0 * M * N * K
+        name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
+        d = by_inst.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1; d[1] += t; d[2] += f
+        tot_t += t; tot_f += f
+    detail = {k: {"launches": n, "avg_us": round(t / n * 1e6, 2), "tflops": round(f / t / 1e12, 1)}
+              for k, (n, t, f) in sorted(by_inst.items(), key=lambda kv: -kv[1][1])}
+    return {"bound": "mfma", "kernel": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv: fwd + dgrad + wgrad)",
             "achieved": round(tot_f / tot_t / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-            "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": None, "launches_per_step": len(rec),
-            "gemm_ms_per_step": round(tot_t * 1e3, 3), "by_kind": detail}
+            "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": None, "launches_per_step": len(calls),
+            "gemm_ms_per_step": round(tot_t * 1e3, 3), "flops_per_step": tot_f, "by_kernel": detail}
+
+
+def usable_cores() -> int:
+    """Host cores this process may really use: min(affinity, cgroup CPU quota).  (The GPU boxes report 256
+    logical CPUs but run under a 16-CPU quota; 256 OpenMP threads there are ~200x slower than 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(args):
     """Oracle training step (fwd + loss + autograd bwd + torch AdamW) on the host cores."""
     from oracle import tulip_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = O.tulip_base_config(img_size=tuple(args.img), target_img_size=tuple(args.target))
     sd = O.key_seeded_state_dict(cfg, seed=0, randomize_affine=False)
