@@ -376,7 +376,7 @@ def window_attention(pr: _Prec, sd, prefix: str, cfg: TulipConfig, x: Tensor, nh
     win, sft = effective_window(H, cfg.window_size, shift)
     L = win[0] * win[1]
     P = C // nh
-    idx = torch.from_numpy(window_token_index(H, W, win, sft))          # (nW, L)
+    idx = torch.from_numpy(window_token_index(H, W, win, sft)).to(x.device)   # (nW, L)
     nW = idx.shape[0]
     tok = x.reshape(B, H * W, C)[:, idx.reshape(-1), :].reshape(B * nW, L, C)
     qkv = pr.r(linear(pr, tok, sd[f"{prefix}.attn.qkv.weight"], sd[f"{prefix}.attn.qkv.bias"]))
@@ -387,14 +387,14 @@ def window_attention(pr: _Prec, sd, prefix: str, cfg: TulipConfig, x: Tensor, nh
     bias = sd[f"{prefix}.attn.relative_position_bias_table"][rpi].reshape(L, L, nh).permute(2, 0, 1)
     attn = attn + bias.unsqueeze(0)
     if shift:
-        mask = torch.from_numpy(shift_attention_mask(H, W, win, sft))    # (nW, L, L)
+        mask = torch.from_numpy(shift_attention_mask(H, W, win, sft)).to(x.device)  # (nW, L, L)
         attn = attn.reshape(B, nW, nh, L, L) + mask[None, :, None]
         attn = attn.reshape(B * nW, nh, L, L)
     attn = torch.softmax(attn, dim=-1)
     o = pr.r(attn) @ v                                                   # (Bn, Nh, L, P)
     o = pr.r(o.permute(0, 2, 1, 3).reshape(B * nW, L, C))
     o = linear(pr, o, sd[f"{prefix}.attn.proj.weight"], sd[f"{prefix}.attn.proj.bias"])
-    out = torch.zeros(B, H * W, C, dtype=o.dtype)
+    out = torch.zeros(B, H * W, C, dtype=o.dtype, device=o.device)
     out[:, idx.reshape(-1), :] = o.reshape(B, nW * L, C)                 # inverse permutation
     return out.reshape(B, H, W, C)
 
