@@ -41,7 +41,7 @@ typedef struct ihipStream_t* hipStream_t;
 /* C[M,N] = opA[M,K] . opB[N,K]^T, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
  * a_trans=0: A is [M][lda]; a_trans=1: A is [K][lda] (A^T stored).  Same for B ([N][ldb] / [K][ldb]).
  * Replaces nn.Linear / 1x1 nn.Conv2d forward (tulip.py:298,318,195,198,105,119,716,175) and their
- * autograd dgrad/wgrad.  Requirements: K%8==0, N%4==0, lda%8==0, ldb%8==0 (and M%8 / N%8 for the
+ * autograd dgrad/wgrad.  Requirements: K%8==0, N%8==0, lda%8==0, ldb%8==0 (and M%8 / N%8 for the
  * transposed operands).  splits>1: the K range is cut across workgroups (for launches too small to fill 256
  * CUs).  With TULIP_EPI_SPLIT_F32 / TULIP_EPI_ATOMIC_F32 the raw partials go to `out`; with any other epilogue
  * the partial slabs go to `workspace` (>= effective_splits*M*N*4 bytes) and a second kernel folds them and

@@ -21,6 +21,7 @@
 // per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging), fp32 accumulate, and
 // split-K atomic accumulation (wgrad).
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -164,70 +165,84 @@ __device__ __forceinline__ void frag_t(const unsigned char* lds, int c32_0, int 
         out[f] = __builtin_shufflevector(lo[f], hi[f], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// ---- epilogue: 4 consecutive columns n..n+3 of row m ------------------------------------------
-__device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 acc) {
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+// ---- epilogue: 8 consecutive columns n..n+7 of row m (16-B bf16 / 32-B fp32 accesses) -----------
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void unpack8(uint4 u, float* h) {
+    h[0] = bf2f((bf16_t)(u.x & 0xffff)); h[1] = bf2f((bf16_t)(u.x >> 16));
+    h[2] = bf2f((bf16_t)(u.y & 0xffff)); h[3] = bf2f((bf16_t)(u.y >> 16));
+    h[4] = bf2f((bf16_t)(u.z & 0xffff)); h[5] = bf2f((bf16_t)(u.z >> 16));
+    h[6] = bf2f((bf16_t)(u.w & 0xffff)); h[7] = bf2f((bf16_t)(u.w >> 16));
+}
+
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float4 lo, float4 hi, int zsplit) {
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (p.bias) {
-        float4 b = *(const float4*)(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
     switch (p.epi) {
         case TULIP_EPI_BF16: {
-            uint2 o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+            *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = pack8(v);
         } break;
         case TULIP_EPI_GELU_DUAL: {
-            bf16_t h[4];
-            float g[4];
+            const uint4 hb = pack8(v);
+            float h[8], g[8];
+            unpack8(hb, h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { h[r] = f2bf(v[r]); g[r] = gelu_exact(bf2f(h[r])); }
-            *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) =
-                make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            *(uint2*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) =
-                make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+            for (int r = 0; r < 8; ++r) g[r] = gelu_exact(h[r]);   // gelu of the *stored* (rounded) h
+            *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = hb;
+            *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(g);
         } break;
         case TULIP_EPI_GELU_BWD: {
-            uint2 hh = *(const uint2*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
-            float h0 = bf2f((bf16_t)(hh.x & 0xffff)), h1 = bf2f((bf16_t)(hh.x >> 16));
-            float h2 = bf2f((bf16_t)(hh.y & 0xffff)), h3 = bf2f((bf16_t)(hh.y >> 16));
-            uint2 o = make_uint2(pack_bf16x2(v[0] * gelu_exact_grad(h0), v[1] * gelu_exact_grad(h1)),
-                                 pack_bf16x2(v[2] * gelu_exact_grad(h2), v[3] * gelu_exact_grad(h3)));
-            *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+            float h[8];
+            unpack8(*(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), h);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= gelu_exact_grad(h[r]);
+            *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = pack8(v);
         } break;
         case TULIP_EPI_F32: {
             float* o = (float*)p.out + (size_t)m * p.ldo + n;
-            float4 r = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.accumulate) { float4 q = *(float4*)o; r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
-            *(float4*)o = r;
+            if (p.accumulate) {
+                const float4 q0 = *(const float4*)o, q1 = *(const float4*)(o + 4);
+                v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
+                v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+            }
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } break;
         case TULIP_EPI_RESID_F32: {
-            float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
-            float4 q = *(const float4*)((const float*)p.aux + (size_t)m * p.ldaux + n);
-            *(float4*)((float*)p.out + (size_t)m * p.ldo + n) =
-                make_float4(q.x + s * v[0], q.y + s * v[1], q.z + s * v[2], q.w + s * v[3]);
+            const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+            const float* a = (const float*)p.aux + (size_t)m * p.ldaux + n;
+            const float4 q0 = *(const float4*)a, q1 = *(const float4*)(a + 4);
+            float* o = (float*)p.out + (size_t)m * p.ldo + n;
+            *(float4*)o = make_float4(q0.x + s * v[0], q0.y + s * v[1], q0.z + s * v[2], q0.w + s * v[3]);
+            *(float4*)(o + 4) = make_float4(q1.x + s * v[4], q1.y + s * v[5], q1.z + s * v[6], q1.w + s * v[7]);
         } break;
         case TULIP_EPI_PIXSHUF2_F32: {
             // token m=(b*H+h)*W+w, column n=4c+2i+j  ->  out[b, 2h+i, 2w+j, c], C_out = N/4
-            int w = m % p.psW, t = m / p.psW;
-            int h = t % p.psH, b = t / p.psH;
-            int co = p.N >> 2, c = n >> 2;
+            const int w = m % p.psW, t = m / p.psW;
+            const int h = t % p.psH, b = t / p.psH;
+            const int co = p.N >> 2;
             float* o = (float*)p.out;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int i = r >> 1, j = r & 1;
-                size_t idx = (((size_t)b * 2 * p.psH + 2 * h + i) * (2 * p.psW) + 2 * w + j) * co + c;
-                o[idx] = v[r];
+            for (int r = 0; r < 8; ++r) {
+                const int c = (n + r) >> 2, i = (r >> 1) & 1, j = r & 1;
+                o[(((size_t)b * 2 * p.psH + 2 * h + i) * (2 * p.psW) + 2 * w + j) * co + c] = v[r];
             }
         } break;
         case TULIP_EPI_SPLIT_F32: {
-            // split-K partial slab: out is [splits][M][ldo], reduced by tulip_reduce_splits
-            float* o = (float*)p.out + ((size_t)blockIdx.z * p.M + m) * p.ldo + n;
+            // split-K partial slab: out is [splits][M][ldo], folded by tulip_reduce_rows2 / splitk_epilogue
+            float* o = (float*)p.out + ((size_t)zsplit * p.M + m) * p.ldo + n;
             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } break;
         case TULIP_EPI_ATOMIC_F32: {
             float* o = (float*)p.out + (size_t)m * p.ldo + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(o + r, v[r]);
+            for (int r = 0; r < 8; ++r) atomicAdd(o + r, v[r]);
         } break;
         default: break;
     }
@@ -241,7 +256,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     using SB = Stage<BN, B_T, KSUB>;
     constexpr int A_BYTES = KSUB * SA::SUB_BYTES, B_BYTES = KSUB * SB::SUB_BYTES;
     constexpr int BKS = BK * KSUB;  // k depth of one pipeline stage
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    constexpr int STG_PITCH = BN * 4 + 16;                 // fp32 staging row pitch (bank-spread)
+    constexpr int STG_BYTES = 64 * STG_PITCH;              // 64 output rows per write-out pass
+    constexpr int PIPE_BYTES = 2 * (A_BYTES + B_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PIPE_BYTES > STG_BYTES ? PIPE_BYTES : STG_BYTES];
     auto ldsA = [&](int buf) -> unsigned char* { return smem + buf * (A_BYTES + B_BYTES); };
     auto ldsB = [&](int buf) -> unsigned char* { return smem + buf * (A_BYTES + B_BYTES) + A_BYTES; };
 
@@ -258,13 +276,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    SA sa;
-    SB sb;
+    // Register prefetch ring: RING-1 stages of global loads are in flight while one stage is computed
+    // (PMC: with a single prefetch stage the waves sat 62-73 % of their cycles in s_waitcnt / s_barrier).
+    // Ring slots are selected with compile-time indices (the loop is unrolled by RING) so the staging
+    // registers never spill to scratch; the compiler's counted vmcnt keeps the younger stage in flight
+    // while the older one is written to LDS.
+    constexpr int RING = (KSUB == 1) ? 3 : 2;
+    SA sa[RING];
+    SB sb[RING];
+    auto issue = [&](auto R, int t) {
+        constexpr int r = decltype(R)::value;
+        sa[r].load(p.A, p.lda, m0, p.M, kbeg + t * BKS, kend, tid);
+        sb[r].load(p.B, p.ldb, n0, p.N, kbeg + t * BKS, kend, tid);
+    };
+    if (nt > 0) issue(std::integral_constant<int, 0>{}, 0);
+    if (RING > 2 && nt > 1) issue(std::integral_constant<int, 1>{}, 1);
     if (nt > 0) {
-        sa.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
-        sb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-        sa.store(ldsA(0), tid);
-        sb.store(ldsB(0), tid);
+        sa[0].store(ldsA(0), tid);
+        sb[0].store(ldsB(0), tid);
     }
     __syncthreads();
 
@@ -278,12 +307,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     for (int i = 0; i < FM; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const short one = (short)0x3F80;
     const bf16x8 ones = {one, one, one, one, one, one, one, one};
-    for (int t = 0; t < nt; ++t) {
+
+    auto step = [&](auto R, int t) {
+        constexpr int r = decltype(R)::value;
         const int cur = t & 1;
-        if (t + 1 < nt) {
-            sa.load(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BKS, kend, tid);
-            sb.load(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BKS, kend, tid);
-        }
+        if (t + RING - 1 < nt) issue(std::integral_constant<int, (r + RING - 1) % RING>{}, t + RING - 1);
         const int ksub_valid = min(KSUB, (kend - (kbeg + t * BKS) + BK - 1) / BK);  // block-uniform
 #pragma unroll
         for (int sidx = 0; sidx < KSUB; ++sidx) {
@@ -313,21 +341,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             }
         }
         if (t + 1 < nt) {
-            sa.store(ldsA(cur ^ 1), tid);
-            sb.store(ldsB(cur ^ 1), tid);
+            sa[(r + 1) % RING].store(ldsA(cur ^ 1), tid);
+            sb[(r + 1) % RING].store(ldsB(cur ^ 1), tid);
         }
         __syncthreads();
+    };
+    for (int t = 0; t < nt; t += RING) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
+        if (RING > 2 && t + 2 < nt) step(std::integral_constant<int, 2 % RING>{}, t + 2);
     }
 
+    // Write-out: the accumulator tile goes through LDS so that the epilogue runs on contiguous 8-column
+    // chunks with consecutive lanes along the row (16-B bf16 / 32-B fp32 per lane, full 64-B+ segments per
+    // row) instead of 8-B pieces scattered over 16 rows per instruction -- the MFMA-layout stores were the
+    // bottleneck of every output-heavy GEMM here.  64 rows per pass (the fp32 tile is 25 KiB).
+    constexpr int NPASS = BM / 64;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + li;
-        if (m >= p.M) continue;
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (NPASS == 1 || wm == ps) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * 48 + j * 16 + g * 4;
-            if (n < p.N) epilogue(p, m, n, acc[i][j]);
+            for (int i = 0; i < FM; ++i) {
+                const int rl = (NPASS == 1 ? wm * (BM / 2) : 0) + i * 16 + li;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *(f32x4*)(smem + rl * STG_PITCH + (wn * 48 + j * 16 + g * 4) * 4) = acc[i][j];
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (64 * (BN / 8)) / 256; ++it) {
+            const int c = tid + it * 256;
+            const int rl = c / (BN / 8), c8 = c - rl * (BN / 8);
+            const int m = m0 + ps * 64 + rl, n = n0 + c8 * 8;
+            if (m < p.M && n < p.N) {
+                const float4 lo = *(const float4*)(smem + rl * STG_PITCH + c8 * 32);
+                const float4 hi = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
+                epilogue8(p, m, n, lo, hi, blockIdx.z);
+            }
+        }
+        if (ps + 1 < NPASS) __syncthreads();
     }
     if (A_T && do_rowsum && g == 0) {
         float* rs = (float*)p.out2;
@@ -346,16 +399,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 // and apply the fused epilogue (bias / GELU / residual / ...) once.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, const float* __restrict__ slabs,
                                                               int splits) {
-    const int n4 = p.N >> 2;
-    const int64_t total = (int64_t)p.M * n4;
+    const int n8 = p.N >> 3;
+    const int64_t total = (int64_t)p.M * n8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int m = (int)(i / n8), n = (int)(i - (int64_t)m * n8) * 8;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
         for (int sidx = 0; sidx < splits; ++sidx) {
-            const float4 v = *(const float4*)(slabs + ((size_t)sidx * p.M + m) * p.N + n);
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            const float* src = slabs + ((size_t)sidx * p.M + m) * p.N + n;
+            const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+            lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w;
+            hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
         }
-        epilogue(p, m, n, acc);
+        epilogue8(p, m, n, lo, hi, 0);
     }
 }
 
@@ -396,7 +451,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
                                int psH, int psW, int splits, void* workspace, int64_t workspace_bytes,
                                hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return TULIP_OK;
-    if ((K & 7) || (N & 3) || (lda & 7) || (ldb & 7)) return TULIP_ERR_ARG;
+    if ((K & 7) || (N & 7) || (lda & 7) || (ldb & 7)) return TULIP_ERR_ARG;
     if (a_trans && (M & 7)) return TULIP_ERR_ARG;
     if (b_trans && (N & 7)) return TULIP_ERR_ARG;
     if (splits < 1) splits = 1;
@@ -427,7 +482,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     else if (a_trans && b_trans) rc = launch<true, true>(q, splits, stream);
     else rc = launch<true, false>(q, splits, stream);
     if (rc != TULIP_OK || !fold) return rc;
-    const int64_t work = (int64_t)M * (N >> 2);
+    const int64_t work = (int64_t)M * (N >> 3);
     const int grid = (int)std::min<int64_t>((work + 255) / 256, 2048);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, p, (const float*)workspace, splits);
     TULIP_CHECK_LAUNCH();
