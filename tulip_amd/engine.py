@@ -200,13 +200,23 @@ class Plan:
             self.b16(p + ".qkv", M, 3 * C); self.b16(p + ".o", M, C); self.f32(p + ".x1", M, C)
             self.b16(p + ".xn2", M, C); self.f32(p + ".mean2", M); self.f32(p + ".rstd2", M)
             self.b16(p + ".h", M, Hd); self.b16(p + ".g", M, Hd); self.f32(p + ".out", M, C)
+        # gradient temporaries that feed a weight-gradient GEMM on the side stream are per block / per use
+        # (never recycled inside a step), so the side stream needs no WAR synchronisation with the main chain
+        for spec in eng.blocks:
+            M, C = B * spec.H * spec.W, spec.C
+            p = spec.prefix
+            self.b16(p + ".dyb_m", M, C); self.b16(p + ".dyb_a", M, C)
+            self.b16(p + ".dh", M, eng.hidden(C)); self.b16(p + ".dqkv", M, 3 * C)
+        for s in range(nl):
+            Ms, Cs = B * (H0 >> s) * (W0 >> s), E << s
+            self.b16(f"lvl{s}.dz2", Ms, 2 * Cs)      # unshuffled grad entering the level-s PatchUnmerging
+            if s > 0:
+                self.b16(f"enc{s}.dyb", Ms, Cs)      # bf16 grad w.r.t. the PatchMerging output of level s-1
         Cmax_tok = max(B * sp.H * sp.W * sp.C for sp in eng.blocks)
         Hdmax_tok = max(B * sp.H * sp.W * eng.hidden(sp.C) for sp in eng.blocks)
-        self.b16("t.dyb", Cmax_tok); self.b16("t.dxn", Cmax_tok); self.b16("t.do", Cmax_tok)
-        self.b16("t.dh", Hdmax_tok); self.b16("t.dqkv", 3 * Cmax_tok)
+        self.b16("t.dxn", Cmax_tok); self.b16("t.do", Cmax_tok)   # consumed on the main stream only
         big = max(4 * (B * (H0 >> s) * (W0 >> s) // 4) * (E << s) for s in range(nl))
         self.b16("t.dxm", big)                     # dgrad of a merge reduction [M/4][4C]
-        self.b16("t.dz2", 2 * Cmax_tok)            # unshuffled grad of an unmerge [M][2C]
         self.b16("tail.xn", maxM, E); self.f32("tail.mean", maxM); self.f32("tail.rstd", maxM)
         self.b16("tail.dz", maxM, 16 * E)
         self.b16("tail.dxn", maxM, E)
@@ -285,6 +295,8 @@ class TulipEngine:
                                     for b in range(m.depths[s])])
         self.n_drop_slots = slot
         self._keep = None
+        self._pending = []        # weight-gradient launches queued for the side stream
+        self._side_dirty = False
         self._graphs = {}
         self._rel32 = None
 
@@ -319,6 +331,10 @@ class TulipEngine:
         if getattr(self, "_ws", None) is None or self._ws.device != self.device:
             self._ws = torch.empty(self.WS_ELEMS + (1 << 20), dtype=torch.float32, device=self.device)
             self._ws_ptr = self._ws.data_ptr()
+            # weight-gradient branch: own stream + own slab workspace
+            self._ws_side = torch.empty(self.WS_ELEMS + (1 << 20), dtype=torch.float32, device=self.device)
+            self._ws_side_ptr = self._ws_side.data_ptr()
+            self._side = torch.cuda.Stream(device=self.device)
         return self.plans[B]
 
     # ------------------------------------------------------------------ forward
@@ -450,17 +466,47 @@ class TulipEngine:
                 return
         ops.gemm(A, B, M, N, K, **kw)
 
+    overlap_wgrad = True   # run the weight-gradient branch on a second HIP stream (forked inside the graph)
+
     def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
         """dW[Nw,Kw] += dY[Mtok,Nw]^T . X[Mtok,Kw]  and, for free, db[Nw] += sum_tokens dY (row sums of the
         transposed operand via one extra all-ones MFMA per fragment).  The token dimension is split over
         workgroups to fill the chip; partials go to fp32 slabs that one reduce kernel folds into both
-        gradients (deterministic, no atomics)."""
+        gradients (deterministic, no atomics).
+
+        Nothing downstream in the backward depends on a weight gradient, so the whole branch (GEMM + fold)
+        is issued on a side stream that forks from the main chain here and is joined at the DDP bucket
+        points / end of backward: the latency-bound dgrad -> LayerNorm -> attention chain and the wgrad
+        GEMMs overlap on the chip (captured as parallel branches of the HIP graph)."""
+        if not self.overlap_wgrad:
+            return self._wgrad_launch(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, self._ws_ptr)
+        # queued: forks cost a few microseconds each inside a HIP graph, so a Swin block's four weight
+        # gradients share ONE fork (their inputs are per-block buffers, so deferring them is hazard-free)
+        self._pending.append((dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias))
+
+    def _flush_wgrads(self):
+        if not self._pending:
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            for a in self._pending:
+                self._wgrad_launch(*a, self._ws_side_ptr)
+        self._pending = []
+        self._side_dirty = True
+
+    def _join_side(self):
+        self._flush_wgrads()
+        if getattr(self, "_side_dirty", False):
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_dirty = False
+
+    def _wgrad_launch(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, ws):
         splits = self._splits(Nw, Kw, Mtok)
         if splits == 1:
             ops.gemm(dY, X, Nw, Kw, Mtok, lda=ldy, ldb=ldx, a_trans=True, b_trans=True, epi=EPI_F32, out=gout, ldo=Kw,
                      accumulate=True, out2=gbias)
             return
-        ws = self._ws_ptr
         wsb = ws + 4 * splits * Nw * Kw if gbias is not None else None
         ops.gemm(dY, X, Nw, Kw, Mtok, lda=ldy, ldb=ldx, a_trans=True, b_trans=True, epi=EPI_SPLIT_F32, out=ws, ldo=Kw,
                  splits=splits, out2=wsb)
@@ -484,7 +530,8 @@ class TulipEngine:
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
-        dyb, dxn, dO, dh, dqkv = P["t.dyb"], P["t.dxn"], P["t.do"], P["t.dh"], P["t.dqkv"]
+        dxn, dO, dh, dqkv = P["t.dxn"], P["t.do"], P[p + ".dh"], P[p + ".dqkv"]
+        dyb = P[p + ".dyb_m"]
         # ---- MLP branch (tulip.py:346-351)
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
         self._gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
@@ -496,6 +543,7 @@ class TulipEngine:
         self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
                      G(p + ".norm2.weight"), G(p + ".norm2.bias"))
         # ---- attention branch (tulip.py:339-344)
+        dyb = P[p + ".dyb_a"]
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 0), tok)
         self._gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
                  ldo=C)
@@ -512,6 +560,7 @@ class TulipEngine:
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
         self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
                      G(p + ".norm1.weight"), G(p + ".norm1.bias"))
+        self._flush_wgrads()
 
     def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G):
         for k in reversed(range(len(specs))):
@@ -525,13 +574,14 @@ class TulipEngine:
         B = P.B
         H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
         M = B * H * W
-        dz = P["t.dz2"]
+        dz = P[f"lvl{s}.dz2"]
         ops.unshuffle2_cast(dfine, dz, B, H, W, C // 2)
         self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), G(prefix + ".expand.bias"))
         self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
                  out=dx_out, ldo=C)
 
-    def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None):
+    def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
+                     join_tags=None):
         """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
         (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
         each parameter group has been *launched* (DDP overlap)."""
@@ -540,7 +590,15 @@ class TulipEngine:
         H0, W0 = self.grid
         gbase = gflat.data_ptr()
         G = lambda name: gbase + 4 * W_.offset[name]
-        hook = bucket_hook or (lambda tag: None)
+        user_hook = bucket_hook or (lambda tag: None)
+
+        def hook(tag):
+            # a bucket is complete only once its side-stream weight gradients are in; without buckets the
+            # side stream is joined once, at the end
+            if tag == "embed" or (join_tags is not None and tag in join_tags):
+                self._join_side()
+            user_hook(tag)
+
         M0 = B * H0 * W0
         ops.l1_loss_bwd(P.pred, P.target, gscale_dev, gscale, P.dpred, P.pred.numel())
         tpart = P["tail.dwd_part"]
@@ -595,7 +653,7 @@ class TulipEngine:
                 Hp, Wp = H0 >> (s - 1), W0 >> (s - 1)
                 rows = B * (Hp // 2) * (Wp // 2)
                 pre = f"layers.{s - 1}.downsample"
-                dyb, dxm = P["t.dyb"], P["t.dxm"]
+                dyb, dxm = P[f"enc{s}.dyb"], P["t.dxm"]
                 ops.cast_f32_bf16(dx, dyb, rows, 2 * Cp)
                 self._wgrad(dyb, 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows,
                             G(pre + ".reduction.weight"))

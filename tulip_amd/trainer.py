@@ -71,7 +71,8 @@ class Trainer:
         self.g.zero_()
         eng.draw_drop_scales(P, self.model.training)
         eng.run_forward(P)
-        eng.run_backward(P, self.g, bucket_hook=hook)
+        eng.run_backward(P, self.g, bucket_hook=hook,
+                         join_tags=set(self.bucketer.by_tag) if self.world > 1 else None)
 
     def _adamw(self):
         W = self.eng.params
