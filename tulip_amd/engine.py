@@ -173,7 +173,6 @@ class Plan:
         self.drop_scale = self.f32("drop_scale", nslots, B)
         self.drop_scale.fill_(1.0)
         self.drop_u = self.f32("drop_u", nslots, B)
-        self.dense_bias = self.f32("dense_bias", max(m.num_heads), 16, 16)
         maxM = B * H0 * W0
         # per-level tensors
         for s in range(nl):
@@ -222,9 +221,6 @@ class Plan:
         self.b16("tail.dxn", maxM, E)
         # partial-row workspaces of the atomic-free reductions
         self.f32("tail.dwd_part", (maxM + 127) // 128, 128)
-        self.ln_part_ptr = self.f32("ln_part", 512, 4096).data_ptr()           # <=512 rows x 2C (C <= 2048)
-        rmax = max(ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, sp.nh, sp.win) * sp.nh for sp in eng.blocks)
-        self.attn_part_ptr = self.f32("attn_part", rmax, 256).data_ptr()
         W_ = eng.params
         o0 = W_.offset["patch_embed.proj.weight"]
         last = "patch_embed.norm.bias" if "patch_embed.norm.bias" in W_.offset else "patch_embed.proj.bias"
@@ -240,6 +236,16 @@ class Plan:
 
     def __getitem__(self, k):
         return self.bufs[k]
+
+    def scratch(self, name: str, numel: int) -> int:
+        """Address of a lazily allocated fp32 scratch buffer that is private to one call site (so work queued
+        on the side stream never races with the next user).  First use happens in the eager warm-up pass,
+        never inside graph capture."""
+        t = self.bufs.get(name)
+        if t is None or t.numel() < numel:
+            t = torch.zeros(numel, dtype=torch.float32, device=self.x_in.device)
+            self.bufs[name] = t
+        return t.data_ptr()
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
@@ -334,7 +340,7 @@ class TulipEngine:
             # weight-gradient branch: own stream + own slab workspace
             self._ws_side = torch.empty(self.WS_ELEMS + (1 << 20), dtype=torch.float32, device=self.device)
             self._ws_side_ptr = self._ws_side.data_ptr()
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side_stream = torch.cuda.Stream(device=self.device)
         return self.plans[B]
 
     # ------------------------------------------------------------------ forward
@@ -466,6 +472,7 @@ class TulipEngine:
                 return
         ops.gemm(A, B, M, N, K, **kw)
 
+    flush_per_block = True
     overlap_wgrad = True   # run the weight-gradient branch on a second HIP stream (forked inside the graph)
 
     def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
@@ -482,23 +489,30 @@ class TulipEngine:
             return self._wgrad_launch(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, self._ws_ptr)
         # queued: forks cost a few microseconds each inside a HIP graph, so a Swin block's four weight
         # gradients share ONE fork (their inputs are per-block buffers, so deferring them is hazard-free)
-        self._pending.append((dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias))
+        self._pending.append(lambda: self._wgrad_launch(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, self._ws_side_ptr))
+
+    def _side(self, fn):
+        """Queue work nothing in the backward chain waits for (gradient folds) for the side stream."""
+        if self.overlap_wgrad:
+            self._pending.append(fn)
+        else:
+            fn()
 
     def _flush_wgrads(self):
         if not self._pending:
             return
         main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            for a in self._pending:
-                self._wgrad_launch(*a, self._ws_side_ptr)
+        self._side_stream.wait_stream(main)
+        with torch.cuda.stream(self._side_stream):
+            for fn in self._pending:
+                fn()
         self._pending = []
         self._side_dirty = True
 
     def _join_side(self):
         self._flush_wgrads()
         if getattr(self, "_side_dirty", False):
-            torch.cuda.current_stream().wait_stream(self._side)
+            torch.cuda.current_stream().wait_stream(self._side_stream)
             self._side_dirty = False
 
     def _wgrad_launch(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, ws):
@@ -512,17 +526,18 @@ class TulipEngine:
                  splits=splits, out2=wsb)
         ops.reduce_rows2(ws, Nw * Kw, gout, Nw * Kw, wsb, Nw, gbias, Nw if gbias is not None else 0, splits)
 
-    def _ln_bwd(self, P: Plan, dy, x, mean, rstd, gamma, dres, dx, rows, C, gw, gb, merge=False, H=0, W=0):
-        """LayerNorm backward: dx (+= dres) and the affine gradients via per-workgroup partial rows."""
+    def _ln_bwd(self, P: Plan, dy, x, mean, rstd, gamma, dres, dx, rows, C, gw, gb, tag, merge=False, H=0, W=0):
+        """LayerNorm backward: dx (+= dres) on the main chain; the affine gradients leave as per-workgroup
+        partial rows (private buffer `tag`) that are folded on the side stream."""
         nrows = ops.layernorm_bwd_partial_rows(rows, C)
         if nrows == 0:  # C > 2048 (tulip_large's deepest PatchMerging norm): stand-alone parameter pass
             ops.layernorm_bwd_params(dy, x, mean, rstd, gw, gb, rows, C, merge=merge, B=P.B, H=H, W=W)
             ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W)
             return
-        part = P.ln_part_ptr
+        part = P.scratch("lnp." + tag, nrows * 2 * C)
         ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
                           param_partials=part)
-        ops.reduce_rows2(part, 2 * C, gw, C, part + 4 * C, 2 * C, gb, C, nrows)
+        self._side(lambda: ops.reduce_rows2(part, 2 * C, gw, C, part + 4 * C, 2 * C, gb, C, nrows))
 
     def _block_bwd(self, P: Plan, sp: BlockSpec, xin, dx, G):
         """In-place: dx (grad w.r.t. block output) -> grad w.r.t. block input.  G(name) = grad address."""
@@ -541,26 +556,33 @@ class TulipEngine:
                  ldo=C)
         self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
         self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
-                     G(p + ".norm2.weight"), G(p + ".norm2.bias"))
+                     G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2")
         # ---- attention branch (tulip.py:339-344)
         dyb = P[p + ".dyb_a"]
         ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 0), tok)
         self._gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
                  ldo=C)
         self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
-        dense, apart = P.dense_bias, P.attn_part_ptr
-        dense.zero_()
+        R = ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, nh, sp.win)
+        apart = P.scratch("apart." + p, R * nh * 256)
+        dense = P.scratch("adense." + p, nh * 256)
         ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
                             apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
-        ops.reduce_rows2(apart, nh * 256, dense, nh * 256, None, 0, None, 0,
-                         ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, nh, sp.win))
-        ops.bias_table_scatter(dense, self._rel32, G(p + ".attn.relative_position_bias_table"), nh, 16)
+        gtab, rel32 = G(p + ".attn.relative_position_bias_table"), self._rel32
+
+        def fold_bias():
+            P.bufs["adense." + p].zero_()
+            ops.reduce_rows2(apart, nh * 256, dense, nh * 256, None, 0, None, 0, R)
+            ops.bias_table_scatter(dense, rel32, gtab, nh, 16)
+
+        self._side(fold_bias)
         self._gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
                  out=dxn, ldo=C)
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
         self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
-                     G(p + ".norm1.weight"), G(p + ".norm1.bias"))
-        self._flush_wgrads()
+                     G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1")
+        if self.flush_per_block:
+            self._flush_wgrads()
 
     def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G):
         for k in reversed(range(len(specs))):
@@ -595,6 +617,7 @@ class TulipEngine:
         def hook(tag):
             # a bucket is complete only once its side-stream weight gradients are in; without buckets the
             # side stream is joined once, at the end
+            self._flush_wgrads()
             if tag == "embed" or (join_tags is not None and tag in join_tags):
                 self._join_side()
             user_hook(tag)
@@ -604,7 +627,8 @@ class TulipEngine:
         tpart = P["tail.dwd_part"]
         ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
                      W_.p32("decoder_pred.weight"), P.dpred, P["tail.dz"], tpart, B, H0, W0, E)
-        ops.reduce_rows2(tpart, 128, G("decoder_pred.weight"), E, None, 0, None, 0, (M0 + 127) // 128)
+        gdw = G("decoder_pred.weight")
+        self._side(lambda: ops.reduce_rows2(tpart, 128, gdw, E, None, 0, None, 0, (M0 + 127) // 128))
         self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),
                     G("ps_head.conv_expand.0.bias"))
         self._gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
@@ -612,7 +636,7 @@ class TulipEngine:
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
         self._ln_bwd(P, P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx, M0,
-                     E, G("norm_up.weight"), G("norm_up.bias"))
+                     E, G("norm_up.weight"), G("norm_up.bias"), "norm_up")
         hook("head")
         # ---- decoder, fine -> coarse
         for i in reversed(range(nl - 1)):
@@ -662,7 +686,7 @@ class TulipEngine:
                 xprev = P[self.enc_blocks[s - 1][-1].prefix + ".out"]
                 self._ln_bwd(P, dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"], W_.p32(pre + ".norm.weight"),
                              None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, G(pre + ".norm.weight"), G(pre + ".norm.bias"),
-                             merge=True, H=Hp, W=Wp)
+                             pre, merge=True, H=Hp, W=Wp)
             hook(f"enc{s}")
         kw = 8 if m.circular_padding else m.patch_size[1]
         # patch-embed parameter gradients: partial rows laid out like the flat gradient slice
@@ -675,8 +699,8 @@ class TulipEngine:
                             ep + rel("patch_embed.norm.weight"), ep + rel("patch_embed.norm.bias"), B, m.in_chans,
                             m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
                             self.eps, partial_stride=P.embed_stride)
-        ops.reduce_rows2(ep, P.embed_stride, G("patch_embed.proj.weight"), P.embed_stride, None, 0, None, 0,
-                         ops.patch_embed_bwd_blocks(B * H0 * W0))
+        gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
+        self._side(lambda: ops.reduce_rows2(ep, P.embed_stride, gpe, P.embed_stride, None, 0, None, 0, nbe))
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge
