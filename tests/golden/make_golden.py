@@ -272,6 +272,7 @@ def main():
     golden_index(T)
     golden_lr(T)
     golden_init(T)
+    golden_train_trajectory(T)
     tiny = O.tiny_config()
     golden_model(T, "g3_tiny_fp32", tiny, batch=2, seed=0, with_grads=True)
     golden_model(T, "g3_tiny_droppath", tiny, batch=4, seed=1, with_grads=True, drop_path=True)
@@ -305,8 +306,38 @@ def golden_init(T):
     print("init fingerprints written")
 
 
+def golden_train_trajectory(T):
+    """f-1: the reference model + torch.optim.AdamW (main_lidar_upsampling.py:282-283 grouping and
+    hyper-parameters) for 4 steps on one tiny batch, fp32, DropPath off: loss before each step."""
+    cfg = O.tiny_config()
+    sd = O.key_seeded_state_dict(cfg, seed=3)
+    lo, hi = O.synthetic_batch(cfg, 4, seed=77)
+    m = ref_model(T, cfg, drop_path_rate=0.0)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    decay = [p for p in m.parameters() if p.ndim > 1]
+    nodecay = [p for p in m.parameters() if p.ndim <= 1]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}],
+                            lr=5e-4, betas=(0.9, 0.95))
+    losses, pix = [], []
+    for step in range(4):
+        opt.zero_grad()
+        _, loss, px = m(lo, hi)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item()); pix.append(px.item())
+    with torch.no_grad():
+        _, loss, px = m(lo, hi)
+    losses.append(loss.item()); pix.append(px.item())
+    np.savez_compressed(os.path.join(HERE, "g7_train_trajectory.npz"), loss=np.array(losses), pixel_loss=np.array(pix),
+                        seed=np.int64(3), batch=np.int64(4), data_seed=np.int64(77))
+    print("train trajectory:", [round(l, 6) for l in losses])
+
+
 if __name__ == "__main__":
-    if "--init-only" in sys.argv:
+    if "--traj-only" in sys.argv:
+        golden_train_trajectory(import_reference())
+    elif "--init-only" in sys.argv:
         golden_init(import_reference())
     else:
         main()
