@@ -65,6 +65,16 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
     return f"gemm_kernel<{bm}, {t(a_trans)}, {t(b_trans)}, {ksub}>"
 
 
+def _pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected +
+    WRITE_SIZE, collected as MI355X_MICROARCH.md prescribes); counters cannot be read from inside bench.py."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_gemm_traffic.json")) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def gemm_roofline(trainer, reps=5):
     """Roofline of the dominant kernel family (the bf16 MFMA GEMM: 98.7 % of the step's FLOPs).
     The ~200 GEMM launches of one step are recorded in an eager pass, then each is re-issued `reps`
@@ -85,7 +95,7 @@ def gemm_roofline(trainer, reps=5):
         torch.cuda.synchronize()
     finally:
         ops.gemm = real
-    by_inst, tot_t, tot_f = {}, 0.0, 0.0
+    by_inst, tot_t, tot_f, alg_bytes = {}, 0.0, 0.0, 0.0
     for A, B, M, N, K, kw in calls:
         real(A, B, M, N, K, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -96,6 +106,7 @@ def gemm_roofline(trainer, reps=5):
         e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
         f = 2.0 * M * N * K
+        alg_bytes += 2.0 * (M * K + N * K) + M * N * (4.0 if kw.get("epi", 0) in (3, 4, 5, 6, 7) else 2.0)
         name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
         d = by_inst.setdefault(name, [0, 0.0, 0.0])
         d[0] += 1; d[1] += t; d[2] += f
@@ -104,7 +115,9 @@ def gemm_roofline(trainer, reps=5):
               for k, (n, t, f) in sorted(by_inst.items(), key=lambda kv: -kv[1][1])}
     return {"bound": "mfma", "kernel": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv: fwd + dgrad + wgrad)",
             "achieved": round(tot_f / tot_t / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-            "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": None, "launches_per_step": len(calls),
+            "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": _pmc_traffic(), "launches_per_step": len(calls),
+            "flops_per_launch": tot_f / len(calls), "operand_bytes_per_launch": round(alg_bytes / len(calls)),
+            "mean_launch_us": round(tot_t / len(calls) * 1e6, 2),
             "gemm_ms_per_step": round(tot_t * 1e3, 3), "flops_per_step": tot_f, "by_kernel": detail}
 
 
