@@ -55,7 +55,7 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
     eff = ops.gemm_effective_splits(K, splits)
     kchunk = -(-(-(-K // eff)) // 32) * 32
     gn = -(-N // 96)
-    if (-(-M // 128) * gn * eff < 256 and M > 64) or M <= 64:
+    if -(-M // 128) * gn * eff < int(os.environ.get("TULIP_GEMM_BIG_TILES", 2048)) or M <= 64:
         grid = gn * -(-M // 64) * eff
         ksub = 4 if (grid <= 192 and kchunk >= 256) else 1
         bm = 64
