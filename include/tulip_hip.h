@@ -78,10 +78,14 @@ int tulip_layernorm_fwd(const float* x, const float* gamma, const float* beta, u
 /* dx = dres + LayerNorm-backward(dy) in the layout of x (scatter for merge=1).  dres may be NULL
  * (treated as zero) or alias dx.  param_partials (may be NULL): receives
  * tulip_layernorm_bwd_partial_rows(rows, C) partial rows of [dgamma[C] | dbeta[C]] (stride 2C), to be
- * folded with tulip_reduce_rows2 -- the parameter gradients cost no second pass over dy and x. */
+ * folded with tulip_reduce_rows2 -- the parameter gradients cost no second pass over dy and x.
+ * dx_bf16 (may be NULL): additionally receives bf16(dx * cast_rowscale[token / cast_rows_per_sample]) in the
+ * layout of dx -- the operand of the next dgrad/wgrad GEMM on the backward chain (DropPath scale of the branch
+ * it enters, tulip.py:25-29), so no separate cast pass is needed. */
 int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, int rows, int C, int merge, int B, int H, int W,
-                        float* param_partials, hipStream_t stream);
+                        float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
+                        int cast_rows_per_sample, hipStream_t stream);
 /* partial rows tulip_layernorm_bwd writes for (rows, C); 0 if C is too wide for the fused form (C > 2048) */
 int tulip_layernorm_bwd_partial_rows(int rows, int C);
 
@@ -144,7 +148,7 @@ int tulip_cast_flat(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
 int tulip_tail_fwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, float* pred, int B, int H,
                    int W, int E, hipStream_t stream);
 /* backward of the head w.r.t. the expand pre-activation: dz[B*H*W][16E] (bf16), and decoder_pred's weight
- * gradient as ceil(B*H*W/128) partial rows dwd_partials[row][128] (first E valid; fold with
+ * gradient as ceil(B*H*W/32) partial rows dwd_partials[row][128] (first E valid; fold with
  * tulip_reduce_rows2). */
 int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
                    uint16_t* dz, float* dwd_partials, int B, int H, int W, int E, hipStream_t stream);

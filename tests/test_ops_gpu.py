@@ -449,7 +449,7 @@ def test_tail_fwd_bwd(ops, B, H, W, E):
     dpred = rnd(B, 1, 4 * H, 4 * W, seed=4)
     ref.backward(dpred)
     dz = torch.empty(M, 16 * E, dtype=torch.bfloat16, device=DEV)
-    dpart = torch.full(((M + 127) // 128, 128), float("nan"), device=DEV)
+    dpart = torch.full(((M + 31) // 32, 128), float("nan"), device=DEV)
     ops.tail_bwd(xn, We, be, wd, dpred, dz, dpart, B, H, W, E)
     dwd = torch.zeros(E, device=DEV)
     ops.reduce_rows2(dpart, 128, dwd, E, None, 0, None, 0, dpart.shape[0])

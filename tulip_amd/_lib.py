@@ -18,7 +18,7 @@ P, I, F, L = c_void_p, c_int, c_float, c_int64
 SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P, L, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
-    "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P],
+    "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],
     "tulip_layernorm_bwd_params": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],

@@ -81,7 +81,11 @@ template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx,
-                                                     int rows, RowGeom g, float* __restrict__ ppart) {
+                                                     int rows, RowGeom g, float* __restrict__ ppart,
+                                                     bf16_t* __restrict__ ycast, const float* __restrict__ cscale,
+                                                     int crps) {
+    // ycast (optional): the NEXT consumer of dx on the backward chain is always a GEMM that wants
+    // bf16(dx * DropPath scale of the branch it enters) -- emitted here, from registers, instead of a cast pass.
     // PARTS: also accumulate d(gamma)=sum dy*xhat and d(beta)=sum dy over this block's rows and emit one
     // partial row [2C] per block (folded later by tulip_reduce_rows2) -- no second pass over dy / x.
     constexpr bool PARTS = NCH <= 8;
@@ -130,6 +134,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
                 *(float4*)(dx + off) = o;
+                if (ycast) {
+                    const int cdx = g.merge ? (g.C >> 2) : g.C;          // channels of the dx tensor
+                    const float sc = cscale ? cscale[(int)(off / cdx) / crps] : 1.0f;
+                    *(uint2*)(ycast + off) = make_uint2(pack_bf16x2(o.x * sc, o.y * sc), pack_bf16x2(o.z * sc, o.w * sc));
+                }
             }
         }
     }
@@ -438,7 +447,8 @@ extern "C" int tulip_layernorm_bwd_partial_rows(int rows, int C) { return rows >
 
 extern "C" int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd,
                                    const float* gamma, const float* dres, float* dx, int rows, int C, int merge, int B,
-                                   int H, int W, float* param_partials, hipStream_t stream) {
+                                   int H, int W, float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
+                                   int cast_rows_per_sample, hipStream_t stream) {
     if (rows <= 0) return TULIP_OK;
     if (!geom_ok(rows, C, merge, B, H, W)) return TULIP_ERR_ARG;
     if (param_partials && ln_bwd_part_rows(rows, C) == 0) return TULIP_ERR_ARG;
@@ -449,7 +459,8 @@ extern "C" int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const flo
         const int grid = param_partials ? ln_bwd_part_rows(rows, C) : std::min((rows + rpb - 1) / rpb, 256 * 16);
         const size_t lds = param_partials ? (size_t)rpb * 2 * C * sizeof(float) : 0;
         hipLaunchKernelGGL((ln_bwd_kernel<LPR, NCH>), dim3(grid), dim3(256), lds, stream, dy, x, mean, rstd, gamma,
-                           dres, dx, rows, g, param_partials);
+                           dres, dx, rows, g, param_partials, dx_bf16, cast_rowscale,
+                           cast_rows_per_sample > 0 ? cast_rows_per_sample : 1);
         TULIP_CHECK_LAUNCH();
         return TULIP_OK;
     });

@@ -55,17 +55,21 @@ __device__ __forceinline__ size_t pred_off(const TailGeom& g, int tok, int i) {
     return ((size_t)b * 4 * g.H + 4 * h + i) * (4 * g.W) + 4 * w;
 }
 
+// Work split: a workgroup owns 32 tokens; its 4 waves share them and each walks a quarter of the E channels
+// (the first version gave each wave 32 tokens and all E channels: 1 wave per SIMD and a 96-deep chain of
+// dependent L2 loads -- latency-bound at 85 / 111 us).  Forward: the four partial pixel sums meet in LDS.
 template <int KS>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
                                                        const float* __restrict__ be, const float* __restrict__ wd,
                                                        float* __restrict__ pred, TailGeom g) {
-    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4;
-    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (m0 >= g.M) return;
+    __shared__ __attribute__((aligned(16))) float red[4][32][16];
+    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4, wid = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 32;
     bf16x8 xb[2][KS];
     load_x<KS>(xn, g, m0, li, gq, xb);
     float pacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int c = 0; c < g.E; ++c) {
+    const int cper = (g.E + 3) / 4, c0 = wid * cper, c1 = min(g.E, c0 + cper);
+    for (int c = c0; c < c1; ++c) {
         f32x4 acc[2];
         expand_channel<KS>(We, g, c, li, gq, xb, acc);
         const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
@@ -80,10 +84,21 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const bf16_t* __restrict_
             }
     }
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        const int tok = m0 + mf * 16 + li;
-        if (tok < g.M)
-            *(float4*)(pred + pred_off(g, tok, gq)) = make_float4(pacc[mf][0], pacc[mf][1], pacc[mf][2], pacc[mf][3]);
+    for (int mf = 0; mf < 2; ++mf)
+        *(float4*)&red[wid][mf * 16 + li][gq * 4] = make_float4(pacc[mf][0], pacc[mf][1], pacc[mf][2], pacc[mf][3]);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 2, i = threadIdx.x & 3;   // token, sub-row i (4 pixels j = 0..3)
+        const int tok = m0 + t;
+        if (tok < g.M) {
+            float4 o = *(const float4*)&red[0][t][i * 4];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = *(const float4*)&red[w][t][i * 4];
+                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            }
+            *(float4*)(pred + pred_off(g, tok, i)) = o;
+        }
     }
 }
 
@@ -93,47 +108,46 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ dpred, bf16_t* __restrict__ dz,
                                                        float* dwd, TailGeom g) {
     __shared__ float lds_dwd[128];
-    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4;
+    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4, wid = threadIdx.x >> 6;
     if (threadIdx.x < 128) lds_dwd[threadIdx.x] = 0.f;
     __syncthreads();
-    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (m0 < g.M) {
-        bf16x8 xb[2][KS];
-        load_x<KS>(xn, g, m0, li, gq, xb);
-        float dp[2][4];
+    const int m0 = blockIdx.x * 32;
+    bf16x8 xb[2][KS];
+    load_x<KS>(xn, g, m0, li, gq, xb);
+    float dp[2][4];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        const int tok = m0 + mf * 16 + li;
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tok < g.M) d = *(const float4*)(dpred + pred_off(g, tok, gq));
+        dp[mf][0] = d.x; dp[mf][1] = d.y; dp[mf][2] = d.z; dp[mf][3] = d.w;
+    }
+    const int N = 16 * g.E;
+    const int cper = (g.E + 3) / 4, c0 = wid * cper, c1 = min(g.E, c0 + cper);
+    for (int c = c0; c < c1; ++c) {
+        f32x4 acc[2];
+        expand_channel<KS>(We, g, c, li, gq, xb, acc);
+        const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
+        const float wc = wd[c];
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        float part = 0.f;
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
-            const int tok = m0 + mf * 16 + li;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tok < g.M) d = *(const float4*)(dpred + pred_off(g, tok, gq));
-            dp[mf][0] = d.x; dp[mf][1] = d.y; dp[mf][2] = d.z; dp[mf][3] = d.w;
-        }
-        const int N = 16 * g.E;
-        for (int c = 0; c < g.E; ++c) {
-            f32x4 acc[2];
-            expand_channel<KS>(We, g, c, li, gq, xb, acc);
-            const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
-            const float wc = wd[c];
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-            float part = 0.f;
+            float o[4];
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = acc[mf][r] + bb[r];
-                    const bool pos = z > 0.f;
-                    part += dp[mf][r] * (pos ? z : 0.01f * z);
-                    o[r] = dp[mf][r] * wc * (pos ? 1.0f : 0.01f);
-                }
-                const int tok = m0 + mf * 16 + li;
-                if (tok < g.M)
-                    *(uint2*)(dz + (size_t)tok * N + c * 16 + gq * 4) =
-                        make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[mf][r] + bb[r];
+                const bool pos = z > 0.f;
+                part += dp[mf][r] * (pos ? z : 0.01f * z);
+                o[r] = dp[mf][r] * wc * (pos ? 1.0f : 0.01f);
             }
-            part = group_sum<64>(part);
-            if (lane == 0) atomicAdd(&lds_dwd[c], part);
+            const int tok = m0 + mf * 16 + li;
+            if (tok < g.M)
+                *(uint2*)(dz + (size_t)tok * N + c * 16 + gq * 4) =
+                    make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
         }
+        part = group_sum<64>(part);
+        if (lane == 0) lds_dwd[c] = part;          // channel c belongs to this wave alone
     }
     __syncthreads();
     // one plain partial row per workgroup: dwd[blockIdx.x][128] (folded by tulip_reduce_rows2)
@@ -147,7 +161,7 @@ extern "C" int tulip_tail_fwd(const uint16_t* xn, const uint16_t* We, const floa
     if (E <= 0 || (E & 7) || E > 128) return TULIP_ERR_ARG;
     TailGeom g{B * H * W, H, W, E};
     if (g.M <= 0) return TULIP_OK;
-    const dim3 grid((g.M + 127) / 128), block(256);
+    const dim3 grid((g.M + 31) / 32), block(256);
     const int ks = (E + 31) / 32;
     if (ks <= 2) hipLaunchKernelGGL(tail_fwd_kernel<2>, grid, block, 0, stream, xn, We, be, wd, pred, g);
     else if (ks == 3) hipLaunchKernelGGL(tail_fwd_kernel<3>, grid, block, 0, stream, xn, We, be, wd, pred, g);
@@ -162,7 +176,7 @@ extern "C" int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const floa
     if (E <= 0 || (E & 7) || E > 128) return TULIP_ERR_ARG;
     TailGeom g{B * H * W, H, W, E};
     if (g.M <= 0) return TULIP_OK;
-    const dim3 grid((g.M + 127) / 128), block(256);
+    const dim3 grid((g.M + 31) / 32), block(256);
     const int ks = (E + 31) / 32;
     if (ks <= 2) hipLaunchKernelGGL(tail_bwd_kernel<2>, grid, block, 0, stream, xn, We, be, wd, dpred, dz, dwd, g);
     else if (ks == 3) hipLaunchKernelGGL(tail_bwd_kernel<3>, grid, block, 0, stream, xn, We, be, wd, dpred, dz, dwd, g);

@@ -220,7 +220,7 @@ class Plan:
         self.b16("tail.dz", maxM, 16 * E)
         self.b16("tail.dxn", maxM, E)
         # partial-row workspaces of the atomic-free reductions
-        self.f32("tail.dwd_part", (maxM + 127) // 128, 128)
+        self.f32("tail.dwd_part", (maxM + 31) // 32, 128)
         W_ = eng.params
         o0 = W_.offset["patch_embed.proj.weight"]
         last = "patch_embed.norm.bias" if "patch_embed.norm.bias" in W_.offset else "patch_embed.proj.bias"
@@ -526,21 +526,32 @@ class TulipEngine:
                  splits=splits, out2=wsb)
         ops.reduce_rows2(ws, Nw * Kw, gout, Nw * Kw, wsb, Nw, gbias, Nw if gbias is not None else 0, splits)
 
-    def _ln_bwd(self, P: Plan, dy, x, mean, rstd, gamma, dres, dx, rows, C, gw, gb, tag, merge=False, H=0, W=0):
+    def _ln_bwd(self, P: Plan, dy, x, mean, rstd, gamma, dres, dx, rows, C, gw, gb, tag, merge=False, H=0, W=0,
+                cast=None):
         """LayerNorm backward: dx (+= dres) on the main chain; the affine gradients leave as per-workgroup
-        partial rows (private buffer `tag`) that are folded on the side stream."""
+        partial rows (private buffer `tag`) that are folded on the side stream.  cast = (bf16 buffer,
+        rowscale address or None, tokens per sample): the operand of the next GEMM on the chain,
+        bf16(dx * DropPath scale), emitted by the same kernel."""
+        cb, cs, ct = cast if cast is not None else (None, None, 1)
         nrows = ops.layernorm_bwd_partial_rows(rows, C)
         if nrows == 0:  # C > 2048 (tulip_large's deepest PatchMerging norm): stand-alone parameter pass
             ops.layernorm_bwd_params(dy, x, mean, rstd, gw, gb, rows, C, merge=merge, B=P.B, H=H, W=W)
-            ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W)
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
+                              dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
             return
         part = P.scratch("lnp." + tag, nrows * 2 * C)
         ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
-                          param_partials=part)
+                          param_partials=part, dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
         self._side(lambda: ops.reduce_rows2(part, 2 * C, gw, C, part + 4 * C, 2 * C, gb, C, nrows))
 
-    def _block_bwd(self, P: Plan, sp: BlockSpec, xin, dx, G):
-        """In-place: dx (grad w.r.t. block output) -> grad w.r.t. block input.  G(name) = grad address."""
+    def _mlp_cast(self, P: Plan, sp: BlockSpec):
+        """What the producer of this block's incoming gradient should emit: (dyb_m, DropPath scale, tokens)."""
+        return (P[sp.prefix + ".dyb_m"], self._ds(P, sp, 1), sp.H * sp.W)
+
+    def _block_bwd(self, P: Plan, sp: BlockSpec, xin, dx, G, have_dyb=False, next_cast=None):
+        """In-place: dx (grad w.r.t. block output) -> grad w.r.t. block input.  G(name) = grad address.
+        have_dyb: the producer of dx already wrote bf16(dx*scale) into this block's dyb_m;
+        next_cast: what the consumer of this block's input gradient wants (see _ln_bwd)."""
         W_ = self.params
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
@@ -548,7 +559,8 @@ class TulipEngine:
         dxn, dO, dh, dqkv = P["t.dxn"], P["t.do"], P[p + ".dh"], P[p + ".dqkv"]
         dyb = P[p + ".dyb_m"]
         # ---- MLP branch (tulip.py:346-351)
-        ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
+        if not have_dyb:
+            ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
         self._gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
                  ldo=Hd, aux=P[p + ".h"], ldaux=Hd)
         self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
@@ -556,10 +568,10 @@ class TulipEngine:
                  ldo=C)
         self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
         self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
-                     G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2")
-        # ---- attention branch (tulip.py:339-344)
+                     G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2",
+                     cast=(P[p + ".dyb_a"], self._ds(P, sp, 0), tok))
+        # ---- attention branch (tulip.py:339-344); its bf16 operand came out of the LayerNorm backward above
         dyb = P[p + ".dyb_a"]
-        ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 0), tok)
         self._gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
                  ldo=C)
         self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
@@ -580,14 +592,18 @@ class TulipEngine:
                  out=dxn, ldo=C)
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
         self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
-                     G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1")
+                     G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1", cast=next_cast)
         if self.flush_per_block:
             self._flush_wgrads()
 
-    def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G):
+    def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G, have_dyb=False, next_cast=None):
+        """have_dyb: the last block's dyb_m was already produced by whoever produced dx;
+        next_cast: consumer of the stage-input gradient (skip / merge cast), or None."""
         for k in reversed(range(len(specs))):
             xin = stage_in if k == 0 else P[specs[k - 1].prefix + ".out"]
-            self._block_bwd(P, specs[k], xin, dx, G)
+            nc = self._mlp_cast(P, specs[k - 1]) if k > 0 else next_cast
+            self._block_bwd(P, specs[k], xin, dx, G, have_dyb=have_dyb, next_cast=nc)
+            have_dyb = True
 
     def _unmerge_bwd(self, P: Plan, prefix: str, s: int, dfine, dx_out, G):
         """Backward of PatchUnmerging from the fine-level grad `dfine` (level s-1 layout) into
@@ -628,7 +644,7 @@ class TulipEngine:
         ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
                      W_.p32("decoder_pred.weight"), P.dpred, P["tail.dz"], tpart, B, H0, W0, E)
         gdw = G("decoder_pred.weight")
-        self._side(lambda: ops.reduce_rows2(tpart, 128, gdw, E, None, 0, None, 0, (M0 + 127) // 128))
+        self._side(lambda: ops.reduce_rows2(tpart, 128, gdw, E, None, 0, None, 0, (M0 + 31) // 32))
         self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),
                     G("ps_head.conv_expand.0.bias"))
         self._gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
@@ -636,7 +652,8 @@ class TulipEngine:
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
         self._ln_bwd(P, P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx, M0,
-                     E, G("norm_up.weight"), G("norm_up.bias"), "norm_up")
+                     E, G("norm_up.weight"), G("norm_up.bias"), "norm_up",
+                     cast=self._mlp_cast(P, (self.dec_blocks[-1] if nl > 1 else self.enc_blocks[0])[-1]))
         hook("head")
         # ---- decoder, fine -> coarse
         for i in reversed(range(nl - 1)):
@@ -647,10 +664,10 @@ class TulipEngine:
             if i < nl - 2:
                 # dx currently holds nothing for this level: pull the grad down from the finer level
                 self._unmerge_bwd(P, f"layers_up.{i}.upsample", s, P[f"dec{s - 1}.dxu"], dx, G)
-            self._stage_bwd(P, self.dec_blocks[i], P[f"dec{s}.in"], dx, G)
-            pre = f"skip_connection_layers.{i}"
             dys = P[f"dec{s}.dyskip"]
-            ops.cast_f32_bf16(dx, dys, Ms, Cs)
+            self._stage_bwd(P, self.dec_blocks[i], P[f"dec{s}.in"], dx, G, have_dyb=(i == nl - 2),
+                            next_cast=(dys, None, 1))          # the skip Linear's dgrad/wgrad operand
+            pre = f"skip_connection_layers.{i}"
             self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
             # grad w.r.t. the first concat half (the unmerged stream); the x_save half is deferred
             self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32,
@@ -663,7 +680,9 @@ class TulipEngine:
         # ---- encoder, coarse -> fine
         for s in reversed(range(nl)):
             dx = P[f"enc{s}.dx"]
-            self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G)
+            bottom_to_merge = (s == nl - 1 and s > 0)
+            self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G, have_dyb=(s < nl - 1),
+                            next_cast=(P[f"enc{s}.dyb"], None, 1) if bottom_to_merge else None)
             if s < nl - 1:
                 # deferred skip-connection gradient w.r.t. x_save[s] (second concat half, tulip.py:715)
                 Cs = E << s
@@ -678,7 +697,8 @@ class TulipEngine:
                 rows = B * (Hp // 2) * (Wp // 2)
                 pre = f"layers.{s - 1}.downsample"
                 dyb, dxm = P[f"enc{s}.dyb"], P["t.dxm"]
-                ops.cast_f32_bf16(dx, dyb, rows, 2 * Cp)
+                if not bottom_to_merge:      # dx was modified by the deferred skip gradient after the last LN backward
+                    ops.cast_f32_bf16(dx, dyb, rows, 2 * Cp)
                 self._wgrad(dyb, 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows,
                             G(pre + ".reduction.weight"))
                 self._gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,
@@ -686,7 +706,7 @@ class TulipEngine:
                 xprev = P[self.enc_blocks[s - 1][-1].prefix + ".out"]
                 self._ln_bwd(P, dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"], W_.p32(pre + ".norm.weight"),
                              None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, G(pre + ".norm.weight"), G(pre + ".norm.bias"),
-                             pre, merge=True, H=Hp, W=Wp)
+                             pre, merge=True, H=Hp, W=Wp, cast=self._mlp_cast(P, self.enc_blocks[s - 1][-1]))
             hook(f"enc{s}")
         kw = 8 if m.circular_padding else m.patch_size[1]
         # patch-embed parameter gradients: partial rows laid out like the flat gradient slice

@@ -50,9 +50,11 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, merge=False, B=0,
     check(rc, "tulip_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0, H=0, W=0, param_partials=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0, H=0, W=0, param_partials=None,
+                  dx_bf16=None, cast_rowscale=None, cast_rows_per_sample=1):
     rc = _lib.load().tulip_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), rows, C,
-                                         int(merge), B, H, W, _p(param_partials), _stream())
+                                         int(merge), B, H, W, _p(param_partials), _p(dx_bf16), _p(cast_rowscale),
+                                         cast_rows_per_sample, _stream())
     check(rc, "tulip_layernorm_bwd")
 
 
