@@ -149,9 +149,12 @@ int tulip_tail_fwd(const uint16_t* xn, const uint16_t* We, const float* be, cons
                    int W, int E, hipStream_t stream);
 /* backward of the head w.r.t. the expand pre-activation: dz[B*H*W][16E] (bf16), and decoder_pred's weight
  * gradient as ceil(B*H*W/32) partial rows dwd_partials[row][128] (first E valid; fold with
- * tulip_reduce_rows2). */
+ * tulip_reduce_rows2).  target == NULL: dpred is the upstream gradient of pred.  target != NULL: dpred is the
+ * forward's pred and the L1 gradient gscale*sign(pred-target)/numel (forward_loss backward, tulip.py:692-693;
+ * gscale read from gscale_dev if non-NULL) is formed inside the kernel. */
 int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
-                   uint16_t* dz, float* dwd_partials, int B, int H, int W, int E, hipStream_t stream);
+                   uint16_t* dz, float* dwd_partials, int B, int H, int W, int E, const float* target,
+                   const float* gscale_dev, float gscale, hipStream_t stream);
 
 /* forward_loss (tulip.py:690-700): losses[0]=mean|pred-target|, losses[1]=mean|expm1(pred)-expm1(target)|
  * (or a copy of losses[0] when log_transform==0).  partials: scratch of 2*1024 floats. Deterministic. */
@@ -164,9 +167,10 @@ int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscal
 /* Fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, main_lidar_upsampling.py:283):
  * hyper (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}.
  * decay_mask64[i/64] != 0 selects weight decay for elements of 64-float block i/64 (timm's grouping,
- * main:282: decay only for ndim>1 parameters); NULL = decay everywhere.  Also refreshes the bf16 shadow. */
-int tulip_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
-                const uint8_t* decay_mask64, hipStream_t stream);
+ * main:282: decay only for ndim>1 parameters); NULL = decay everywhere.  Also refreshes the bf16 shadow.
+ * zero_grad != 0: g is cleared after it has been consumed (optimizer.zero_grad(), engine_upsampling.py:97). */
+int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
+                const uint8_t* decay_mask64, int zero_grad, hipStream_t stream);
 
 /* library self-description */
 int tulip_abi_version(void);

@@ -38,10 +38,10 @@ SIGNATURES = {
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],
-    "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
+    "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
     "tulip_l1_loss_fwd": [P, P, P, P, L, I, P],
     "tulip_l1_loss_bwd": [P, P, P, F, P, L, P],
-    "tulip_adamw": [P, P, P, P, P, L, P, P, P],
+    "tulip_adamw": [P, P, P, P, P, L, P, P, I, P],
     "tulip_abi_version": [],
     "tulip_build_arch": [],
 }

@@ -232,10 +232,10 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
 
 // ---------------------------------------------------------------- AdamW
 // hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
-                                                    const uint8_t* __restrict__ mask64) {
+                                                    const uint8_t* __restrict__ mask64, int zero_grad) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
     const float bc1 = hyper[5], bc2 = hyper[6], gs = hyper[7];
     const float decay_on = 1.0f - lr * wd;
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             P[k] = P[k] * decay - step * (M[k] / denom);
         }
         *(float4*)(p + i * 4) = pp; *(float4*)(m + i * 4) = mm; *(float4*)(v + i * 4) = vv;
+        if (zero_grad) *(float4*)(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pb) *(uint2*)(pb + i * 4) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
     }
 }
@@ -387,12 +388,12 @@ extern "C" int tulip_l1_loss_bwd(const float* pred, const float* target, const f
     return TULIP_OK;
 }
 
-extern "C" int tulip_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
-                           const float* hyper, const uint8_t* decay_mask64, hipStream_t stream) {
+extern "C" int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
+                           const float* hyper, const uint8_t* decay_mask64, int zero_grad, hipStream_t stream) {
     if (n <= 0) return TULIP_OK;
     if (n & 3) return TULIP_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, hyper,
-                       decay_mask64);
+                       decay_mask64, zero_grad);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

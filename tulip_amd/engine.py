@@ -639,10 +639,10 @@ class TulipEngine:
             user_hook(tag)
 
         M0 = B * H0 * W0
-        ops.l1_loss_bwd(P.pred, P.target, gscale_dev, gscale, P.dpred, P.pred.numel())
         tpart = P["tail.dwd_part"]
         ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
-                     W_.p32("decoder_pred.weight"), P.dpred, P["tail.dz"], tpart, B, H0, W0, E)
+                     W_.p32("decoder_pred.weight"), P.pred, P["tail.dz"], tpart, B, H0, W0, E, target=P.target,
+                     gscale_dev=gscale_dev, gscale=gscale)     # L1 backward (tulip.py:692-693) formed in-kernel
         gdw = G("decoder_pred.weight")
         self._side(lambda: ops.reduce_rows2(tpart, 128, gdw, E, None, 0, None, 0, (M0 + 31) // 32))
         self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),

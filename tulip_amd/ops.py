@@ -152,9 +152,9 @@ def tail_fwd(xn, We, be, wd, pred, B, H, W, E):
           "tulip_tail_fwd")
 
 
-def tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E):
+def tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E, target=None, gscale_dev=None, gscale=1.0):
     check(_lib.load().tulip_tail_bwd(_p(xn), _p(We), _p(be), _p(wd), _p(dpred), _p(dz), _p(dwd), B, H, W, E,
-                                     _stream()), "tulip_tail_bwd")
+                                     _p(target), _p(gscale_dev), float(gscale), _stream()), "tulip_tail_bwd")
 
 
 def l1_loss_fwd(pred, target, partials, losses, n, log_transform):
@@ -167,6 +167,6 @@ def l1_loss_bwd(pred, target, gscale_dev, gscale, dpred, n):
                                         _stream()), "tulip_l1_loss_bwd")
 
 
-def adamw(p, g, m, v, p_bf16, n, hyper, decay_mask64=None):
-    check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _p(decay_mask64), _stream()),
-          "tulip_adamw")
+def adamw(p, g, m, v, p_bf16, n, hyper, decay_mask64=None, zero_grad=False):
+    check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _p(decay_mask64),
+                                  int(zero_grad), _stream()), "tulip_adamw")

@@ -68,7 +68,7 @@ class Trainer:
 
     def _fwd_bwd(self, hook):
         eng, P = self.eng, self.P
-        self.g.zero_()
+        # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training)
         eng.run_forward(P)
         eng.run_backward(P, self.g, bucket_hook=hook,
@@ -76,7 +76,7 @@ class Trainer:
 
     def _adamw(self):
         W = self.eng.params
-        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask)
+        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=True)
 
     # ------------------------------------------------------------------ graph capture
     def _capture(self):
@@ -134,6 +134,7 @@ class Trainer:
             self._fwd_bwd(lambda tag: None)
             scratch = torch.zeros(64, dtype=torch.float32, device=self.device)
             ops.adamw(scratch, scratch.clone(), scratch.clone(), scratch.clone(), None, 64, self.hyper, None)
+            self.g.zero_()      # the warm-up pass above accumulated into g without an optimizer step
             torch.cuda.synchronize()
             self._capture()
         for graph, tag in self._segments:
