@@ -172,6 +172,28 @@ int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscal
 int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
                 const uint8_t* decay_mask64, int zero_grad, hipStream_t stream);
 
+/* Gradient L2 norm read-out (misc.py:317-329 get_grad_norm_, taken before the optimizer step, misc.py:303):
+ * out[0] = sqrt(sum g[i]^2) * scale * (scale_dev ? scale_dev[0] : 1).  partials: scratch of 1024 doubles.
+ * Fixed partition and fold order: deterministic. */
+int tulip_grad_norm(const float* g, int64_t n, double* partials, const float* scale_dev, float scale, float* out,
+                    hipStream_t stream);
+
+/* Range-image input transforms in one pass (util/datasets.py): ScaleTensor :138-142, FilterInvalidPixels
+ * :144-151, DownsampleTensor :117-125, DownsampleTensorWidth :127-135, LogTransform :68-70,
+ * RandomRollRangeMap :96-107, composed as build_{durlar,kitti,carla}_upsampling_dataset do (:244-340).
+ * raw: B sensor images in metres, element type float32 (raw_dtype 0) or float16 (raw_dtype 1); pixel (i,j) of
+ * image b is raw[b*batch_stride + base_offset + i*row_stride + j*col_stride] (strides in elements, may be
+ * negative), so the (H,W,2) .npy payload is read in place with col_stride 2 (npy_loader :175-179 takes channel 0)
+ * and the .rimg payload with row_stride -1, col_stride -s0, base_offset s0*s1-1 (rimg_loader :181-193:
+ * transpose + flip).  hi (B,1,H,W) and/or lo (B,1,H/row_factor,W/col_factor); either may be NULL.
+ *   v = raw*scale; if gate: v = (min_range<=v<=max_range) ? v : 0; if log_transform: v = log1p(v);
+ *   hi[i][(j+roll)%W] = v;  lo[(i-row_phase)/row_factor][((j-col_phase)/col_factor+roll)%(W/col_factor)] = v
+ *   for rows/columns with (i-row_phase)%row_factor==0, (j-col_phase)%col_factor==0. */
+int tulip_range_prep(const void* raw, int raw_dtype, int64_t batch_stride, int64_t row_stride, int64_t col_stride,
+                     int64_t base_offset, float* hi, float* lo, int B, int H, int W, int row_factor, int col_factor,
+                     int row_phase, int col_phase, float scale, int gate, float min_range, float max_range,
+                     int log_transform, int roll_shift, hipStream_t stream);
+
 /* library self-description */
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);

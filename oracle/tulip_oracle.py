@@ -558,3 +558,36 @@ def adamw_reference_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, 
     vhat = v / (1 - beta2 ** step)
     p = p - lr * mhat / (vhat.sqrt() + eps)
     return p, m, v
+
+
+def train_loop_reference(sd: Dict[str, Tensor], cfg: TulipConfig, batches, epochs_run: int, lr: float,
+                         min_lr: float, warmup_epochs: float, epochs: float, accum_iter: int = 1,
+                         betas=(0.9, 0.95), eps: float = 1e-8, wd: float = 0.01, lowp: bool = False):
+    """engine_upsampling.py:46-124 on the oracle: per-window LR from `it/len + epoch` (:68-69), gradients of
+    loss/accum_iter accumulated (:90), L2 norm of all gradients before the step (misc.py:303,317-329), AdamW with
+    decay on ndim>1 parameters only (main:282-283), gradients cleared after the step (:96-97) and at the top of
+    each epoch (:61).  Returns (loss per micro-step, lr per micro-step, grad norm per optimizer step)."""
+    params = {k: v.clone() for k, v in sd.items() if v.is_floating_point()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    losses, lrs, norms, t, cur = [], [], [], 0, lr
+    for epoch in range(epochs_run):
+        acc = {k: torch.zeros_like(v) for k, v in params.items()}
+        for it, (lo, hi) in enumerate(batches):
+            if it % accum_iter == 0:
+                cur = cosine_lr(it / len(batches) + epoch, lr, min_lr, warmup_epochs, epochs)
+            full = dict(sd)
+            full.update(params)
+            _, loss, _, g = tulip_loss_and_grads(full, cfg, lo, hi, lowp=lowp)
+            losses.append(loss.item())
+            for k in acc:
+                acc[k] += g[k] / accum_iter
+            if (it + 1) % accum_iter == 0:
+                norms.append(math.sqrt(sum(float((a.double() ** 2).sum()) for a in acc.values())))
+                t += 1
+                for k in params:
+                    params[k], m[k], v2[k] = adamw_reference_step(params[k], acc[k], m[k], v2[k], t, cur, betas[0],
+                                                                  betas[1], eps, wd if params[k].ndim > 1 else 0.0)
+                    acc[k].zero_()
+            lrs.append(cur)
+    return losses, lrs, norms

@@ -273,6 +273,8 @@ def main():
     golden_lr(T)
     golden_init(T)
     golden_train_trajectory(T)
+    golden_train_loop(T)
+    golden_transforms()
     tiny = O.tiny_config()
     golden_model(T, "g3_tiny_fp32", tiny, batch=2, seed=0, with_grads=True)
     golden_model(T, "g3_tiny_droppath", tiny, batch=4, seed=1, with_grads=True, drop_path=True)
@@ -334,8 +336,143 @@ def golden_train_trajectory(T):
     print("train trajectory:", [round(l, 6) for l in losses])
 
 
+def golden_train_loop(T):
+    """f-1: the reference's train_one_epoch semantics (engine_upsampling.py:46-124) with accum_iter=2 over two
+    epochs of 4 micro-batches: util.lr_sched.adjust_learning_rate (imported) at every window start, loss/accum
+    backward, util.misc.get_grad_norm_ (imported) before each optimizer step, zero_grad after it."""
+    import math
+    six = types.ModuleType("torch._six")          # util/misc.py:21 imports `inf` from a module torch no longer has
+    six.inf = math.inf
+    sys.modules["torch._six"] = six
+    import util.lr_sched as lr_sched
+    import util.misc as misc
+    cfg = O.tiny_config()
+    sd = O.key_seeded_state_dict(cfg, seed=5)
+    batches = [O.synthetic_batch(cfg, 2, seed=100 + i) for i in range(4)]
+    m = ref_model(T, cfg, drop_path_rate=0.0)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    decay = [p for p in m.parameters() if p.ndim > 1]
+    nodecay = [p for p in m.parameters() if p.ndim <= 1]
+    args = types.SimpleNamespace(lr=5e-4, min_lr=1e-5, warmup_epochs=1, epochs=3, accum_iter=2)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}],
+                            lr=args.lr, betas=(0.9, 0.95))
+    losses, lrs, norms = [], [], []
+    for epoch in range(2):
+        opt.zero_grad()
+        for it, (lo, hi) in enumerate(batches):
+            if it % args.accum_iter == 0:
+                lr_sched.adjust_learning_rate(opt, it / len(batches) + epoch, args)
+            _, loss, _ = m(lo, hi)
+            losses.append(loss.item())
+            (loss / args.accum_iter).backward()
+            if (it + 1) % args.accum_iter == 0:
+                norms.append(misc.get_grad_norm_(m.parameters()).item())
+                opt.step()
+                opt.zero_grad()
+            lrs.append(opt.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(HERE, "g9_train_loop.npz"), loss=np.array(losses), lr=np.array(lrs),
+                        grad_norm=np.array(norms), seed=np.int64(5), batch=np.int64(2), data_seed0=np.int64(100),
+                        n_batches=np.int64(4), accum_iter=np.int64(2), epochs_run=np.int64(2),
+                        sched=np.array([args.lr, args.min_lr, args.warmup_epochs, args.epochs]))
+    print("train loop:", [round(l, 6) for l in losses], [round(n_, 5) for n_ in norms], lrs)
+
+
+def import_reference_datasets():
+    """util/datasets.py needs torchvision and timm.data at import time (DatasetFolder base class, ImageNet
+    helpers); neither is used by the transform classes or the two loaders captured here."""
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvd = types.ModuleType("torchvision.datasets")
+    tvv = types.ModuleType("torchvision.datasets.vision")
+    tvd.ImageFolder = tvd.DatasetFolder = tvv.VisionDataset = type("_Absent", (), {})
+    tv.transforms, tv.datasets = tvt, tvd
+    td = types.ModuleType("timm.data")
+    td.create_transform = None
+    tdc = types.ModuleType("timm.data.constants")
+    tdc.IMAGENET_DEFAULT_MEAN = tdc.IMAGENET_DEFAULT_STD = None
+    tdd = types.ModuleType("timm.data.dataset")
+    tdd.ImageDataset = object
+    sys.modules.setdefault("timm", types.ModuleType("timm"))
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.datasets": tvd,
+                        "torchvision.datasets.vision": tvv, "timm.data": td, "timm.data.constants": tdc,
+                        "timm.data.dataset": tdd})
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import util.datasets as D
+    return D
+
+
+def golden_transforms():
+    """f-3: the reference's transform classes composed in the order of build_{durlar,kitti,carla}_upsampling_dataset
+    (datasets.py:244-340), and its npy/rimg loaders on files written here.  ToTensor is absent (torchvision):
+    for float32 (H, W) input it is from_numpy(a)[None]."""
+    import tempfile
+    from oracle import data_oracle as DO
+    D = import_reference_datasets()
+    out = {}
+    cases = [("kitti", (16, 64), (64, 64), True, None), ("kitti_w", (16, 32), (64, 64), True, None),
+             ("durlar", (32, 128), (128, 128), True, 37), ("carla", (8, 96), (32, 96), False, None),
+             ("durlar_lin", (16, 64), (64, 64), False, 5)]
+    for i, (name, lo_size, hi_size, log_t, shift) in enumerate(cases):
+        ds = name.split("_")[0]
+        raw = DO.synthetic_raw(2, hi_size[0], hi_size[1], seed=40 + i)
+        if ds == "durlar":
+            t_lo = [D.ScaleTensor(1 / 120), D.FilterInvalidPixels(min_range=0.3 / 120, max_range=1)]
+            t_hi = [D.ScaleTensor(1 / 120), D.FilterInvalidPixels(min_range=0.3 / 120, max_range=1)]
+        elif ds == "kitti":
+            t_lo, t_hi = [D.ScaleTensor(1 / 80)], [D.ScaleTensor(1 / 80)]
+        else:
+            t_lo = [D.ScaleTensor(1 / 80), D.FilterInvalidPixels(min_range=2 / 80, max_range=1)]
+            t_hi = [D.ScaleTensor(1 / 80), D.FilterInvalidPixels(min_range=2 / 80, max_range=1)]
+        t_lo.append(D.DownsampleTensor(h_high_res=hi_size[0], downsample_factor=hi_size[0] // lo_size[0]))
+        if hi_size[1] // lo_size[1] > 1:
+            t_lo.append(D.DownsampleTensorWidth(w_high_res=hi_size[1], downsample_factor=hi_size[1] // lo_size[1]))
+        if log_t:
+            t_lo.append(D.LogTransform()); t_hi.append(D.LogTransform())
+        if shift is not None:
+            t_lo.append(D.RandomRollRangeMap(shift=shift)); t_hi.append(D.RandomRollRangeMap(shift=shift))
+        los, his = [], []
+        for b in range(raw.shape[0]):
+            lo = hi = torch.from_numpy(raw[b].numpy())[None]
+            for t in t_lo:
+                lo = t(lo)
+            for t in t_hi:
+                hi = t(hi)
+            los.append(lo); his.append(hi)
+        lo, hi = torch.stack(los), torch.stack(his)
+        olo, ohi = DO.range_prep(raw, DO.DATASETS[ds], lo_size, hi_size, log_t, shift)
+        assert torch.equal(olo, lo) and torch.equal(ohi, hi), name
+        out[f"{name}_lo"], out[f"{name}_hi"] = lo.numpy(), hi.numpy()
+        out[f"{name}_meta"] = np.array([40 + i, *lo_size, *hi_size, int(log_t), -1 if shift is None else shift])
+    # loaders
+    rng = np.random.default_rng(7)
+    with tempfile.TemporaryDirectory() as tmp:
+        a = (rng.random((16, 48, 2)) * 100).astype(np.float32)
+        p = os.path.join(tmp, "a.npy")
+        np.save(p, a)
+        out["npy_bytes"] = np.frombuffer(open(p, "rb").read(), dtype=np.uint8)
+        out["npy_expected"] = D.npy_loader(p)
+        pay = (rng.random((40, 12)) * 80).astype(np.float16)          # stored (s1, s0) with header (s0, s1)
+        p = os.path.join(tmp, "a.rimg")
+        with open(p, "wb") as f:
+            np.array([12, 40], dtype=np.uint).tofile(f)
+            pay.tofile(f)
+        out["rimg_bytes"] = np.frombuffer(open(p, "rb").read(), dtype=np.uint8)
+        out["rimg_expected"] = D.rimg_loader(p)
+    assert np.array_equal(DO.npy_range(out["npy_bytes"].tobytes()), out["npy_expected"])
+    assert np.array_equal(DO.rimg_range(out["rimg_bytes"].tobytes()), out["rimg_expected"])
+    out["cases"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "g8_transforms.npz"), **out)
+    print("transform fixtures written:", [c[0] for c in cases], out["rimg_expected"].shape)
+
+
 if __name__ == "__main__":
-    if "--traj-only" in sys.argv:
+    if "--transforms-only" in sys.argv:
+        golden_transforms()
+    elif "--loop-only" in sys.argv:
+        golden_train_loop(import_reference())
+    elif "--traj-only" in sys.argv:
         golden_train_trajectory(import_reference())
     elif "--init-only" in sys.argv:
         golden_init(import_reference())

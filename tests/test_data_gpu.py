@@ -1,0 +1,112 @@
+"""SURVEY 8(f)-3 on the GPU: tulip_range_prep (through the C ABI) against the reference-generated fixture g8 and
+against the data oracle.  Scale, gate, subsample and roll are bit exact; log1p differs from torch's CPU log1p by
+at most 2 ulp of the result (<= 2.4e-7 absolute, values <= 0.7)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_oracle as DO
+from tulip_amd import data as D
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOG_ATOL = 2.4e-7
+
+
+@pytest.fixture(scope="module")
+def g8(golden_dir):
+    return np.load(os.path.join(golden_dir, "g8_transforms.npz"))
+
+
+def close(got: torch.Tensor, ref, log_t: bool):
+    ref = torch.as_tensor(np.ascontiguousarray(ref))
+    got = got.cpu()
+    assert got.shape == ref.shape
+    if not log_t:
+        assert torch.equal(got, ref)
+    else:
+        assert torch.equal(got == 0, ref == 0)          # the gate decisions themselves are exact
+        assert (got - ref).abs().max().item() <= LOG_ATOL
+
+
+def test_kernel_matches_reference_fixture(g8):
+    for name in g8["cases"].tolist():
+        seed, h, w, H, W, log_t, shift = (int(v) for v in g8[f"{name}_meta"])
+        raw = DO.synthetic_raw(2, H, W, seed=seed).to(DEV)
+        prep = D.RangePrep(name.split("_")[0], (h, w), (H, W), bool(log_t), None if shift < 0 else shift)
+        lo, hi = prep(raw)
+        close(lo, g8[f"{name}_lo"], bool(log_t))
+        close(hi, g8[f"{name}_hi"], bool(log_t))
+
+
+@pytest.mark.parametrize("ds,lo_size,hi_size", [("kitti", (16, 1024), (64, 1024)), ("durlar", (32, 2048), (128, 2048)),
+                                                ("carla", (32, 2048), (128, 2048)), ("kitti", (16, 512), (64, 1024))])
+def test_full_size_npy_payload_in_place(ds, lo_size, hi_size):
+    """BASELINE sizes, raw read straight from the interleaved (H,W,2) .npy payload (channel 0)."""
+    B = 8
+    rng = DO.synthetic_raw(B, *hi_size, seed=11)
+    payload = torch.stack([rng, torch.rand_like(rng)], dim=-1).contiguous()        # [range, intensity]
+    for log_t, shift in ((True, None), (False, 1500)):
+        prep = D.RangePrep(ds, lo_size, hi_size, log_t, shift)
+        lo, hi = prep(payload.to(DEV))
+        olo, ohi = DO.range_prep(rng, DO.DATASETS[ds], lo_size, hi_size, log_t, shift)
+        close(lo, olo, log_t)
+        close(hi, ohi, log_t)
+        lo2, none = prep(payload.to(DEV), want_hi=False)                            # inference: no target
+        assert none is None and torch.equal(lo2, lo)
+
+
+def test_rimg_payload_in_place(g8, tmp_path):
+    p = tmp_path / "a.rimg"
+    p.write_bytes(g8["rimg_bytes"].tobytes())
+    s0, s1, pay = D.read_rimg_payload(str(p))
+    prep = D.RangePrep("carla", (s0 // 4, s1), (s0, s1), False)
+    lo, hi = prep.from_rimg(torch.from_numpy(pay.copy())[None].to(DEV))
+    olo, ohi = DO.range_prep(torch.from_numpy(g8["rimg_expected"].copy())[None], DO.DATASETS["carla"], (s0 // 4, s1),
+                             (s0, s1), False)
+    close(lo, olo, False)
+    close(hi, ohi, False)
+    # full CARLA size, random payload
+    g = torch.Generator().manual_seed(5)
+    pay = (torch.rand(2, 2048, 128, generator=g) * 90).half()
+    ref = torch.flip(pay.transpose(1, 2), dims=(1, 2)).float()                     # datasets.py:190-193
+    prep = D.RangePrep("carla", (32, 2048), (128, 2048), True)
+    lo, hi = prep.from_rimg(pay.to(DEV))
+    olo, ohi = DO.range_prep(ref, DO.DATASETS["carla"], (32, 2048), (128, 2048), True)
+    close(lo, olo, True)
+    close(hi, ohi, True)
+
+
+def test_row_and_column_phase():
+    """DownsampleTensor(random=True) picks a non-zero start row/column (datasets.py:118-121,128-131)."""
+    raw = DO.synthetic_raw(2, 64, 128, seed=2)
+    prep = D.RangePrep("durlar", (16, 64), (64, 128), False, None, row_phase=3, col_phase=1)
+    lo, hi = prep(raw.to(DEV))
+    olo, ohi = DO.range_prep(raw, DO.DATASETS["durlar"], (16, 64), (64, 128), False, None, row_phase=3, col_phase=1)
+    close(lo, olo, False)
+    close(hi, ohi, False)
+
+
+def test_device_loader_end_to_end(tmp_path):
+    """files on disk -> pinned staging -> one kernel -> (low_res, high_res), against loader + transform oracle"""
+    rng = np.random.default_rng(0)
+    root = tmp_path / "train"
+    root.mkdir()
+    raws = []
+    for i in range(5):
+        a = (rng.random((64, 256, 2)) * 100).astype(np.float32)
+        np.save(root / f"{i:06d}.npy", a)
+        raws.append(torch.from_numpy(a[..., 0].copy()))
+    prep = D.RangePrep("kitti", (16, 256), (64, 256), True)
+    ld = D.DeviceRangeLoader(str(root), prep, 2, drop_last=False)
+    assert len(ld) == 3
+    seen = 0
+    for lo, hi in ld:
+        n = lo.shape[0]
+        olo, ohi = DO.range_prep(torch.stack(raws[seen:seen + n]), DO.DATASETS["kitti"], (16, 256), (64, 256), True)
+        close(lo, olo, True)
+        close(hi, ohi, True)
+        seen += n
+    assert seen == 5

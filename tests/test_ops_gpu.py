@@ -494,3 +494,18 @@ def test_adamw_matches_torch(ops):
         ops.adamw(q, (g * step).contiguous(), m, v, qb, n, hyper, None)
         close(q, p.detach(), 1e-5, 1e-6, f"adamw step {step}")
         assert torch.equal(qb, bf(q))
+
+
+@pytest.mark.parametrize("n", [64, 1003, 27_150_337])
+def test_grad_norm(n):
+    """tulip_grad_norm vs float64 torch (misc.py:317-329); deterministic across calls."""
+    g = torch.randn(n, device=DEV) * 0.01
+    part = torch.zeros(1024, dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    scale = torch.tensor([0.5], device=DEV)
+    ops.grad_norm(g, n, part, out, scale_dev=scale)
+    ref = g.double().norm().item() * 0.5
+    assert abs(out.item() - ref) <= 1e-6 * ref
+    first = out.clone()
+    ops.grad_norm(g, n, part, out, scale_dev=scale)
+    assert torch.equal(first, out)

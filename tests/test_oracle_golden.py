@@ -161,3 +161,18 @@ def test_adamw_step_matches_torch():
         opt.step()
         q, m, v = O.adamw_reference_step(q, g * step, m, v, step, 5e-4)
         assert torch.allclose(q, p.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_train_loop_vs_reference(golden_dir):
+    """8(f)-1: the oracle's restatement of train_one_epoch (accum_iter=2, warm-up + cosine LR, grad norm,
+    AdamW with timm's decay grouping) against the REFERENCE model + imported lr_sched/get_grad_norm_ (g9)."""
+    z = np.load(os.path.join(golden_dir, "g9_train_loop.npz"))
+    cfg = O.tiny_config(drop_path_rate=0.0)
+    sd = O.key_seeded_state_dict(cfg, seed=int(z["seed"]))
+    batches = [O.synthetic_batch(cfg, int(z["batch"]), seed=int(z["data_seed0"]) + i) for i in range(int(z["n_batches"]))]
+    lr, min_lr, warm, epochs = z["sched"].tolist()
+    losses, lrs, norms = O.train_loop_reference(sd, cfg, batches, int(z["epochs_run"]), lr, min_lr, warm, epochs,
+                                                accum_iter=int(z["accum_iter"]))
+    np.testing.assert_allclose(lrs, z["lr"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(losses, z["loss"], rtol=2e-5)
+    np.testing.assert_allclose(norms, z["grad_norm"], rtol=2e-4)

@@ -262,6 +262,39 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
 }
 
+// ---------------------------------------------------------------- gradient L2 norm (misc.py:317-329)
+// fixed block -> partial mapping and a fixed fold order: the read-out is run-to-run deterministic
+constexpr int NORM_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, double* __restrict__ partials,
+                                                            int64_t n) {
+    __shared__ float red[4];
+    const int64_t n4 = n >> 2;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = *(const float4*)(g + i * 4);
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = g[n4 * 4 + threadIdx.x]; s += t * t; }
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partials, int nblocks,
+                                                          const float* __restrict__ scale_dev, float scale,
+                                                          float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partials[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (red[0] + red[1]) + (red[2] + red[3]);
+        out[0] = (float)(sqrt(t) * (double)(scale_dev ? scale_dev[0] * scale : scale));
+    }
+}
+
 inline int grid_for(int64_t work, int cap = 256 * 8) {
     int64_t b = (work + 255) / 256;
     if (b > cap) b = cap;
@@ -394,6 +427,16 @@ extern "C" int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_b
     if (n & 3) return TULIP_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, hyper,
                        decay_mask64, zero_grad);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_grad_norm(const float* g, int64_t n, double* partials, const float* scale_dev, float scale,
+                               float* out, hipStream_t stream) {
+    if (n <= 0 || !partials || !out) return TULIP_ERR_ARG;
+    const int nb = grid_for((n + 3) / 4, NORM_BLOCKS);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, g, partials, n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, nb, scale_dev, scale, out);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

@@ -170,3 +170,16 @@ def l1_loss_bwd(pred, target, gscale_dev, gscale, dpred, n):
 def adamw(p, g, m, v, p_bf16, n, hyper, decay_mask64=None, zero_grad=False):
     check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _p(decay_mask64),
                                   int(zero_grad), _stream()), "tulip_adamw")
+
+
+def grad_norm(g, n, partials, out, scale_dev=None, scale=1.0):
+    check(_lib.load().tulip_grad_norm(_p(g), n, _p(partials), _p(scale_dev), float(scale), _p(out), _stream()),
+          "tulip_grad_norm")
+
+
+def range_prep(raw, raw_dtype, batch_stride, row_stride, col_stride, base_offset, hi, lo, B, H, W, row_factor,
+               col_factor, row_phase, col_phase, scale, gate, min_range, max_range, log_transform, roll_shift):
+    check(_lib.load().tulip_range_prep(_p(raw), raw_dtype, batch_stride, row_stride, col_stride, base_offset, _p(hi),
+                                       _p(lo), B, H, W, row_factor, col_factor, row_phase, col_phase, float(scale),
+                                       int(gate), float(min_range), float(max_range), int(log_transform),
+                                       int(roll_shift), _stream()), "tulip_range_prep")

@@ -8,12 +8,16 @@ captured once into HIP graphs (torch.cuda.CUDAGraph) and replayed; the host only
 8-float hyper-parameter block (lr and bias corrections) per step.  With world_size > 1 the sequence
 is cut into graph segments at the bucket boundaries and the all-reduces are issued between replays
 (collectives are deliberately NOT captured).  bf16 needs no GradScaler (misc.py:288-308 exists for
-fp16); the non-finite-loss abort (engine:85-88) is left to the caller via `losses`.
+fp16).  Gradient accumulation (`accum_iter`, engine:90-97) runs the forward/backward sequence with
+d(loss/accum_iter) accumulating into the flat gradient buffer; only the last micro-step of a window
+all-reduces (the sum of the per-micro-step all-reduces the reference issues) and applies AdamW.
+`train_one_epoch` is the reference's loop around it (per-iteration LR, non-finite-loss abort).
 """
 from __future__ import annotations
 
 import math
-from typing import Optional
+import sys
+from typing import Iterable, Optional
 
 import torch
 import torch.distributed as dist
@@ -33,7 +37,7 @@ def cosine_lr(epoch_float: float, lr: float, min_lr: float, warmup_epochs: float
 class Trainer:
     def __init__(self, model, batch_size: int, lr: float = 5e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, device=None, use_graph: bool = True, process_group=None,
-                 bucket_mb: float = 16.0):
+                 bucket_mb: float = 16.0, accum_iter: int = 1, track_grad_norm: bool = False):
         self.model = model
         device = device or torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -48,39 +52,50 @@ class Trainer:
         self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.t = 0
+        self.accum_iter, self.micro = int(accum_iter), 0
+        if self.accum_iter < 1:
+            raise ValueError("accum_iter must be >= 1")
+        # misc.py:303 get_grad_norm_ (the reference computes it at every update and drops the value)
+        self.track_grad_norm = track_grad_norm
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=device)
+        self._norm_part = torch.zeros(1024, dtype=torch.float64, device=device)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucketer = GradBucketer(W.groups, W.total, bucket_mb, process_group)
         self.use_graph = use_graph
-        self._segments = None     # [(CUDAGraph, tag or None)]
+        self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
         self._side = torch.cuda.Stream(device=device) if use_graph else None
         W.refresh_shadow()
 
     # ------------------------------------------------------------------ pieces
-    def _set_hyper(self, lr: Optional[float]):
+    def _set_hyper(self):
         self.t += 1
         b1, b2 = self.betas
         h = self.hyper_host
-        h[0] = self.lr if lr is None else lr
+        h[0] = self.lr
         h[1], h[2], h[3], h[4] = b1, b2, self.eps, self.wd
         h[5], h[6] = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
         h[7] = 1.0 / self.world
         self.hyper.copy_(h, non_blocking=True)
 
-    def _fwd_bwd(self, hook):
+    def _fwd_bwd(self, hook, update: bool = True):
         eng, P = self.eng, self.P
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training)
         eng.run_forward(P)
-        eng.run_backward(P, self.g, bucket_hook=hook,
-                         join_tags=set(self.bucketer.by_tag) if self.world > 1 else None)
+        eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
+                         join_tags=set(self.bucketer.by_tag) if (self.world > 1 and update) else None)
 
     def _adamw(self):
         W = self.eng.params
+        if self.track_grad_norm:
+            # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
+            ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
         ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=True)
 
     # ------------------------------------------------------------------ graph capture
-    def _capture(self):
-        """Capture the step as graph segments cut at the all-reduce points."""
+    def _capture(self, update: bool):
+        """Capture one step as graph segments cut at the all-reduce points.  update=False is a
+        gradient-accumulation micro-step: forward + backward only, no all-reduce, no AdamW."""
         segs = []
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
@@ -90,14 +105,17 @@ class Trainer:
 
             def hook(tag):
                 nonlocal cur
-                if self.world > 1 and tag in self.bucketer.by_tag:
+                if update and self.world > 1 and tag in self.bucketer.by_tag:
                     cur.capture_end()
                     segs.append((cur, tag))
                     cur = torch.cuda.CUDAGraph()
                     cur.capture_begin()
 
-            self._fwd_bwd(hook)
-            if self.world == 1:
+            self._fwd_bwd(hook, update)
+            if not update:
+                cur.capture_end()
+                segs.append((cur, None))
+            elif self.world == 1:
                 self._adamw()
                 cur.capture_end()
                 segs.append((cur, None))
@@ -110,34 +128,52 @@ class Trainer:
                 g2.capture_end()
                 segs.append((g2, "adamw"))
         torch.cuda.current_stream().wait_stream(side)
-        self._segments = segs
+        return segs
 
     # ------------------------------------------------------------------ public
     def load_batch(self, x: torch.Tensor, target: torch.Tensor):
         self.P.x_in.copy_(x.reshape(self.P.x_in.shape), non_blocking=True)
         self.P.target.copy_(target.reshape(self.P.target.shape), non_blocking=True)
 
+    def zero_grad(self):
+        """optimizer.zero_grad() at the top of an epoch (engine_upsampling.py:61): drops the gradients of
+        an unfinished accumulation window."""
+        self.g.zero_()
+        self.micro = 0
+
     def step(self, x: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None,
              lr: Optional[float] = None) -> torch.Tensor:
-        """One optimizer step on the batch (or on the batch already resident in the plan).
-        Returns the device tensor [loss, pixel_loss] (no host sync)."""
+        """One micro-step on the batch (or on the batch already resident in the plan); every
+        `accum_iter`-th call is an optimizer step.  `lr` (if given) becomes the learning rate of the
+        next optimizer step.  Returns the device tensor [loss, pixel_loss] (no host sync)."""
         if x is not None:
             self.load_batch(x, target)
-        self._set_hyper(lr)
+        if lr is not None:
+            self.lr = lr
+        self.micro += 1
+        update = self.micro % self.accum_iter == 0
+        if update:
+            self._set_hyper()
         if not self.use_graph:
-            self._fwd_bwd(lambda tag: self.bucketer.on_group_done(tag, self.g))
-            self.bucketer.wait_all()
-            self._adamw()
+            if update:
+                self._fwd_bwd(lambda tag: self.bucketer.on_group_done(tag, self.g))
+                self.bucketer.wait_all()
+                self._adamw()
+            else:
+                self._fwd_bwd(lambda tag: None, update=False)
             return self.P.losses
         if self._segments is None:
             # load every kernel once outside capture, without touching parameters or optimizer state
             self._fwd_bwd(lambda tag: None)
             scratch = torch.zeros(64, dtype=torch.float32, device=self.device)
             ops.adamw(scratch, scratch.clone(), scratch.clone(), scratch.clone(), None, 64, self.hyper, None)
+            ops.grad_norm(scratch, 64, self._norm_part, self.grad_norm)
             self.g.zero_()      # the warm-up pass above accumulated into g without an optimizer step
             torch.cuda.synchronize()
-            self._capture()
-        for graph, tag in self._segments:
+            self._segments = {True: self._capture(True)}
+            if self.accum_iter > 1:
+                self._segments[False] = self._capture(False)
+        for graph, tag in self._segments[update]:
             if tag == "adamw":
                 self.bucketer.wait_all()
                 graph.replay()
@@ -146,3 +182,32 @@ class Trainer:
                 if tag is not None:
                     self.bucketer.on_group_done(tag, self.g)
         return self.P.losses
+
+
+def train_one_epoch(trainer: Trainer, data_loader: Iterable, epoch: int, args, log_every: int = 0) -> dict:
+    """engine_upsampling.py:46-124 around the fused step: the learning rate is set from
+    `data_iter_step / len(data_loader) + epoch` at the first micro-step of every accumulation window
+    (engine:68-69), a non-finite loss prints both losses and exits with status 1 (engine:85-88), and
+    the returned dict holds the epoch averages of `loss` and the last `lr` (engine:124).
+    `args` needs lr, min_lr, warmup_epochs, epochs (lr_sched.py:9-21); batches are
+    (low_res, high_res) tensors or the reference's ({'sample': ...}, {'sample': ...}) dicts.
+    Like the reference, the loss is read back every iteration (one host sync per step)."""
+    trainer.model.train(True)
+    trainer.zero_grad()
+    n = len(data_loader)
+    tot, cnt, lr = 0.0, 0, trainer.lr
+    for it, (lo, hi) in enumerate(data_loader):
+        if it % trainer.accum_iter == 0:
+            lr = cosine_lr(it / n + epoch, args.lr, args.min_lr, args.warmup_epochs, args.epochs)
+        if isinstance(lo, dict):
+            lo, hi = lo["sample"], hi["sample"]
+        losses = trainer.step(lo.to(trainer.device, non_blocking=True), hi.to(trainer.device, non_blocking=True),
+                              lr=lr).tolist()
+        if not math.isfinite(losses[0]):
+            print("Total Loss is {}, stopping training".format(losses[0]))
+            print("Pixel Loss is {}, stopping training".format(losses[1]))
+            sys.exit(1)
+        tot, cnt = tot + losses[0], cnt + 1
+        if log_every and (it + 1) % log_every == 0:
+            print(f"Epoch: [{epoch}]  [{it + 1}/{n}]  lr: {lr:.6f}  loss: {losses[0]:.4f}")
+    return {"loss": tot / max(cnt, 1), "lr": lr}
