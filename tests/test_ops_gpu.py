@@ -497,7 +497,7 @@ def test_adamw_matches_torch(ops):
 
 
 @pytest.mark.parametrize("n", [64, 1003, 27_150_337])
-def test_grad_norm(n):
+def test_grad_norm(ops, n):
     """tulip_grad_norm vs float64 torch (misc.py:317-329); deterministic across calls."""
     g = torch.randn(n, device=DEV) * 0.01
     part = torch.zeros(1024, dtype=torch.float64, device=DEV)
