@@ -275,6 +275,7 @@ def main():
     golden_train_trajectory(T)
     golden_train_loop(T)
     golden_transforms()
+    golden_eval()
     tiny = O.tiny_config()
     golden_model(T, "g3_tiny_fp32", tiny, batch=2, seed=0, with_grads=True)
     golden_model(T, "g3_tiny_droppath", tiny, batch=4, seed=1, with_grads=True, drop_path=True)
@@ -467,8 +468,167 @@ def golden_transforms():
     print("transform fixtures written:", [c[0] for c in cases], out["rimg_expected"].shape)
 
 
+def import_reference_engine():
+    """engine_upsampling.py imports plotting/export helpers and the Chamfer CUDA extension at module level.
+    Stand-ins that do not touch the evaluated arithmetic: torchvision.utils.make_grid (tensorboard image),
+    trimesh (.ply export, off), torch._six.inf.  The Chamfer extension is absent: the class below restates it
+    (squared float32 nearest-neighbour distances, oracle/eval_oracle.py) so the loop can run; chamfer values
+    in the fixture are therefore NOT reference outputs."""
+    import math
+    from oracle import eval_oracle as EO
+    import_reference_datasets()                       # torchvision stubs
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = lambda imgs, nrow=1: torch.zeros(3, 1, 1)
+    sys.modules["torchvision.utils"] = tvu
+    sys.modules["torchvision"].utils = tvu
+    sys.modules["trimesh"] = types.ModuleType("trimesh")
+    six = types.ModuleType("torch._six")
+    six.inf = math.inf
+    sys.modules["torch._six"] = six
+
+    class ChamferDistance:
+        def __call__(self, a, b):
+            a, b = a[0].float(), b[0].float()
+
+            def nn_sq(p, q):
+                out = torch.empty(p.shape[0])
+                for s0 in range(0, p.shape[0], 2048):
+                    d = p[s0:s0 + 2048, None, :] - q[None, :, :]
+                    out[s0:s0 + 2048] = (d * d).sum(-1).min(dim=1).values
+                return out
+            return nn_sq(a, b)[None], nn_sq(b, a)[None], None, None
+
+    cd = types.ModuleType("chamfer_distance")
+    cd.ChamferDistance = ChamferDistance
+    sys.modules["chamfer_distance"] = cd
+    for k in [k for k in sys.modules if k == "util.evaluation"]:
+        del sys.modules[k]                             # re-import against the stand-in above
+    torch.Tensor.cuda = lambda self, *a, **k: self     # evaluation.py:126-127 moves the clouds to the GPU
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import engine_upsampling as E
+    return E
+
+
+def golden_eval():
+    """f-2 / f-4: the reference's evaluate() and MCdrop() run end to end on CPU over seeded synthetic images with a
+    stand-in model whose outputs are seeded tensors; results.txt metrics and the intermediate point clouds
+    (recorded by wrapping the img_to_pcd_* names the loops call) are stored, and oracle/eval_oracle.py is
+    asserted against them."""
+    import json
+    import tempfile
+    import warnings
+    from oracle import eval_oracle as EO
+    warnings.filterwarnings("ignore")
+    E = import_reference_engine()
+    import util.evaluation as RE
+    out = {"durlar_elevation_lut": np.array(RE.elevation_lut), "durlar_offset_lut": np.array(RE.offset_lut),
+           "durlar_azimuth_lut": np.array(RE.azimuth_lut)}
+    recorded = []
+    for fn in ("img_to_pcd_kitti", "img_to_pcd_carla", "img_to_pcd_durlar"):
+        def wrap(f):
+            def g(img, *a, **k):
+                r = f(img, *a, **k)
+                recorded.append((np.array(img, copy=True), r))
+                return r
+            return g
+        setattr(E, fn, wrap(getattr(RE, fn)))
+
+    class Writer:
+        log_dir = "none"
+        def add_scalar(self, *a, **k): pass
+        def add_image(self, *a, **k): pass
+
+    class Model(nn.Module):
+        def __init__(self, preds, mc_sigma=0.0):
+            super().__init__()
+            self.preds, self.i, self.calls, self.mc_sigma = preds, 0, 0, mc_sigma
+        def forward(self, lo, hi, eval=False, mc_drop=False):
+            if not mc_drop:
+                p = self.preds[self.i]; self.i += 1
+                return p, None, None
+            n = lo.shape[0]
+            base = self.preds[self.i]
+            outs = []
+            for k in range(n):
+                g = torch.Generator().manual_seed(9000 + self.calls); self.calls += 1
+                outs.append(base[0] + self.mc_sigma * torch.randn(base.shape[1:], generator=g) *
+                            (torch.rand(base.shape[1:], generator=g) < 0.3))
+            if self.calls % 12 == 0:
+                self.i += 1
+            return torch.stack(outs)
+
+    cases = [  # name, dataset, (H,W), (h,w), log, mc, keep_close, n_images
+        ("kitti", "kitti", (64, 1024), (16, 1024), True, False, False, 2),
+        ("carla", "carla", (32, 256), (8, 256), False, False, False, 2),
+        ("carla_w", "carla", (32, 256), (8, 128), True, False, False, 1),
+        ("durlar", "durlar", (128, 256), (32, 256), True, False, True, 2),
+        ("kitti_mc", "kitti", (64, 1024), (16, 1024), True, True, True, 1),
+        ("durlar_mc", "durlar", (128, 256), (32, 256), True, True, False, 1),
+    ]
+    for ci, (name, ds, HW, hw, log_t, mc, keep, n_img) in enumerate(cases):
+        data = [EO.synthetic_eval_case(ds, *HW, *hw, seed=500 + 10 * ci + k, log_transform=log_t) for k in range(n_img)]
+        loader = [({"sample": lo}, {"sample": hi}) for _, hi, lo in data]
+        thr = 0.0005 if ds == "durlar" else 0.03
+        with tempfile.TemporaryDirectory() as tmp:
+            args = types.SimpleNamespace(img_size_low_res=hw, img_size_high_res=HW, grid_size=0.1, log_transform=log_t,
+                                         dataset_select=ds, output_dir=tmp, save_pcd=False, keep_close_scan=keep,
+                                         num_mcdropout_iterations=12, noise_threshold=thr)
+            model = Model([p for p, _, _ in data], mc_sigma=0.01)
+            recorded.clear()
+            if mc:
+                E.MCdrop(loader, model, "cpu", Writer(), args)
+                res = json.load(open(os.path.join(tmp, "results_mcdrop.txt")))
+            else:
+                E.evaluate(loader, model, "cpu", Writer(), args)
+                res = json.load(open(os.path.join(tmp, "results.txt")))
+        for k in ("mae", "chamfer_dist", "iou", "precision", "recall", "f1"):
+            out[f"{name}_{k}"] = np.array(res[k], dtype=np.float64)
+        # ---- oracle vs reference, image by image
+        el = out["durlar_elevation_lut"]
+        for k, (pred, hi, lo) in enumerate(data):
+            if mc:
+                stack = []
+                for c in range(12):
+                    g = torch.Generator().manual_seed(9000 + c)
+                    stack.append(pred[0] + 0.01 * torch.randn(pred.shape[1:], generator=g) *
+                                 (torch.rand(pred.shape[1:], generator=g) < 0.3))
+                pred_in = EO.mc_aggregate(torch.stack(stack), thr)
+            else:
+                pred_in = pred
+            mae, mae_low, p_img, t_img = EO.postprocess(pred_in, hi, lo, ds, log_t, mc_drop=mc, keep_close_scan=keep)
+            (rp_img, rp_pcd), (rt_img, rt_pcd) = recorded[2 * k], recorded[2 * k + 1]
+            assert np.array_equal(p_img, rp_img) and np.array_equal(t_img, rt_img), name
+            if ds == "kitti":
+                op, ot = (EO.spherical_pcd(im, EO.kitti_tables(), 80) for im in (p_img, t_img))
+            elif ds == "carla":
+                op, ot = (EO.spherical_pcd(im, EO.carla_tables(*HW), 80) for im in (p_img, t_img))
+            else:
+                op, ot = (EO.durlar_pcd(im, el, 120) for im in (p_img, t_img))
+            assert op.dtype == rp_pcd.dtype and np.array_equal(op, rp_pcd) and np.array_equal(ot, rt_pcd), name
+            iou, prec, rec, f1, dims = EO.voxel_metrics(op, ot, 0.1)
+            assert abs(mae - res["mae"][k]) <= 1e-7 * max(1.0, abs(mae)), (name, mae, res["mae"][k])
+            if "iou" in res and len(res["iou"]) > k:
+                assert (iou, prec, rec, f1) == (res["iou"][k], res["precision"][k], res["recall"][k], res["f1"][k]), name
+            cd = EO.chamfer_sq(ot, op)
+            assert abs(cd - res["chamfer_dist"][k]) <= 1e-6 * cd, (name, cd, res["chamfer_dist"][k])
+            out[f"{name}_{k}_pcd_pred_sample"] = rp_pcd[::97].copy()
+            out[f"{name}_{k}_pcd_gt_sample"] = rt_pcd[::97].copy()
+            out[f"{name}_{k}_voxel"] = np.array([iou, prec, rec, f1], dtype=np.float64)
+            out[f"{name}_{k}_dims"] = np.array(dims)
+            out[f"{name}_{k}_mae_low"] = np.float64(mae_low)
+            print(f"  {name}[{k}] mae={mae:.6f} cd={cd:.6f} iou={iou:.4f} p={prec:.4f} r={rec:.4f} dims={dims}")
+        out[f"{name}_meta"] = np.array([ci, *HW, *hw, int(log_t), int(mc), int(keep), n_img])
+    out["cases"] = np.array([c[0] for c in cases])
+    out["case_dataset"] = np.array([c[1] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "g10_eval.npz"), **out)
+    print("eval fixtures written")
+
+
 if __name__ == "__main__":
-    if "--transforms-only" in sys.argv:
+    if "--eval-only" in sys.argv:
+        golden_eval()
+    elif "--transforms-only" in sys.argv:
         golden_transforms()
     elif "--loop-only" in sys.argv:
         golden_train_loop(import_reference())
