@@ -194,6 +194,55 @@ int tulip_range_prep(const void* raw, int raw_dtype, int64_t batch_stride, int64
                      int row_phase, int col_phase, float scale, int gate, float min_range, float max_range,
                      int log_transform, int roll_shift, hipStream_t stream);
 
+/* ---- evaluation post-processing and 3-D metrics (engine_upsampling.py:126-355,361-608; util/evaluation.py) ---- */
+
+/* MC-dropout aggregate (engine_upsampling.py:421-426): preds (passes, n) -> out (n):
+ * mean over the passes, zeroed where the unbiased std exceeds noise_threshold*mean. */
+int tulip_mc_aggregate(const float* preds, int passes, int64_t n, float noise_threshold, float* out,
+                       hipStream_t stream);
+
+/* One image (engine_upsampling.py:176-251): pred/hi (H,W), lo (h,w) in the model's value space.
+ * expm1 of all three when log_transform (:178-181); pred = (gate_min<=pred<=gate_max) ? pred : 0 (:183-190);
+ * mae_out[0] = mean|pred-hi| (:192-193); when w==W: mae_out[1] = mean over rows 0::H/h of |pred-lo| (:226-228) and
+ * those rows of pred are replaced by lo (:230), else mae_out[1] = 0 (:208-209); keep_close>0 zeroes pixels of both
+ * images above it (:247-249).  pred_img/hi_img (H,W): the images the point clouds are made from.
+ * partials: scratch of 2*1024 doubles. */
+int tulip_eval_postprocess(const float* pred, const float* hi, const float* lo, float* pred_img, float* hi_img,
+                           double* partials, float* mae_out, int H, int W, int h, int w, int log_transform,
+                           float gate_min, float gate_max, float keep_close, hipStream_t stream);
+
+/* Range image -> (H*W,3) float32 points, row-major pixel order (evaluation.py img_to_pcd_kitti :52-87 and
+ * img_to_pcd_carla :90-116): r = img*max_range; x = (sin_h[j]*cos_v[i])*r; y = (cos_h[j]*cos_v[i])*r;
+ * z = sin_v[i]*r, float32 products in that order (bit exact against numpy given the same tables). */
+int tulip_range_to_xyz(const float* img, const float* sin_h, const float* cos_h, const float* sin_v,
+                       const float* cos_v, float max_range, int H, int W, float* xyz, hipStream_t stream);
+
+/* DurLAR / OS1-128 (evaluation.py img_to_pcd_durlar :21-50) -> (H*W,3) float64 points:
+ * t = float32(img*max_range) - origin_offset (float32); col_tables = [cos(enc+az) | sin(enc+az) | o*cos(enc) |
+ * o*sin(enc)] (4*W), row_tables = [cos(el) | sin(el)] (2*H); x = -((t*c0[u])*cos_el[v] + c2[u]),
+ * y = -((t*c1[u])*cos_el[v] + c3[u]), z = t*sin_el[v] + z_offset, unfused float64; pixel (v,u) is written at
+ * index v*W + (u + W - row_offset[v]) % W (idx_from_px :21-24). */
+int tulip_range_to_xyz_durlar(const float* img, const double* col_tables, const double* row_tables,
+                              const int32_t* row_offset, float max_range, float origin_offset, double z_offset, int H,
+                              int W, double* xyz, hipStream_t stream);
+
+/* Voxel IoU / precision / recall / F1 of two clouds (engine_upsampling.py:254-271; evaluation.py
+ * voxelize_point_cloud :148-160, calculate_metrics :162-175).  Points (n,3) float32 (is_f64=0) or float64; voxel
+ * of p = ((p - min)/grid_size).astype(int) with min/max over BOTH clouds, evaluated in the clouds' own type.
+ * The two occupancy grids are bitmaps of bitmap_words 32-bit words each, all zero on entry and on exit (cleared
+ * again point by point); out = {iou, precision, recall, f1, dims0, dims1, dims2, status}; status 1 (metrics NaN)
+ * when dims0*dims1*dims2 exceeds 32*bitmap_words.  scratch: 6*1024+16 doubles, zero before first use. */
+int tulip_voxel_metrics(const void* pcd_pred, int64_t n_pred, const void* pcd_gt, int64_t n_gt, int is_f64,
+                        double grid_size, uint32_t* bitmap_pred, uint32_t* bitmap_gt, int64_t bitmap_words,
+                        double* scratch, double* out, hipStream_t stream);
+
+/* Chamfer distance as the reference reduces it (evaluation.py:125-135): out[0] = mean(dist_a) + mean(dist_b),
+ * dist_a[i] = min_j |a_i - b_j|^2 and dist_b[j] = min_i |b_j - a_i|^2 in float32 (float64 clouds are cast), the
+ * semantics of the ChamferDistance CUDA extension the reference imports (not vendored there).
+ * scratch: 2*1024 doubles. */
+int tulip_chamfer_sq(const void* a, int64_t na, const void* b, int64_t nb, int is_f64, float* dist_a, float* dist_b,
+                     double* scratch, double* out, hipStream_t stream);
+
 /* library self-description */
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);

@@ -7,12 +7,12 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtulip_hip.so")
 
-P, I, F, L = c_void_p, c_int, c_float, c_int64
+P, I, F, L, D = c_void_p, c_int, c_float, c_int64, c_double
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -44,6 +44,12 @@ SIGNATURES = {
     "tulip_adamw": [P, P, P, P, P, L, P, P, I, P],
     "tulip_grad_norm": [P, L, P, P, F, P, P],
     "tulip_range_prep": [P, I, L, L, L, L, P, P, I, I, I, I, I, I, I, F, I, F, F, I, I, P],
+    "tulip_mc_aggregate": [P, I, L, F, P, P],
+    "tulip_eval_postprocess": [P, P, P, P, P, P, P, I, I, I, I, I, F, F, F, P],
+    "tulip_range_to_xyz": [P, P, P, P, P, F, I, I, P, P],
+    "tulip_range_to_xyz_durlar": [P, P, P, P, F, F, D, I, I, P, P],
+    "tulip_voxel_metrics": [P, L, P, L, I, D, P, P, L, P, P, P],
+    "tulip_chamfer_sq": [P, L, P, L, I, P, P, P, P, P],
     "tulip_abi_version": [],
     "tulip_build_arch": [],
 }

@@ -183,3 +183,39 @@ def range_prep(raw, raw_dtype, batch_stride, row_stride, col_stride, base_offset
                                        _p(lo), B, H, W, row_factor, col_factor, row_phase, col_phase, float(scale),
                                        int(gate), float(min_range), float(max_range), int(log_transform),
                                        int(roll_shift), _stream()), "tulip_range_prep")
+
+
+# ---- evaluation post-processing / metrics (csrc/evalpost.hip)
+def mc_aggregate(preds, passes, n, noise_threshold, out):
+    check(_lib.load().tulip_mc_aggregate(_p(preds), passes, n, float(noise_threshold), _p(out), _stream()),
+          "tulip_mc_aggregate")
+
+
+def eval_postprocess(pred, hi, lo, pred_img, hi_img, partials, mae_out, H, W, h, w, log_transform, gate_min, gate_max,
+                     keep_close):
+    check(_lib.load().tulip_eval_postprocess(_p(pred), _p(hi), _p(lo), _p(pred_img), _p(hi_img), _p(partials),
+                                             _p(mae_out), H, W, h, w, int(log_transform), float(gate_min),
+                                             float(gate_max), float(keep_close), _stream()), "tulip_eval_postprocess")
+
+
+def range_to_xyz(img, sin_h, cos_h, sin_v, cos_v, max_range, H, W, xyz):
+    check(_lib.load().tulip_range_to_xyz(_p(img), _p(sin_h), _p(cos_h), _p(sin_v), _p(cos_v), float(max_range), H, W,
+                                         _p(xyz), _stream()), "tulip_range_to_xyz")
+
+
+def range_to_xyz_durlar(img, col_tables, row_tables, row_offset, max_range, origin_offset, z_offset, H, W, xyz):
+    check(_lib.load().tulip_range_to_xyz_durlar(_p(img), _p(col_tables), _p(row_tables), _p(row_offset),
+                                                float(max_range), float(origin_offset), float(z_offset), H, W,
+                                                _p(xyz), _stream()), "tulip_range_to_xyz_durlar")
+
+
+def voxel_metrics(pcd_pred, n_pred, pcd_gt, n_gt, is_f64, grid_size, bitmap_pred, bitmap_gt, bitmap_words, scratch,
+                  out):
+    check(_lib.load().tulip_voxel_metrics(_p(pcd_pred), n_pred, _p(pcd_gt), n_gt, int(is_f64), float(grid_size),
+                                          _p(bitmap_pred), _p(bitmap_gt), bitmap_words, _p(scratch), _p(out),
+                                          _stream()), "tulip_voxel_metrics")
+
+
+def chamfer_sq(a, na, b, nb, is_f64, dist_a, dist_b, scratch, out):
+    check(_lib.load().tulip_chamfer_sq(_p(a), na, _p(b), nb, int(is_f64), _p(dist_a), _p(dist_b), _p(scratch),
+                                       _p(out), _stream()), "tulip_chamfer_sq")
