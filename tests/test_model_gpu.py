@@ -319,3 +319,27 @@ def test_non_finite_loss_aborts_like_reference():
     with pytest.raises(SystemExit) as e:
         train_one_epoch(tr, [(lo, hi)], 0, args)
     assert e.value.code == 1
+
+
+def test_graphed_inference_matches_module_forward():
+    """HIP-graph replay of the eval forward == module forward (mc_drop=True), bit for bit, also after
+    the weights change under it."""
+    from tulip_amd.infer import GraphedForward
+    cfg = O.tiny_config(drop_path_rate=0.1)
+    sd = O.key_seeded_state_dict(cfg, seed=2)
+    m = build(cfg, sd, train=False)
+    lo, hi = O.synthetic_batch(cfg, 8, seed=9)
+    gf = GraphedForward(m, 8)
+    with torch.no_grad():
+        ref = m(lo.to(DEV), hi.to(DEV), mc_drop=True)
+    for _ in range(2):
+        assert torch.equal(gf(lo.to(DEV)), ref)
+    # tiled input of MCdrop (engine_upsampling.py:414): all 8 predictions identical
+    out = gf(lo[:1].tile(8, 1, 1, 1).to(DEV))
+    assert all(torch.equal(out[0], out[i]) for i in range(1, 8))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+        ref2 = m(lo.to(DEV), hi.to(DEV), mc_drop=True)
+    gf.weights_changed()
+    assert torch.equal(gf(lo.to(DEV)), ref2) and not torch.equal(ref, ref2)

@@ -1,0 +1,57 @@
+"""Batched inference: the eval / MC-dropout forward of TULIP.forward (tulip.py:702-735) captured
+once as a HIP graph and replayed.  `MCdrop` (engine_upsampling.py:411-419) tiles one input 8 times, so with every
+dropout probability at 0 (tulip.py:741-743) its forward is a deterministic B=8 batch: this is that launch sequence
+with the Python/launch overhead removed.  The graph reads `x` and writes `pred` in place."""
+from __future__ import annotations
+
+import torch
+
+
+class GraphedForward:
+    def __init__(self, model, batch_size: int, device=None):
+        self.model = model
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.eng = model.engine()
+        self.eng.bind(self.device)
+        self.P = self.eng.plan(batch_size)
+        self.B = batch_size
+        self._graph = None
+        self._side = torch.cuda.Stream(device=self.device)
+
+    @property
+    def x(self) -> torch.Tensor:            # static input  (B, C, h, w)
+        return self.P.x_in
+
+    @property
+    def pred(self) -> torch.Tensor:         # static output (B, 1, H, W)
+        return self.P.pred
+
+    def weights_changed(self):
+        """Call after modifying parameters in place (a foreign optimizer, load_state_dict): the bf16 shadow the
+        GEMMs read is re-derived from the fp32 parameters before the next replay."""
+        self.eng.params.shadow_dirty = True
+
+    def _forward(self):
+        self.eng.draw_drop_scales(self.P, False)          # eval: DropPath is the identity (tulip.py:25-27)
+        self.eng.run_forward(self.P, with_loss=False)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor = None) -> torch.Tensor:
+        """Returns the static output buffer (valid until the next call)."""
+        if x is not None:
+            self.P.x_in.copy_(x.reshape(self.P.x_in.shape), non_blocking=True)
+        if self.eng.params.shadow_dirty:
+            self.eng.params.refresh_shadow()              # outside the graph: weights changed since capture
+        if self._graph is None:
+            self._forward()                               # load kernels / size lazy buffers outside capture
+            torch.cuda.synchronize()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin()
+                self._forward()
+                g.capture_end()
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._graph = g
+        self._graph.replay()
+        return self.P.pred
