@@ -72,6 +72,67 @@ __global__ __launch_bounds__(256) void range_prep_kernel(const T* __restrict__ r
     }
 }
 
+// Row-major float32 sources (plain (B,H,W) or the interleaved (B,H,W,2) .npy payload): no transpose needed, so
+// each thread takes 4 consecutive pixels of one row: 16-byte loads, 16-byte stores when the roll keeps alignment.
+template <int SJ>
+__global__ __launch_bounds__(256) void range_prep_rows_kernel(const float* __restrict__ raw, PrepArgs a) {
+    const int W4 = a.W >> 2;
+    const int64_t n4 = (int64_t)a.H * W4;
+    const int b = blockIdx.y;
+    const int Hl = a.H / a.f, Wl = a.W / a.fw;
+    const float* src = raw + (int64_t)b * a.sb;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (int64_t)gridDim.x * 256) {
+        const int i = (int)(k / W4), j = (int)(k - (int64_t)i * W4) * 4;
+        const bool lo_row = a.lo && i >= a.rp && (i - a.rp) % a.f == 0;
+        if (!a.hi && !lo_row) continue;
+        float v[4];
+        const float* p = src + (int64_t)i * a.si + (int64_t)j * SJ;
+        if (SJ == 1) {
+            const float4 q = *(const float4*)p;
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            const float4 q0 = *(const float4*)p, q1 = *(const float4*)(p + 4);
+            v[0] = q0.x; v[1] = q0.z; v[2] = q1.x; v[3] = q1.z;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = v[c] * a.scale;
+            if (a.gate) x = (x >= a.gmin && x <= a.gmax) ? x : 0.f;
+            if (a.logt) x = log1pf(x);
+            v[c] = x;
+        }
+        if (a.hi) {
+            float* dst = a.hi + ((int64_t)b * a.H + i) * a.W;
+            int jo = j + a.shift_hi;
+            if (jo >= a.W) jo -= a.W;
+            if ((a.shift_hi & 3) == 0) {
+                *(float4*)(dst + jo) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { dst[jo] = v[c]; if (++jo == a.W) jo = 0; }
+            }
+        }
+        if (lo_row) {
+            float* dst = a.lo + ((int64_t)b * Hl + (i - a.rp) / a.f) * Wl;
+            if (a.fw == 1 && (a.shift_lo & 3) == 0) {
+                int jl = j + a.shift_lo;
+                if (jl >= Wl) jl -= Wl;
+                *(float4*)(dst + jl) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int jj = j + c;
+                    if (jj >= a.cp && (jj - a.cp) % a.fw == 0) {
+                        int jl = (jj - a.cp) / a.fw + a.shift_lo;
+                        if (jl >= Wl) jl -= Wl;
+                        dst[jl] = v[c];
+                    }
+                }
+            }
+        }
+    }
+}
+
 inline int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
 
 }  // namespace
@@ -94,6 +155,20 @@ extern "C" int tulip_range_prep(const void* raw, int raw_dtype, int64_t batch_st
     a.shift_hi = ((roll_shift % W) + W) % W;
     a.shift_lo = ((roll_shift % Wl) + Wl) % Wl;
     a.along_i = iabs64(row_stride) < iabs64(col_stride);
+    const bool rows16 = raw_dtype == 0 && (W & 3) == 0 && base_offset == 0 && (col_stride == 1 || col_stride == 2) &&
+                        row_stride == (int64_t)W * col_stride && (batch_stride & 3) == 0 &&
+                        ((uintptr_t)raw & 15) == 0 && (!hi || ((uintptr_t)hi & 15) == 0) && (!lo || ((uintptr_t)lo & 15) == 0) &&
+                        (Wl & 3) == 0;
+    if (rows16) {
+        int64_t nb = ((int64_t)H * (W / 4) + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        if (col_stride == 1)
+            hipLaunchKernelGGL(range_prep_rows_kernel<1>, dim3((int)nb, B), dim3(256), 0, stream, (const float*)raw, a);
+        else
+            hipLaunchKernelGGL(range_prep_rows_kernel<2>, dim3((int)nb, B), dim3(256), 0, stream, (const float*)raw, a);
+        TULIP_CHECK_LAUNCH();
+        return TULIP_OK;
+    }
     const dim3 grid((W + TJ - 1) / TJ, (H + TI - 1) / TI, B);
     if (raw_dtype == 0)
         hipLaunchKernelGGL(range_prep_kernel<float>, grid, dim3(256), 0, stream, (const float*)raw, a);
