@@ -427,8 +427,9 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
     const bool small = ((p.M + 127) / 128) * gn * splits < big_tiles;
     if (small || p.M <= 64) {
         dim3 grid(gn, (p.M + 63) / 64, splits);
-        // 1 workgroup/CU (deep stages, 80-150 KB LDS) only pays when the grid cannot fill the chip anyway
-        if ((int)(grid.x * grid.y * grid.z) <= 192 && p.kchunk >= 256)
+        // 128-deep k stages (80-150 KB LDS, 1-2 workgroups/CU) pay while the grid is at most ~1.5 waves of the chip
+        static const int ksub_grid = getenv("TULIP_GEMM_KSUB_GRID") ? atoi(getenv("TULIP_GEMM_KSUB_GRID")) : 400;
+        if ((int)(grid.x * grid.y * grid.z) <= ksub_grid && p.kchunk >= 256)
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 4>), grid, dim3(256), 0, stream, p);
         else
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
