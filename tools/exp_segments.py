@@ -1,0 +1,20 @@
+"""dev experiment: step time when the step graph is cut into segments at the DDP bucket points (as with
+world_size > 1) but without any collective: isolates the cost of segmentation + side-stream joins."""
+import sys, os, argparse, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from tulip_amd.trainer import Trainer
+args = argparse.Namespace(model="tulip_base", img=[16, 1024], target=[64, 1024], batch=8)
+dev = torch.device("cuda", 0)
+for fake in (1, 2):
+    model = bench.make_model(args).to(dev).train()
+    tr = Trainer(model, 8, device=dev)
+    tr.world = fake
+    tr.bucketer.on_group_done = lambda *a: None
+    tr.bucketer.wait_all = lambda: None
+    lo, hi = bench.synthetic(args, 0, dev); tr.load_batch(lo, hi)
+    for _ in range(10): tr.step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100): tr.step()
+    torch.cuda.synchronize()
+    print(f"fake world {fake}: segments {len(tr._segments[True])} step {(time.perf_counter() - t0) * 10:.3f} ms")
