@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_FWD_BWD_PER_IMG = 46.349e9      # tulip_base KITTI, 2*MAC, matmul/conv only
+BYTES_FWD_OPLEVEL_PER_IMG = 245e6    # op-level forward traffic per image, bf16
 PEAK_BF16 = 2.5e15                   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 
@@ -57,7 +58,7 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
     gn = -(-N // 96)
     if -(-M // 128) * gn * eff < int(os.environ.get("TULIP_GEMM_BIG_TILES", 2048)) or M <= 64:
         grid = gn * -(-M // 64) * eff
-        ksub = 4 if (grid <= 192 and kchunk >= 256) else 1
+        ksub = 4 if (grid <= int(os.environ.get("TULIP_GEMM_KSUB_GRID", 400)) and kchunk >= 256) else 1
         bm = 64
     else:
         bm, ksub = 128, 1
@@ -252,6 +253,9 @@ def main():
                       "hip_graph": not args.no_graph},
            "final_loss": round(loss_val, 6),
            "step_mfma_frac": round(value * FLOP_FWD_BWD_PER_IMG / world / PEAK_BF16, 5)
+           if args.model == "tulip_base" and tuple(args.img) == (16, 1024) else None,
+           # SURVEY.md 8(d) op-level convention: 3 x 245 MB per image (forward op traffic x3 for training)
+           "step_hbm_frac_oplevel": round(value * 3 * BYTES_FWD_OPLEVEL_PER_IMG / world / PEAK_HBM, 5)
            if args.model == "tulip_base" and tuple(args.img) == (16, 1024) else None}
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = gemm_roofline(trainer)

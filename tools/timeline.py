@@ -4,7 +4,8 @@ import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 print("columns:", cols)
-sc = "stream_id" if "stream_id" in cols else ("stream" if "stream" in cols else ("queue_id" if "queue_id" in cols else "queue"))
+import os
+sc = os.environ.get("TL_COL", "queue_id")
 rows = cur.execute(f"select name, start, end, {sc} from kernels order by start").fetchall()
 # a step ends with adamw_kernel: take the kernels between the last two adamw launches
 ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
@@ -28,11 +29,10 @@ for sid, rs in sorted(streams.items(), key=lambda kv: -len(kv[1])):
     print(f" stream {sid}: {len(rs)} kernels, busy {busy / 1e3:.1f} us, span {span / 1e3:.1f} us, first at +{(rs[0][1] - t0) / 1e3:.1f}, "
           f"last end +{(max(r[2] for r in rs) - t0) / 1e3:.1f}, median gap {gaps[len(gaps) // 2] if gaps else 0:.2f} us, "
           f"sum gaps {sum(g for g in gaps if g > 0):.1f} us, top gaps {[round(g, 1) for g in gaps[:6]]}")
-main = max(streams.values(), key=len)
 if len(sys.argv) > 2:
-    for r in main:
+    for r in step:
         n = re.sub(r"\(anonymous namespace\)::|^void ", "", r[0])[:60]
-        print(f"  +{(r[1] - t0) / 1e3:8.1f} {(r[2] - r[1]) / 1e3:7.1f} {n}")
+        print(f"  q{r[3]} +{(r[1] - t0) / 1e3:8.1f} {(r[2] - r[1]) / 1e3:7.1f} {n}")
 # gap positions of the last few steps
 for k in range(2, min(6, len(ad))):
     st = rows[ad[-k] + 1: ad[-k + 1] + 1]
