@@ -172,6 +172,13 @@ int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscal
 int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
                 const uint8_t* decay_mask64, int zero_grad, hipStream_t stream);
 
+/* DropPath multipliers of one step (tulip.py:25-29; timm drop_path: keep a sample's residual branch with
+ * probability keep, scale kept branches by 1/keep): scale[slot*B+b] = floor(keep[slot] + u)/keep[slot] with
+ * u ~ U[0,1) from a counter-based generator keyed by (seed, *counter, index).  *counter is advanced by one:
+ * replaying the launch from a HIP graph draws fresh numbers every step.  u_out (optional) receives the draws. */
+int tulip_drop_path_scales(const float* keep, float* scale, float* u_out, int nslots, int B, uint64_t seed,
+                           uint64_t* counter, hipStream_t stream);
+
 /* Gradient L2 norm read-out (misc.py:317-329 get_grad_norm_, taken before the optimizer step, misc.py:303):
  * out[0] = sqrt(sum g[i]^2) * scale * (scale_dev ? scale_dev[0] : 1).  partials: scratch of 1024 doubles.
  * Fixed partition and fold order: deterministic. */

@@ -509,3 +509,36 @@ def test_grad_norm(ops, n):
     first = out.clone()
     ops.grad_norm(g, n, part, out, scale_dev=scale)
     assert torch.equal(first, out)
+
+
+def test_drop_path_scales_kernel(ops):
+    """tulip.py:25-29 / timm drop_path: scale in {0, 1/keep}, P(keep) = keep, fresh draws per launch (device
+    counter), reproducible for a given (seed, counter), u uniform in [0,1)."""
+    nslots, B = 28, 8
+    keep = torch.linspace(1.0, 0.9, nslots, device=DEV).reshape(nslots, 1).contiguous()
+    scale = torch.empty(nslots, B, device=DEV)
+    u = torch.empty(nslots, B, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    draws, scales = [], []
+    for _ in range(400):
+        ops.drop_path_scales(keep, scale, u, nslots, B, 1234, ctr)
+        draws.append(u.clone()); scales.append(scale.clone())
+    assert ctr.item() == 400
+    U, S = torch.stack(draws), torch.stack(scales)
+    assert (U >= 0).all() and (U < 1).all()
+    assert abs(U.mean().item() - 0.5) < 0.01 and abs(U.var().item() - 1 / 12) < 0.005
+    assert torch.equal(S, torch.floor(keep + U) / keep)                     # the reference formula, bit for bit
+    kept = (S > 0).float().mean(dim=(0, 2))                                  # per slot
+    assert (kept - keep[:, 0]).abs().max().item() < 0.02
+    assert not torch.equal(draws[0], draws[1])
+    # same seed + counter -> same draws; another seed -> different
+    ctr.zero_()
+    ops.drop_path_scales(keep, scale, u, nslots, B, 1234, ctr)
+    assert torch.equal(u, draws[0])
+    ctr.zero_()
+    ops.drop_path_scales(keep, scale, u, nslots, B, 99, ctr)
+    assert not torch.equal(u, draws[0])
+    # lag-1 and cross-slot correlations of the stream are negligible
+    flat = U.reshape(400, -1)
+    c = torch.corrcoef(torch.stack([flat[:-1].reshape(-1), flat[1:].reshape(-1)]))[0, 1].abs().item()
+    assert c < 0.02

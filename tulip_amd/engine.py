@@ -331,6 +331,8 @@ class TulipEngine:
             if sp.slot >= 0:
                 rates[sp.slot] = rates[sp.slot + 1] = 1.0 - sp.rate
         self._keep = rates.to(device)
+        self._drop_seed = torch.initial_seed()      # torch.manual_seed() governs the DropPath stream
+        self._drop_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
     def plan(self, B: int) -> Plan:
         if B not in self.plans:
@@ -353,10 +355,12 @@ class TulipEngine:
         if not train or self.n_drop_slots == 0:
             P.drop_scale.fill_(1.0)
             return
-        if drop_u is not None:
-            P.drop_u.copy_(drop_u)
-        else:
-            P.drop_u.uniform_()
+        if drop_u is None:
+            # one launch; the step counter lives on the device, so a graph replay draws fresh numbers
+            ops.drop_path_scales(self._keep, P.drop_scale, P.drop_u, self.n_drop_slots, P.B, self._drop_seed,
+                                 self._drop_counter)
+            return
+        P.drop_u.copy_(drop_u)                     # injected draws (parity tests against the oracle)
         torch.floor(self._keep + P.drop_u, out=P.drop_scale)
         P.drop_scale.div_(self._keep)
 

@@ -219,3 +219,8 @@ def voxel_metrics(pcd_pred, n_pred, pcd_gt, n_gt, is_f64, grid_size, bitmap_pred
 def chamfer_sq(a, na, b, nb, is_f64, dist_a, dist_b, scratch, out):
     check(_lib.load().tulip_chamfer_sq(_p(a), na, _p(b), nb, int(is_f64), _p(dist_a), _p(dist_b), _p(scratch),
                                        _p(out), _stream()), "tulip_chamfer_sq")
+
+
+def drop_path_scales(keep, scale, u_out, nslots, B, seed, counter):
+    check(_lib.load().tulip_drop_path_scales(_p(keep), _p(scale), _p(u_out), nslots, B, int(seed) & (2 ** 64 - 1),
+                                             _p(counter), _stream()), "tulip_drop_path_scales")
