@@ -117,6 +117,9 @@ def gemm_roofline(trainer, reps=5):
     return {"bound": "mfma", "kernel": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv: fwd + dgrad + wgrad)",
             "achieved": round(tot_f / tot_t / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
             "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": _pmc_traffic(), "launches_per_step": len(calls),
+            # the same launches against the other roof: PMC HBM bytes per launch / mean launch time / 8 TB/s
+            "hbm_frac_of_traffic": (round(_pmc_traffic() / (tot_t / len(calls)) / PEAK_HBM, 4)
+                                    if _pmc_traffic() else None),
             "flops_per_launch": tot_f / len(calls), "operand_bytes_per_launch": round(alg_bytes / len(calls)),
             "mean_launch_us": round(tot_t / len(calls) * 1e6, 2),
             "gemm_ms_per_step": round(tot_t * 1e3, 3), "flops_per_step": tot_f, "by_kernel": detail}

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): regenerates everything profiles/ cites.
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/kt.log 2>&1
+python tools/kstats.py $(find $O/kt -name "*.db" | head -1) 26 > $O/kernel_stats.txt
+python tools/timeline.py $(find $O/kt -name "*.db" | head -1) > $O/timeline_summary.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_w.log 2>&1
+python tools/pmc_summary.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) $O/pmc_gemm_traffic.json > $O/pmc_hbm_traffic.txt
+python tools/bench_eval.py > $O/eval_bench.json 2>/dev/null
+rm -rf $O/kt $O/pmc_f $O/pmc_w
+ls -la $O
