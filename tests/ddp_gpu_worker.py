@@ -1,0 +1,44 @@
+"""Worker of tests/test_ddp_gpu.py: one rank of a 2-process data-parallel run that shares ONE GPU.
+RCCL refuses two ranks on the same device, so the collective goes through gloo (which accepts device tensors);
+everything else -- graph segments cut at the bucket points, side-stream joins, 1/world folded into AdamW -- is the
+code the 8-GPU run uses."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, use_graph, steps = sys.argv[1], sys.argv[2] == "1", int(sys.argv[3])
+    from oracle import tulip_oracle as O
+    from tests.test_model_gpu import build
+    from tulip_amd.trainer import Trainer
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = O.tiny_config(drop_path_rate=0.0)
+    sd = O.key_seeded_state_dict(cfg, seed=3)
+    lo, hi = O.synthetic_batch(cfg, 2 * world, seed=77)
+    m = build(cfg, sd, train=True)
+    tr = Trainer(m, 2, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph, bucket_mb=0.05)
+    assert tr.world == world and len(tr.bucketer.buckets) >= 2
+    tr.load_batch(lo[2 * rank:2 * rank + 2].cuda(), hi[2 * rank:2 * rank + 2].cuda())
+    losses = [tr.step().clone() for _ in range(steps)]
+    torch.cuda.synchronize()
+    flat = tr.eng.params.flat.clone()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({"flat": flat.cpu(), "same_on_all_ranks": all(torch.equal(gathered[0], g) for g in gathered),
+                    "losses": torch.stack(losses).cpu(), "segments": len(tr._segments[True]) if use_graph else 0,
+                    "buckets": tr.bucketer.buckets}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

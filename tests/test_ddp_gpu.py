@@ -1,0 +1,58 @@
+"""SURVEY 8(e) on the GPU box: the N>1 training path (graph segments cut at the DDP bucket points, bucketed
+all-reduce of the flat gradient buffer between segment replays, side-stream joins, mean folded into AdamW) run as
+two ranks sharing the one GPU over gloo, against a single-process run on the concatenated batch.
+DDP semantics: mean of the two ranks' gradients = gradient of the mean loss over the 4 images."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import tulip_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph):
+    from tests.test_model_gpu import build
+    from tulip_amd.trainer import Trainer
+    steps = 3
+    out = tmp_path / "r0.pt"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), str(out),
+           "1" if use_graph else "0", str(steps)]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    assert got["same_on_all_ranks"]                              # replicas stay bit-identical
+    if use_graph:
+        assert got["segments"] == len(got["buckets"]) + 1        # one segment per bucket + the AdamW segment
+    cfg = O.tiny_config(drop_path_rate=0.0)
+    sd = O.key_seeded_state_dict(cfg, seed=3)
+    lo, hi = O.synthetic_batch(cfg, 4, seed=77)
+    m = build(cfg, sd, train=True)
+    tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph)
+    tr.load_batch(lo.cuda(), hi.cuda())
+    losses = [tr.step().clone() for _ in range(steps)]
+    torch.cuda.synchronize()
+    ref = tr.eng.params.flat.cpu()
+    # rank 0 saw images 0-1: its loss differs from the full-batch loss, but the parameters must agree
+    d = (got["flat"] - ref).abs().max().item()
+    assert d <= 2e-5, d
+    init = Trainer(build(cfg, sd, train=True), 4, use_graph=False).eng.params.flat.cpu()
+    assert (ref - init).abs().max().item() > 1e-4                # ... and must actually have moved
+    full = torch.stack(losses).cpu()[:, 0]
+    assert abs(got["losses"][-1, 0].item() - full[-1].item()) < 0.2 * full[-1].item()

@@ -120,8 +120,13 @@ class Trainer:
                 cur.capture_end()
                 segs.append((cur, None))
             else:
+                # the last bucket closes with the backward's final hook ("embed"): the piece opened after it is
+                # empty and is not replayed
                 cur.capture_end()
-                segs.append((cur, None))
+                if not (segs and segs[-1][1] == self.bucketer.buckets[-1][0]):
+                    segs.append((cur, None))
+                else:
+                    self._empty_tail = cur          # keep the (empty) graph object alive
                 g2 = torch.cuda.CUDAGraph()
                 g2.capture_begin()
                 self._adamw()
