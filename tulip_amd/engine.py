@@ -331,6 +331,9 @@ class TulipEngine:
             if sp.slot >= 0:
                 rates[sp.slot] = rates[sp.slot + 1] = 1.0 - sp.rate
         self._keep = rates.to(device)
+        nearly = int(os.environ.get("TULIP_EARLY_FLUSH_BLOCKS", "1"))
+        # backward order ends with encoder stage 0, block 1 then block 0
+        self.early_flush = frozenset(sp.prefix for sp in self.enc_blocks[0][:nearly])
         self._drop_seed = torch.initial_seed()      # torch.manual_seed() governs the DropPath stream
         self._drop_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
@@ -487,6 +490,7 @@ class TulipEngine:
         ops.gemm(A, B, M, N, K, **kw)
 
     flush_per_block = True
+    early_flush = frozenset()   # block prefixes with a mid-block side flush (set in bind())
     # Side streams, used round-robin by Swin block.  Measured on MI355X / ROCm 7.2 (graph replay, B=8):
     # 1 stream 4.63 ms, 2: 4.46, 3: 4.82, 4: 4.05, 5: 4.63, 6: 4.33, 8: 4.05, 12: 4.08, 16: 4.05 -- the HIP graph
     # executor spreads the captured branches over 4 hardware queues, and branch counts that are not a multiple
@@ -517,13 +521,15 @@ class TulipEngine:
         else:
             fn()
 
-    def _flush_wgrads(self):
+    def _flush_wgrads(self, advance: bool = True):
+        """Issue the queued side work on the current side stream; advance: move on to the next stream afterwards."""
         if not self._pending:
             return
         main = torch.cuda.current_stream()
         k = self._side_rr % self.n_side
         st, ws = self._side_streams[k], self._ws_sides[k].data_ptr()
-        self._side_rr += 1
+        if advance:                         # advance=False: a mid-block flush, the block's remainder follows on
+            self._side_rr += 1              # the same stream
         st.wait_stream(main)
         with torch.cuda.stream(st):
             for fn in self._pending:
@@ -593,6 +599,10 @@ class TulipEngine:
         self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
                      G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2",
                      cast=(P[p + ".dyb_a"], self._ds(P, sp, 0), tok))
+        if sp.prefix in self.early_flush:
+            # the last blocks of the backward: nothing is left to hide their weight gradients behind, so the MLP
+            # half starts as soon as its operands exist instead of at the end of the block
+            self._flush_wgrads(advance=False)
         # ---- attention branch (tulip.py:339-344); its bf16 operand came out of the LayerNorm backward above
         dyb = P[p + ".dyb_a"]
         self._gemm(dyb, W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, b_trans=True, epi=EPI_BF16, out=dO,
