@@ -407,6 +407,98 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
     }
 }
 
+// ---- 16 lanes per token, 4 tokens per wave (E % 16 == 0, E <= 128, taps <= TAPS): lane `sub` owns the
+// CPL = E/16 consecutive channels sub*CPL .. +CPL-1, so a token's row is written as 16 contiguous pieces and the
+// LayerNorm reductions are 4-step group sums; four tokens advance through the dependent shuffle chains together.
+template <int CPL, int TAPS>
+__global__ __launch_bounds__(256) void patch_embed_bwd16_kernel(const float* __restrict__ img,
+                                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ dout, float* dw, float* db,
+                                                                float* dgamma, float* dbeta, EmbedGeom g, float eps,
+                                                                int pstride) {
+    // partial-row mode only (pstride > 0): row blockIdx.x of a [gridDim.x][pstride] buffer, folded by the caller
+    __shared__ float red[4][16 * CPL][TAPS + 3];           // [wave][channel][dw taps | db dgamma dbeta]
+    const int lane = threadIdx.x & 63, sub = lane & 15, slot = lane >> 4, wid = threadIdx.x >> 6;
+    const int group = (blockIdx.x * 4 + wid) * 4 + slot, ngroups = gridDim.x * 16;
+    const int ntok = g.B * g.Ho * g.Wo;
+    const float invE = 1.0f / (float)g.E;
+    float wr[CPL][TAPS], br[CPL], gar[CPL];
+    float aw[CPL][TAPS], ab[CPL], ag[CPL], abe[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = sub * CPL + k;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) { wr[k][t] = t < g.taps ? w[c * g.taps + t] : 0.f; aw[k][t] = 0.f; }
+        br[k] = bias[c]; gar[k] = gamma[c]; ab[k] = 0.f; ag[k] = 0.f; abe[k] = 0.f;
+    }
+    for (int tok = group; tok < ntok; tok += ngroups) {
+        const int wq = tok % g.Wo, t2 = tok / g.Wo;
+        const int h = t2 % g.Ho, b = t2 / g.Ho;
+        float xt[TAPS];
+        #pragma unroll
+        for (int t = 0; t < TAPS; ++t) xt[t] = (t < g.taps) ? embed_tap(img, g, b, h, wq, t) : 0.f;
+        const float* dyp = dout + (size_t)tok * g.E + sub * CPL;
+        float a[CPL], dy[CPL], s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            dy[k] = dyp[k];
+            a[k] = br[k];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) a[k] += wr[k][t] * xt[t];
+            s += a[k];
+        }
+        const float mu = group_sum<16>(s) * invE;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) { a[k] -= mu; q += a[k] * a[k]; }
+        const float rs = rsqrtf(group_sum<16>(q) * invE + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            a[k] *= rs;                                   // xhat
+            ag[k] += dy[k] * a[k]; abe[k] += dy[k];
+            dy[k] *= gar[k];                              // gy
+            s1 += dy[k]; s2 += dy[k] * a[k];
+        }
+        const float m1 = group_sum<16>(s1) * invE, m2 = group_sum<16>(s2) * invE;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const float dc = rs * (dy[k] - m1 - a[k] * m2);
+            ab[k] += dc;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) aw[k][t] += dc * xt[t];
+        }
+    }
+    // fold the wave's 4 token slots (lanes sub, sub+16, sub+32, sub+48), then the 4 waves through LDS
+    auto fold4 = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) aw[k][t] = fold4(aw[k][t]);
+        ab[k] = fold4(ab[k]); ag[k] = fold4(ag[k]); abe[k] = fold4(abe[k]);
+    }
+    if (slot == 0) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            float* r = red[wid][sub * CPL + k];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) r[t] = aw[k][t];
+            r[TAPS] = ab[k]; r[TAPS + 1] = ag[k]; r[TAPS + 2] = abe[k];
+        }
+    }
+    __syncthreads();
+    const size_t ro = (size_t)blockIdx.x * pstride;
+    for (int i = threadIdx.x; i < g.E * (TAPS + 3); i += 256) {
+        const int c = i / (TAPS + 3), v = i - c * (TAPS + 3);
+        const float acc = (red[0][c][v] + red[1][c][v]) + (red[2][c][v] + red[3][c][v]);
+        if (v < TAPS) { if (v < g.taps) dw[ro + c * g.taps + v] = acc; }
+        else if (v == TAPS) db[ro + c] = acc;
+        else if (v == TAPS + 1) dgamma[ro + c] = acc;
+        else dbeta[ro + c] = acc;
+    }
+}
+
 bool embed_geom(EmbedGeom& g, int B, int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular) {
     if (E <= 0 || E > 128 || p0 <= 0 || p1 <= 0 || Hin % p0 || Win % p1) return false;
     if (circular && kw != p1 + 4) return false;   // kernel (p0, 8) over a (2,2)-padded row with stride 4 (tulip.py:41,60)
@@ -517,6 +609,15 @@ extern "C" int tulip_patch_embed_bwd(const float* img, const float* w, const flo
     if (ntok <= 0) return TULIP_OK;
     if (partial_stride > 0 && g.taps > EMB_MAXT) return TULIP_ERR_ARG;
     const int grid = tulip_patch_embed_bwd_blocks(ntok);
+    if (partial_stride > 0 && g.taps <= EMB_MAXT && (E == 96 || E == 48)) {
+#define TULIP_PE_BWD(CPL, TAPS) hipLaunchKernelGGL((patch_embed_bwd16_kernel<CPL, TAPS>), dim3(grid), dim3(256), 0, stream, \
+                                                  img, w, b, gamma, dout, dw, db, dgamma, dbeta, g, eps, partial_stride)
+        if (g.taps <= 8) { if (E == 96) TULIP_PE_BWD(6, 8); else TULIP_PE_BWD(3, 8); }
+        else { if (E == 96) TULIP_PE_BWD(6, 16); else TULIP_PE_BWD(3, 16); }
+#undef TULIP_PE_BWD
+        TULIP_CHECK_LAUNCH();
+        return TULIP_OK;
+    }
     if (g.taps <= EMB_MAXT)
         hipLaunchKernelGGL(patch_embed_bwd_kernel<true>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, dout, dw,
                            db, dgamma, dbeta, g, eps, partial_stride);
