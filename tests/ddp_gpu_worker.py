@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, use_graph, steps = sys.argv[1], sys.argv[2] == "1", int(sys.argv[3])
+    accum = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     from oracle import tulip_oracle as O
     from tests.test_model_gpu import build
     from tulip_amd.trainer import Trainer
@@ -24,10 +25,11 @@ def main():
     sd = O.key_seeded_state_dict(cfg, seed=3)
     lo, hi = O.synthetic_batch(cfg, 2 * world, seed=77)
     m = build(cfg, sd, train=True)
-    tr = Trainer(m, 2, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph, bucket_mb=0.05)
+    tr = Trainer(m, 2, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph, bucket_mb=0.05,
+                 accum_iter=accum)
     assert tr.world == world and len(tr.bucketer.buckets) >= 2
     tr.load_batch(lo[2 * rank:2 * rank + 2].cuda(), hi[2 * rank:2 * rank + 2].cuda())
-    losses = [tr.step().clone() for _ in range(steps)]
+    losses = [tr.step().clone() for _ in range(steps * accum)]
     torch.cuda.synchronize()
     flat = tr.eng.params.flat.clone()
     gathered = [torch.empty_like(flat) for _ in range(world)]

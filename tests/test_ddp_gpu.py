@@ -24,15 +24,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph):
+@pytest.mark.parametrize("use_graph,accum", [(True, 1), (False, 1), (True, 2)])
+def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph, accum):
     from tests.test_model_gpu import build
     from tulip_amd.trainer import Trainer
     steps = 3
     out = tmp_path / "r0.pt"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), str(out),
-           "1" if use_graph else "0", str(steps)]
+           "1" if use_graph else "0", str(steps), str(accum)]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -44,9 +44,10 @@ def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph):
     sd = O.key_seeded_state_dict(cfg, seed=3)
     lo, hi = O.synthetic_batch(cfg, 4, seed=77)
     m = build(cfg, sd, train=True)
-    tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph)
+    tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph, accum_iter=accum)
     tr.load_batch(lo.cuda(), hi.cuda())
-    losses = [tr.step().clone() for _ in range(steps)]
+    losses = [tr.step().clone() for _ in range(steps * accum)]     # accum micro-steps per optimizer step
+    assert tr.t == steps
     torch.cuda.synchronize()
     ref = tr.eng.params.flat.cpu()
     # rank 0 saw images 0-1: its loss differs from the full-batch loss, but the parameter UPDATES must agree.
