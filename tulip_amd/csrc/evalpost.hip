@@ -154,13 +154,30 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const T* __restrict
                                                                  : fmax(fmax(r[0], r[1]), fmax(r[2], r[3]));
     }
 }
-__global__ __launch_bounds__(64) void minmax_final_kernel(const double* __restrict__ partials, int nb,
-                                                          double* __restrict__ out) {
-    const int c = threadIdx.x;
-    if (c >= 6) return;
-    double v = partials[c];
-    for (int i = 1; i < nb; ++i) v = c < 3 ? fmin(v, partials[i * 6 + c]) : fmax(v, partials[i * 6 + c]);
-    out[c] = v;
+__global__ __launch_bounds__(256) void minmax_final_kernel(const double* __restrict__ partials, int nb,
+                                                           double* __restrict__ out) {
+    __shared__ double red[6][4];
+    double v[6] = {1e300, 1e300, 1e300, -1e300, -1e300, -1e300};
+    for (int i = threadIdx.x; i < nb; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = fmin(v[c], partials[i * 6 + c]);
+            v[3 + c] = fmax(v[3 + c], partials[i * 6 + 3 + c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(v[c], o, 64);
+            v[c] = c < 3 ? fmin(v[c], w) : fmax(v[c], w);
+        }
+        if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double* r = red[threadIdx.x];
+        out[threadIdx.x] = threadIdx.x < 3 ? fmin(fmin(r[0], r[1]), fmin(r[2], r[3])) : fmax(fmax(r[0], r[1]), fmax(r[2], r[3]));
+    }
 }
 
 // voxel index of a point in the clouds' own arithmetic: ((p - min)/grid).astype(int); dims = ((max-min)/grid).astype(int)+1
@@ -379,7 +396,7 @@ int voxel_metrics_t(const void* pp, int64_t np_, const void* pg, int64_t ng, dou
     const int64_t cap = words * 32;
     const int nb = blocks_for(np_ + ng);
     hipLaunchKernelGGL(minmax_partial_kernel<T>, dim3(nb), dim3(256), 0, stream, a, np_, b, ng, partials);
-    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, stream, partials, nb, mm);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, stream, partials, nb, mm);
     hipLaunchKernelGGL((voxel_mark_kernel<T, false>), dim3(blocks_for(np_)), dim3(256), 0, stream, a, np_, mm, grid, bm_p,
                        (const uint32_t*)bm_g, cap, counters);
     hipLaunchKernelGGL((voxel_mark_kernel<T, true>), dim3(blocks_for(ng)), dim3(256), 0, stream, b, ng, mm, grid, bm_g,
