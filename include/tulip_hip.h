@@ -65,6 +65,8 @@ int tulip_gemm_effective_splits(int K, int splits);
  * n, stride multiples of 4; a region with n<=0 is skipped. */
 int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
                        int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream);
+/* out[i] = sum over the partial rows (overwrites: no zero-fill of `out` needed) */
+int tulip_reduce_rows_set(const float* part, int64_t stride, float* out, int64_t n, int nrows, hipStream_t stream);
 /* out[i] += sum_s slabs[s*n + i]  (= tulip_reduce_rows2 with one region of stride n) */
 int tulip_reduce_splits(const float* slabs, float* out, int64_t n, int splits, hipStream_t stream);
 

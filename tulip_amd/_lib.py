@@ -35,6 +35,7 @@ SIGNATURES = {
     "tulip_cast_colsum": [P, P, P, I, I, P, I, P],
     "tulip_reduce_splits": [P, P, L, I, P],
     "tulip_reduce_rows2": [P, L, P, L, P, L, P, L, I, P],
+    "tulip_reduce_rows_set": [P, L, P, L, I, P],
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],

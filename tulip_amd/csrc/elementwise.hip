@@ -144,6 +144,7 @@ struct ReduceRegion {
     int64_t stride;  // floats between partial rows
     int64_t n4;      // float4 columns
     int nblocks;
+    int overwrite;   // out = sum instead of out += sum
 };
 template <int RL>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(ReduceRegion r0, ReduceRegion r1, int S) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ReduceRegion r0, Reduc
         }
     }
     if (rl == 0 && col < r.n4) {
-        float4 o = *(const float4*)(r.out + col * 4);
+        float4 o = r.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(r.out + col * 4);
         o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
         *(float4*)(r.out + col * 4) = o;
     }
@@ -404,8 +405,8 @@ extern "C" int tulip_cast_colsum(const float* x, uint16_t* y, float* colsum, int
     return TULIP_OK;
 }
 
-extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
-                                  int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream) {
+static int reduce_rows_impl(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
+                            int64_t stride1, float* out1, int64_t n1, int nrows, int overwrite, hipStream_t stream) {
     if (nrows <= 0 || (n0 <= 0 && n1 <= 0)) return TULIP_OK;
     if ((n0 & 3) || (n1 & 3) || (stride0 & 3) || (stride1 & 3)) return TULIP_ERR_ARG;
     if (n0 < 0) n0 = 0;
@@ -413,13 +414,23 @@ extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* ou
     // few columns -> spread the partial rows over 16 row lanes; many columns -> one thread per column
     const bool wide = (n0 + n1) / 4 >= 8192;
     const int CT = wide ? 256 : 16;
-    ReduceRegion r0{part0, out0, stride0, n0 / 4, (int)((n0 / 4 + CT - 1) / CT)};
-    ReduceRegion r1{part1, out1, stride1, n1 / 4, (int)((n1 / 4 + CT - 1) / CT)};
+    ReduceRegion r0{part0, out0, stride0, n0 / 4, (int)((n0 / 4 + CT - 1) / CT), overwrite};
+    ReduceRegion r1{part1, out1, stride1, n1 / 4, (int)((n1 / 4 + CT - 1) / CT), overwrite};
     const dim3 grid(r0.nblocks + r1.nblocks);
     if (wide) hipLaunchKernelGGL(reduce_rows_kernel<1>, grid, dim3(256), 0, stream, r0, r1, nrows);
     else hipLaunchKernelGGL(reduce_rows_kernel<16>, grid, dim3(256), 0, stream, r0, r1, nrows);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
+}
+
+extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
+                                  int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream) {
+    return reduce_rows_impl(part0, stride0, out0, n0, part1, stride1, out1, n1, nrows, 0, stream);
+}
+
+extern "C" int tulip_reduce_rows_set(const float* part, int64_t stride, float* out, int64_t n, int nrows,
+                                     hipStream_t stream) {
+    return reduce_rows_impl(part, stride, out, n, nullptr, 0, nullptr, 0, nrows, 1, stream);
 }
 
 extern "C" int tulip_reduce_splits(const float* slabs, float* out, int64_t n, int splits, hipStream_t stream) {

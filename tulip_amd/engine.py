@@ -616,8 +616,7 @@ class TulipEngine:
         gtab, rel32 = G(p + ".attn.relative_position_bias_table"), self._rel32
 
         def fold_bias():
-            P.bufs["adense." + p].zero_()
-            ops.reduce_rows2(apart, nh * 256, dense, nh * 256, None, 0, None, 0, R)
+            ops.reduce_rows_set(apart, nh * 256, dense, nh * 256, R)
             ops.bias_table_scatter(dense, rel32, gtab, nh, 16)
 
         self._side(fold_bias)

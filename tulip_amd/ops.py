@@ -67,6 +67,10 @@ def reduce_rows2(part0, stride0, out0, n0, part1, stride1, out1, n1, nrows):
                                          _stream()), "tulip_reduce_rows2")
 
 
+def reduce_rows_set(part, stride, out, n, nrows):
+    check(_lib.load().tulip_reduce_rows_set(_p(part), stride, _p(out), n, nrows, _stream()), "tulip_reduce_rows_set")
+
+
 def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False, B=0, H=0, W=0):
     rc = _lib.load().tulip_layernorm_bwd_params(_p(dy), _p(x), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), rows, C,
                                                 int(merge), B, H, W, _stream())
