@@ -491,6 +491,8 @@ class TulipEngine:
 
     flush_per_block = True
     early_flush = frozenset()   # block prefixes with a mid-block side flush (set in bind())
+    lag_bucket_join = os.environ.get("TULIP_LAG_BUCKET_JOIN", "1") != "0"
+    _lagged_hook = None
     # Side streams, used round-robin by Swin block.  Measured on MI355X / ROCm 7.2 (graph replay, B=8):
     # 1 stream 4.63 ms, 2: 4.46, 3: 4.82, 4: 4.05, 5: 4.63, 6: 4.33, 8: 4.05, 12: 4.08, 16: 4.05 -- the HIP graph
     # executor spreads the captured branches over 4 hardware queues, and branch counts that are not a multiple
@@ -536,6 +538,13 @@ class TulipEngine:
                 fn(ws)
         self._pending = []
         self._side_dirty = True
+
+    def _wait_side(self):
+        """The current stream waits for everything issued on the side streams so far (queued work stays queued)."""
+        if getattr(self, "_side_dirty", False):
+            for st in self._side_streams:
+                torch.cuda.current_stream().wait_stream(st)
+            self._side_dirty = False
 
     def _join_side(self):
         self._flush_wgrads()
@@ -625,6 +634,9 @@ class TulipEngine:
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
         self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
                      G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1", cast=next_cast)
+        if self._lagged_hook is not None:
+            fn, self._lagged_hook = self._lagged_hook, None
+            fn()                                    # bucket join + all-reduce of the previous group, one block late
         if self.flush_per_block:
             self._flush_wgrads()
 
@@ -662,13 +674,29 @@ class TulipEngine:
         G = lambda name: gbase + 4 * W_.offset[name]
         user_hook = bucket_hook or (lambda tag: None)
 
+        def join_and_fire(tag):
+            self._wait_side()
+            user_hook(tag)
+
         def hook(tag):
             # a bucket is complete only once its side-stream weight gradients are in; without buckets the
-            # side stream is joined once, at the end
+            # side streams are joined once, at the end
+            if self._lagged_hook is not None:           # two hooks without a block in between
+                fn, self._lagged_hook = self._lagged_hook, None
+                fn()
             self._flush_wgrads()
-            if tag == "embed" or (join_tags is not None and tag in join_tags):
-                self._join_side()
-            user_hook(tag)
+            bucket = join_tags is not None and tag in join_tags
+            if tag == "embed":
+                join_and_fire(tag)
+            elif bucket and self.lag_bucket_join:
+                # joining here would stall the chain behind the side work that was forked a moment ago; the join
+                # (and with it the bucket's all-reduce) moves to the end of the NEXT block's chain work, before that
+                # block's own side work is issued (see _block_bwd)
+                self._lagged_hook = lambda: join_and_fire(tag)
+            elif bucket:
+                join_and_fire(tag)
+            else:
+                user_hook(tag)
 
         M0 = B * H0 * W0
         tpart = P["tail.dwd_part"]
