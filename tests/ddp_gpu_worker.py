@@ -36,7 +36,7 @@ def main():
     dist.all_gather(gathered, flat)
     if rank == 0:
         torch.save({"flat": flat.cpu(), "same_on_all_ranks": all(torch.equal(gathered[0], g) for g in gathered),
-                    "losses": torch.stack(losses).cpu(), "segments": len(tr._segments[True]) if use_graph else 0,
+                    "losses": torch.stack(losses).cpu(), "segments": len(tr._segments[True]) if use_graph else 0, "bucket_adamw": tr.bucket_adamw,
                     "buckets": tr.bucketer.buckets}, out_path)
     dist.barrier()
     dist.destroy_process_group()

@@ -39,7 +39,8 @@ def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph, a
     got = torch.load(out)
     assert got["same_on_all_ranks"]                              # replicas stay bit-identical
     if use_graph:
-        assert got["segments"] == len(got["buckets"]) + 1        # one segment per bucket + the AdamW segment
+        # one graph segment per bucket; the optimizer runs per bucket behind its all-reduce (no AdamW segment)
+        assert got["bucket_adamw"] and got["segments"] == len(got["buckets"])
     cfg = O.tiny_config(drop_path_rate=0.0)
     sd = O.key_seeded_state_dict(cfg, seed=3)
     lo, hi = O.synthetic_batch(cfg, 4, seed=77)
@@ -58,6 +59,7 @@ def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph, a
     u_ddp, u_ref = got["flat"] - init, ref - init
     assert u_ref.abs().max().item() > 1e-4                        # the parameters actually moved
     rel = ((u_ddp - u_ref).norm() / u_ref.norm()).item()
+    print(f"update-vector relative L2 difference: {rel:.4e}")
     assert rel <= 1e-2, rel
     assert (u_ddp - u_ref).abs().max().item() <= 2 * 5e-4 * steps + 1e-6
     assert ((u_ddp - u_ref).abs() <= 2e-5).float().mean().item() >= 0.995

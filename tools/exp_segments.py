@@ -10,8 +10,17 @@ for fake in (1, 2):
     model = bench.make_model(args).to(dev).train()
     tr = Trainer(model, 8, device=dev)
     tr.world = fake
-    tr.bucketer.on_group_done = lambda *a: None
+    class _Done:
+        def wait(self): pass
+    tr.bucketer.on_group_done = (lambda tag, g, keep=True, b=tr.bucketer:
+                                 (_Done(), *b.by_tag[tag]) if (fake > 1 and tag in b.by_tag) else None)
     tr.bucketer.wait_all = lambda: None
+    if fake > 1 and os.environ.get("TULIP_BUCKET_ADAMW", "1") != "0":
+        tr.bucket_adamw, tr._opt_stream = True, torch.cuda.Stream()
+        W = tr.eng.params
+        tr._late_buckets = {tag for tag, a, b in tr.bucketer.buckets
+                            if any("skip_connection_layers" in n and a <= W.offset[n] < b for n in W.names)}
+        tr._late = []
     lo, hi = bench.synthetic(args, 0, dev); tr.load_batch(lo, hi)
     for _ in range(10): tr.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()

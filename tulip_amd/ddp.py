@@ -43,12 +43,17 @@ class GradBucketer:
         self.pending: List = []
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
-    def on_group_done(self, tag: str, gflat: torch.Tensor) -> None:
-        """Call after the launches producing group `tag` have been enqueued on the current stream."""
+    def on_group_done(self, tag: str, gflat: torch.Tensor, keep: bool = True):
+        """Call after the launches producing group `tag` have been enqueued on the current stream.
+        Returns (work, start, end) of the bucket's all-reduce, or None.  keep=False: the caller waits on the work
+        itself (per-bucket optimizer), wait_all() will not."""
         if self.world == 1 or tag not in self.by_tag:
-            return
+            return None
         a, b = self.by_tag[tag]
-        self.pending.append(dist.all_reduce(gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        work = dist.all_reduce(gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if keep:
+            self.pending.append(work)
+        return work, a, b
 
     def wait_all(self) -> None:
         for w in self.pending:

@@ -16,6 +16,7 @@ all-reduces (the sum of the per-micro-step all-reduces the reference issues) and
 from __future__ import annotations
 
 import math
+import os
 import sys
 from typing import Iterable, Optional
 
@@ -62,6 +63,18 @@ class Trainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucketer = GradBucketer(W.groups, W.total, bucket_mb, process_group)
         self.use_graph = use_graph
+        # N > 1: each bucket is updated (fused AdamW on its slice) on a separate stream as soon as ITS all-reduce has
+        # finished, beside the rest of the backward, instead of one update after the last bucket; nothing later in
+        # the step reads a finished bucket's parameters or gradients.  The grad-norm read-out needs all gradients.
+        self.bucket_adamw = (self.world > 1 and not track_grad_norm
+                             and os.environ.get("TULIP_BUCKET_ADAMW", "1") != "0")
+        self._opt_stream = torch.cuda.Stream(device=device) if self.bucket_adamw else None
+        # ... except the skip-connection Linears: the x_save half of their input gradient is formed when the backward
+        # reaches the encoder stage (engine.run_backward), long after their decoder bucket has been reduced, so
+        # buckets holding them are updated at the end of the step
+        self._late_buckets = {tag for tag, a, b in self.bucketer.buckets
+                              if any("skip_connection_layers" in n and a <= W.offset[n] < b for n in W.names)}
+        self._late = []
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
         self._side = torch.cuda.Stream(device=device) if use_graph else None
         W.refresh_shadow()
@@ -84,6 +97,40 @@ class Trainer:
         eng.run_forward(P)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.world > 1 and update) else None)
+
+    def _adamw_range(self, lo: int, hi: int):
+        W = self.eng.params
+        ops.adamw(W.base32 + 4 * lo, self.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                  self.v.data_ptr() + 4 * lo, W.base16 + 2 * lo, hi - lo, self.hyper,
+                  W.decay_mask.data_ptr() + lo // 64, zero_grad=True)
+
+    def _bucket_done(self, tag):
+        """All-reduce of the bucket that `tag` completes; with bucket_adamw also its optimizer update, ordered behind
+        the collective on the optimizer stream (work.wait() is a stream-level dependency for RCCL)."""
+        r = self.bucketer.on_group_done(tag, self.g, keep=not self.bucket_adamw)
+        if r is None or not self.bucket_adamw:
+            return
+        work, a, b = r
+        if tag in self._late_buckets:
+            self._late.append(r)
+            return
+        with torch.cuda.stream(self._opt_stream):
+            work.wait()
+            self._adamw_range(a, b)
+
+    def _finish_buckets(self):
+        if self.bucket_adamw:
+            cur = torch.cuda.current_stream()
+            self._opt_stream.wait_stream(cur)          # the backward has consumed every weight by now
+            with torch.cuda.stream(self._opt_stream):
+                for work, a, b in self._late:
+                    work.wait()
+                    self._adamw_range(a, b)
+            self._late.clear()
+            cur.wait_stream(self._opt_stream)
+        else:
+            self.bucketer.wait_all()
+            self._adamw()
 
     def _adamw(self):
         W = self.eng.params
@@ -129,11 +176,12 @@ class Trainer:
                     segs.append((cur, None))
                 else:
                     self._empty_tail = cur          # keep the (empty) graph object alive
-                g2 = torch.cuda.CUDAGraph()
-                g2.capture_begin(capture_error_mode="thread_local")
-                self._adamw()
-                g2.capture_end()
-                segs.append((g2, "adamw"))
+                if not self.bucket_adamw:
+                    g2 = torch.cuda.CUDAGraph()
+                    g2.capture_begin(capture_error_mode="thread_local")
+                    self._adamw()
+                    g2.capture_end()
+                    segs.append((g2, "adamw"))
         torch.cuda.current_stream().wait_stream(side)
         return segs
 
@@ -163,9 +211,11 @@ class Trainer:
             self._set_hyper()
         if not self.use_graph:
             if update:
-                self._fwd_bwd(lambda tag: self.bucketer.on_group_done(tag, self.g))
-                self.bucketer.wait_all()
-                self._adamw()
+                self._fwd_bwd(self._bucket_done)
+                if self.world > 1:
+                    self._finish_buckets()
+                else:
+                    self._adamw()
             else:
                 self._fwd_bwd(lambda tag: None, update=False)
             return self.P.losses
@@ -187,7 +237,9 @@ class Trainer:
             else:
                 graph.replay()
                 if tag is not None:
-                    self.bucketer.on_group_done(tag, self.g)
+                    self._bucket_done(tag)
+        if update and self.bucket_adamw:
+            self._finish_buckets()
         return self.P.losses
 
 
