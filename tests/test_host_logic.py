@@ -108,6 +108,20 @@ def test_bucket_plan_covers_buffer_once():
             assert e0 == s1
         assert all(e > s for _, s, e in b)
     assert len(plan_buckets(fp.groups, fp.total, 1 << 40)) == 1
+    # a group may be handed to the optimizer when its hook fires, so every parameter must sit in the group where the
+    # backward READS it last: the skip Linear of level s is read again at encoder stage s (x_save half of its input
+    # gradient, tulip.py:715 backward), blocks / merges / unmerges / head only inside their own stage
+    nl = m.num_layers
+    starts = dict(zip([t for t, _ in fp.groups], [0] + [e for _, e in fp.groups][:-1]))
+    ends = dict(fp.groups)
+    group_of = lambda name: next(t for t in starts if starts[t] <= fp.offset[name] < ends[t])
+    for i in range(nl - 1):
+        for suffix in ("weight", "bias"):
+            assert group_of(f"skip_connection_layers.{i}.{suffix}") == f"enc{nl - i - 2}"
+    assert group_of("first_patch_expanding.expand.weight") == f"enc{nl - 1}"
+    assert group_of("layers.0.downsample.reduction.weight") == "enc1"
+    assert group_of("layers_up.0.blocks.0.attn.qkv.weight") == "dec0"
+    assert group_of("decoder_pred.weight") == "head" and group_of("patch_embed.proj.weight") == "embed"
 
 
 def test_engine_block_specs():

@@ -17,10 +17,7 @@ for fake in (1, 2):
     tr.bucketer.wait_all = lambda: None
     if fake > 1 and os.environ.get("TULIP_BUCKET_ADAMW", "1") != "0":
         tr.bucket_adamw, tr._opt_stream = True, torch.cuda.Stream()
-        W = tr.eng.params
-        tr._late_buckets = {tag for tag, a, b in tr.bucketer.buckets
-                            if any("skip_connection_layers" in n and a <= W.offset[n] < b for n in W.names)}
-        tr._late = []
+
     lo, hi = bench.synthetic(args, 0, dev); tr.load_batch(lo, hi)
     for _ in range(10): tr.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()

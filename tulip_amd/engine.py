@@ -119,11 +119,16 @@ class FlatParams:
         for i in reversed(range(nl - 1)):
             add(f"layers_up.{i}.upsample.")
             blocks_rev(f"layers_up.{i}", model.depths[nl - i - 2])
-            add(f"skip_connection_layers.{i}.")
             marks.append((f"dec{i}", len(order)))
         add("first_patch_expanding.")
         for s in reversed(range(nl)):
             blocks_rev(f"layers.{s}", model.depths[s])
+            if s < nl - 1:
+                # the skip Linear of level s: its gradient is complete with decoder stage s, but its weight is read
+                # once more when the backward reaches encoder stage s (x_save half of its input gradient, see
+                # run_backward) -- it is grouped where it is last READ, so that a group may be handed to the
+                # optimizer as soon as the group's hook has fired
+                add(f"skip_connection_layers.{nl - s - 2}.")
             if s > 0:
                 add(f"layers.{s - 1}.downsample.")
             marks.append((f"enc{s}", len(order)))

@@ -69,12 +69,8 @@ class Trainer:
         self.bucket_adamw = (self.world > 1 and not track_grad_norm
                              and os.environ.get("TULIP_BUCKET_ADAMW", "1") != "0")
         self._opt_stream = torch.cuda.Stream(device=device) if self.bucket_adamw else None
-        # ... except the skip-connection Linears: the x_save half of their input gradient is formed when the backward
-        # reaches the encoder stage (engine.run_backward), long after their decoder bucket has been reduced, so
-        # buckets holding them are updated at the end of the step
-        self._late_buckets = {tag for tag, a, b in self.bucketer.buckets
-                              if any("skip_connection_layers" in n and a <= W.offset[n] < b for n in W.names)}
-        self._late = []
+        # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
+        # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
         self._side = torch.cuda.Stream(device=device) if use_graph else None
         W.refresh_shadow()
@@ -111,23 +107,13 @@ class Trainer:
         if r is None or not self.bucket_adamw:
             return
         work, a, b = r
-        if tag in self._late_buckets:
-            self._late.append(r)
-            return
         with torch.cuda.stream(self._opt_stream):
             work.wait()
             self._adamw_range(a, b)
 
     def _finish_buckets(self):
         if self.bucket_adamw:
-            cur = torch.cuda.current_stream()
-            self._opt_stream.wait_stream(cur)          # the backward has consumed every weight by now
-            with torch.cuda.stream(self._opt_stream):
-                for work, a, b in self._late:
-                    work.wait()
-                    self._adamw_range(a, b)
-            self._late.clear()
-            cur.wait_stream(self._opt_stream)
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
         else:
             self.bucketer.wait_all()
             self._adamw()
