@@ -4,7 +4,8 @@ import sys, os, argparse, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from tulip_amd.trainer import Trainer
-args = argparse.Namespace(model="tulip_base", img=[16, 1024], target=[64, 1024], batch=8)
+args = argparse.Namespace(model=os.environ.get("MODEL", "tulip_base"), img=[int(v) for v in os.environ.get("IMG", "16,1024").split(",")],
+                          target=[int(v) for v in os.environ.get("TARGET", "64,1024").split(",")], batch=8)
 dev = torch.device("cuda", 0)
 for fake in (1, 2):
     model = bench.make_model(args).to(dev).train()
