@@ -675,6 +675,7 @@ class TulipEngine:
         m, W_ = self.model, self.params
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
+        self._pending, self._lagged_hook = [], None     # nothing survives from an aborted earlier call
         gbase = gflat.data_ptr()
         G = lambda name: gbase + 4 * W_.offset[name]
         user_hook = bucket_hook or (lambda tag: None)
