@@ -50,7 +50,10 @@ class Trainer:
         self.m = torch.zeros_like(self.g)
         self.v = torch.zeros_like(self.g)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=device)
-        self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        # the host runs several steps ahead of the GPU: each upload of the hyper block reads its own pinned slot, and a
+        # slot is rewritten only after the copy that last read it has executed
+        self._hyper_slots = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._hyper_events = [None] * 4
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.t = 0
         self.accum_iter, self.micro = int(accum_iter), 0
@@ -79,12 +82,18 @@ class Trainer:
     def _set_hyper(self):
         self.t += 1
         b1, b2 = self.betas
-        h = self.hyper_host
+        k = self.t % len(self._hyper_slots)
+        if self._hyper_events[k] is not None:
+            self._hyper_events[k].synchronize()
+        h = self._hyper_slots[k]
         h[0] = self.lr
         h[1], h[2], h[3], h[4] = b1, b2, self.eps, self.wd
         h[5], h[6] = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
         h[7] = 1.0 / self.world
         self.hyper.copy_(h, non_blocking=True)
+        if self._hyper_events[k] is None:
+            self._hyper_events[k] = torch.cuda.Event()
+        self._hyper_events[k].record()
 
     def _fwd_bwd(self, hook, update: bool = True):
         eng, P = self.eng, self.P
