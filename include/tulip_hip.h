@@ -252,6 +252,17 @@ int tulip_voxel_metrics(const void* pcd_pred, int64_t n_pred, const void* pcd_gt
 int tulip_chamfer_sq(const void* a, int64_t na, const void* b, int64_t nb, int is_f64, float* dist_a, float* dist_b,
                      double* scratch, double* out, hipStream_t stream);
 
+/* KITTI point cloud -> range image, the producer of the .npy files the loaders read
+ * (kitti_utils/sample_kitti_dataset.py create_range_map :24-66, parameters :139-145): points (n,4) float32
+ * [x,y,z,intensity]; row = rint((atan2(z,sqrt(x^2+y^2))*180/pi + ang_start_y)/ang_res_y),
+ * col = -trunc((atan2(x,y)*180/pi - 90)/ang_res_x) + cols/2 (wrapped once), all float32 in numpy's op order; a pixel
+ * keeps the LAST point (in point order) that falls into it; range outside [min_range,max_range] -> 0, the
+ * intensity of such a point is kept (as in the reference); out (rows,cols,2) float32 [range, intensity].
+ * winner: scratch of rows*cols int32, all -1 on entry and on exit. */
+int tulip_kitti_range_map(const float* points, int64_t n, int rows, int cols, float ang_start_y, float ang_res_y,
+                          float ang_res_x, float max_range, float min_range, int32_t* winner, float* out,
+                          hipStream_t stream);
+
 /* library self-description */
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);

@@ -89,3 +89,63 @@ def synthetic_raw(B: int, H: int, W: int, seed: int, max_m: float = 130.0) -> to
     for b in range(B):
         flat[b, idx[b]] = edge[torch.arange(64) % edge.numel()]
     return flat.reshape(B, H, W).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# KITTI point cloud -> range image (the producer of the .npy files): kitti_utils/sample_kitti_dataset.py:24-66,139-160
+# ---------------------------------------------------------------------------------------------------
+KITTI_PROJECTION = dict(image_rows=64, image_cols=1024, ang_start_y=24.8, ang_res_y=26.8 / 63, ang_res_x=360 / 1024,
+                        max_range=120, min_range=0)
+
+
+def kitti_pixel_of_points(points: np.ndarray, image_rows, image_cols, ang_start_y, ang_res_y, ang_res_x, **_):
+    """(rowId, colId, range) of every point, in numpy float32 arithmetic like create_range_map :27-44:
+    row = rint((atan2(z, sqrt(x^2+y^2))*180/pi + ang_start_y) / ang_res_y);
+    col = -trunc((atan2(x, y)*180/pi - 90) / ang_res_x) + cols/2, minus cols where >= cols."""
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    assert x.dtype == np.float32
+    vert = np.arctan2(z, np.sqrt(x * x + y * y)) * 180.0 / np.pi
+    row = np.int_(np.round(( vert + ang_start_y) / ang_res_y))
+    hor = np.arctan2(x, y) * 180.0 / np.pi
+    col = -np.int_((hor - 90.0) / ang_res_x) + image_cols / 2
+    col[col >= image_cols] -= image_cols
+    col = col.astype(np.int64)
+    rng = np.sqrt(x * x + y * y + z * z)
+    return row, col, rng
+
+
+def kitti_range_map(points: np.ndarray, image_rows=64, image_cols=1024, ang_start_y=24.8, ang_res_y=26.8 / 63,
+                    ang_res_x=360 / 1024, max_range=120, min_range=0) -> np.ndarray:
+    """create_range_map (:24-66): (N,4) [x,y,z,intensity] float32 -> (rows, cols, 2) [range, intensity] float32.
+    Ranges outside [min_range, max_range] become 0 (:41-42) -- the intensities of those points are KEPT, because the
+    reference tests the already zeroed range (:45-46); points outside the image are dropped (:49); when several points
+    hit a pixel the LAST one in point order stays (fancy-index assignment :56-57)."""
+    row, col, rng = kitti_pixel_of_points(points, image_rows, image_cols, ang_start_y, ang_res_y, ang_res_x)
+    rng = rng.copy()
+    rng[rng > max_range] = 0
+    rng[rng < min_range] = 0
+    inten = points[:, 3]
+    ok = (row >= 0) & (row < image_rows) & (col >= 0) & (col < image_cols)
+    out = np.zeros((image_rows, image_cols, 2), dtype=np.float32)
+    # last point in order wins: iterate winners explicitly instead of relying on assignment order
+    pix = row[ok] * image_cols + col[ok]
+    idx = np.nonzero(ok)[0]
+    winner = np.full(image_rows * image_cols, -1, dtype=np.int64)
+    np.maximum.at(winner, pix, idx)
+    hit = winner >= 0
+    flat = out.reshape(-1, 2)
+    flat[hit, 0] = rng[winner[hit]]
+    flat[hit, 1] = inten[winner[hit]]
+    return out
+
+
+def synthetic_kitti_scan(n: int, seed: int) -> np.ndarray:
+    """Seeded Velodyne-like scan: 64 beams between -24.8 and +2 degrees with jitter, full azimuth, ranges 1..130 m
+    (some beyond max_range), a few points above/below the vertical field of view, duplicates on the same pixel."""
+    g = np.random.default_rng(seed)
+    el = np.deg2rad(g.choice(np.linspace(-24.8, 2.0, 64), n) + g.normal(0, 0.08, n))
+    el[: n // 50] = np.deg2rad(g.uniform(-30, 6, n // 50))
+    az = g.uniform(-np.pi, np.pi, n)
+    r = g.uniform(1.0, 130.0, n)
+    pts = np.stack([r * np.cos(el) * np.sin(az), r * np.cos(el) * np.cos(az), r * np.sin(el), g.uniform(0, 1, n)], -1)
+    return pts.astype(np.float32)

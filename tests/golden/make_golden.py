@@ -276,6 +276,7 @@ def main():
     golden_train_loop(T)
     golden_transforms()
     golden_eval()
+    golden_kitti_projection()
     tiny = O.tiny_config()
     golden_model(T, "g3_tiny_fp32", tiny, batch=2, seed=0, with_grads=True)
     golden_model(T, "g3_tiny_droppath", tiny, batch=4, seed=1, with_grads=True, drop_path=True)
@@ -625,8 +626,30 @@ def golden_eval():
     print("eval fixtures written")
 
 
+def golden_kitti_projection():
+    """f-3 (producer side): kitti_utils/sample_kitti_dataset.py create_range_map on a seeded synthetic scan.
+    The module imports cv2 at the top (unused by the function: stubbed) and calls np.round_, an alias NumPy 2.0
+    removed (restored as np.round, the same function)."""
+    from oracle import data_oracle as DO
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    if not hasattr(np, "round_"):
+        np.round_ = np.round
+    sys.path.insert(0, os.path.join(os.path.dirname(REF), "kitti_utils"))
+    import sample_kitti_dataset as K
+    pts = DO.synthetic_kitti_scan(120000, seed=3)
+    ref = K.create_range_map(pts.copy(), image_rows_full=64, image_cols=1024, ang_start_y=24.8, ang_res_y=26.8 / 63,
+                             ang_res_x=360 / 1024, max_range=120, min_range=0)
+    assert np.array_equal(ref, DO.kitti_range_map(pts))
+    np.savez_compressed(os.path.join(HERE, "g11_kitti_projection.npz"), n=np.int64(120000), seed=np.int64(3),
+                        every_third_column=ref[:, ::3, :].copy(), sums=ref.astype(np.float64).sum(axis=(0, 1)),
+                        nonzero=np.array([(ref[..., 0] > 0).sum(), (ref[..., 1] > 0).sum()]))
+    print("kitti projection fixture written:", ref.shape, (ref[..., 0] > 0).mean())
+
+
 if __name__ == "__main__":
-    if "--eval-only" in sys.argv:
+    if "--kitti-projection-only" in sys.argv:
+        golden_kitti_projection()
+    elif "--eval-only" in sys.argv:
         golden_eval()
     elif "--transforms-only" in sys.argv:
         golden_transforms()

@@ -91,3 +91,16 @@ def test_prep_argument_errors():
         prep(torch.zeros(1, 64, 64))
     with pytest.raises(ValueError):
         prep(torch.zeros(1, 32, 64))
+
+
+def test_kitti_projection_oracle_vs_reference(golden_dir):
+    """producer of the .npy files: oracle restatement of create_range_map against the reference's output (g11)"""
+    z = np.load(os.path.join(golden_dir, "g11_kitti_projection.npz"))
+    pts = DO.synthetic_kitti_scan(int(z["n"]), int(z["seed"]))
+    img = DO.kitti_range_map(pts)
+    assert img.shape == (64, 1024, 2) and img.dtype == np.float32
+    assert np.array_equal(img[:, ::3, :], z["every_third_column"])
+    assert np.array_equal(np.array([(img[..., 0] > 0).sum(), (img[..., 1] > 0).sum()]), z["nonzero"])
+    np.testing.assert_allclose(img.astype(np.float64).sum(axis=(0, 1)), z["sums"], rtol=1e-12)
+    # the reference's quirk: ranges beyond max_range are zeroed, their intensities are not
+    assert (img[..., 1] > 0).sum() > (img[..., 0] > 0).sum()

@@ -110,3 +110,38 @@ def test_device_loader_end_to_end(tmp_path):
         close(hi, ohi, True)
         seen += n
     assert seen == 5
+
+
+def test_kitti_range_projection_kernel():
+    """tulip_kitti_range_map vs the oracle (== create_range_map).  atan2f on the device and numpy's float32 arctan2
+    differ by an ulp, which moves a point across a pixel boundary only when it sits within ~1e-5 pixels of one:
+    pixels whose every candidate point is safely inside its cell must agree bit for bit, and the rest must be few."""
+    pts = DO.synthetic_kitti_scan(120000, seed=3)
+    proj = D.KittiRangeProjector()
+    got = proj(torch.from_numpy(pts).to(DEV)).cpu().numpy()
+    ref = DO.kitti_range_map(pts)
+    assert got.shape == ref.shape == (64, 1024, 2)
+    # float64 margins of every point to its row-rounding and column-truncation boundaries
+    x, y, zc = (pts[:, i].astype(np.float64) for i in range(3))
+    rr = (np.degrees(np.arctan2(zc, np.hypot(x, y))) + 24.8) / (26.8 / 63)
+    cc = (np.degrees(np.arctan2(x, y)) - 90.0) / (360 / 1024)
+    unsafe = (np.abs(rr - np.floor(rr) - 0.5) < 1e-3) | (np.abs(cc - np.round(cc)) < 1e-3)
+    row, col, _ = DO.kitti_pixel_of_points(pts, **DO.KITTI_PROJECTION)
+    tainted = np.zeros((64, 1024), dtype=bool)
+    for dr in (-1, 0, 1):
+        for dc in (-1, 0, 1):
+            r, c = row[unsafe] + dr, (col[unsafe] + dc) % 1024
+            ok = (r >= 0) & (r < 64)
+            tainted[r[ok], c[ok]] = True
+    assert tainted.mean() < 0.05
+    assert np.array_equal(got[~tainted], ref[~tainted])
+    assert (got != ref).any(axis=-1).mean() < 2e-4
+    assert not (proj._winner != -1).any().item()                    # scratch handed back reset
+    again = proj(torch.from_numpy(pts).to(DEV)).cpu().numpy()
+    assert np.array_equal(again, got)                                # deterministic: last point in order wins
+    # feeds straight into the input transforms: the (H,W,2) array is what RangePrep reads in place
+    prep = D.RangePrep("kitti", (16, 1024), (64, 1024), True)
+    lo, hi = prep(torch.from_numpy(got)[None].to(DEV))
+    olo, ohi = DO.range_prep(torch.from_numpy(got[..., 0].copy())[None], DO.DATASETS["kitti"], (16, 1024), (64, 1024), True)
+    close(lo, olo, True)
+    close(hi, ohi, True)

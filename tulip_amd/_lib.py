@@ -45,6 +45,7 @@ SIGNATURES = {
     "tulip_adamw": [P, P, P, P, P, L, P, P, I, P],
     "tulip_drop_path_scales": [P, P, P, I, I, ctypes.c_uint64, P, P],
     "tulip_grad_norm": [P, L, P, P, F, P, P],
+    "tulip_kitti_range_map": [P, L, I, I, F, F, F, F, F, P, P, P],
     "tulip_range_prep": [P, I, L, L, L, L, P, P, I, I, I, I, I, I, I, F, I, F, F, I, I, P],
     "tulip_mc_aggregate": [P, I, L, F, P, P],
     "tulip_eval_postprocess": [P, P, P, P, P, P, P, I, I, I, I, I, F, F, F, P],

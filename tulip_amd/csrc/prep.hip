@@ -133,6 +133,52 @@ __global__ __launch_bounds__(256) void range_prep_rows_kernel(const float* __res
     }
 }
 
+// ---- KITTI point cloud -> range image (kitti_utils/sample_kitti_dataset.py:24-66), float32 in numpy's op order
+struct KittiProj {
+    int rows, cols;
+    float ang_start_y, ang_res_y, ang_res_x, max_range, min_range, half_cols;
+};
+__device__ __forceinline__ bool kitti_pixel(const float* __restrict__ p, const KittiProj& k, int& row, int& col) {
+#pragma clang fp contract(off)
+    const float x = p[0], y = p[1], z = p[2];
+    const float deg = 180.0f, pi = 3.14159274101257324f;                       // float32(180.0), float32(np.pi)
+    const float vert = atan2f(z, sqrtf(x * x + y * y)) * deg / pi;              // :32
+    const float r = rintf((vert + k.ang_start_y) / k.ang_res_y);                // :33-34 (round half to even)
+    const float hor = atan2f(x, y) * deg / pi;                                  // :36
+    const float c = truncf((hor - 90.0f) / k.ang_res_x);                        // :38 np.int_ truncates
+    if (!(fabsf(r) < 1e9f) || !(fabsf(c) < 1e9f)) return false;
+    long long ci = -(long long)c + (long long)k.half_cols;
+    if (ci >= k.cols) ci -= k.cols;                                             // :40-41
+    const long long ri = (long long)r;
+    row = (int)ri; col = (int)ci;
+    return ri >= 0 && ri < k.rows && ci >= 0 && ci < k.cols;                    // :49
+}
+__global__ __launch_bounds__(256) void kitti_mark_kernel(const float* __restrict__ pts, int64_t n, KittiProj k,
+                                                         int* __restrict__ winner) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int row, col;
+        if (kitti_pixel(pts + i * 4, k, row, col)) atomicMax(&winner[row * k.cols + col], (int)i);   // last point wins
+    }
+}
+__global__ __launch_bounds__(256) void kitti_resolve_kernel(const float* __restrict__ pts, KittiProj k,
+                                                            int* __restrict__ winner, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int npix = k.rows * k.cols;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const int w = winner[i];
+        float rng = 0.f, inten = 0.f;
+        if (w >= 0) {
+            const float* p = pts + (int64_t)w * 4;
+            rng = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);               // :43
+            if (rng > k.max_range || rng < k.min_range) rng = 0.f;               // :44-45
+            inten = p[3];                                                        // :47-48 never fire (range already 0)
+        }
+        out[(int64_t)i * 2] = rng;
+        out[(int64_t)i * 2 + 1] = inten;
+        winner[i] = -1;                                                          // scratch handed back reset
+    }
+}
+
 inline int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
 
 }  // namespace
@@ -174,6 +220,24 @@ extern "C" int tulip_range_prep(const void* raw, int raw_dtype, int64_t batch_st
         hipLaunchKernelGGL(range_prep_kernel<float>, grid, dim3(256), 0, stream, (const float*)raw, a);
     else
         hipLaunchKernelGGL(range_prep_kernel<__half>, grid, dim3(256), 0, stream, (const __half*)raw, a);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_kitti_range_map(const float* points, int64_t n, int rows, int cols, float ang_start_y,
+                                     float ang_res_y, float ang_res_x, float max_range, float min_range,
+                                     int32_t* winner, float* out, hipStream_t stream) {
+    if (!points || !winner || !out || n < 0 || n > 0x7fffffff || rows <= 0 || cols <= 0 || !(ang_res_y > 0.f) ||
+        !(ang_res_x > 0.f))
+        return TULIP_ERR_ARG;
+    KittiProj k{rows, cols, ang_start_y, ang_res_y, ang_res_x, max_range, min_range, (float)cols / 2.0f};
+    if (n > 0) {
+        int64_t nb = (n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(kitti_mark_kernel, dim3((int)nb), dim3(256), 0, stream, points, n, k, winner);
+    }
+    hipLaunchKernelGGL(kitti_resolve_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, stream, points, k, winner,
+                       out);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

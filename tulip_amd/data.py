@@ -186,3 +186,28 @@ class DeviceRangeLoader:
         dev = st[:n].to(self.device, non_blocking=True)
         self._events[k].record(torch.cuda.current_stream(self.device))
         return dev
+
+
+# -- the producer of the KITTI .npy files ------------------------------------------------------------------
+class KittiRangeProjector:
+    """kitti_utils/sample_kitti_dataset.py create_range_map (:24-66) with the reference's parameters (:139-145) as a
+    device kernel: a (N,4) float32 [x,y,z,intensity] Velodyne scan -> the (64,1024,2) [range m, intensity] array the
+    reference stores as .npy and `RangePrep` reads in place."""
+
+    def __init__(self, image_rows: int = 64, image_cols: int = 1024, ang_start_y: float = 24.8,
+                 ang_res_y: float = 26.8 / 63, ang_res_x: float = 360 / 1024, max_range: float = 120,
+                 min_range: float = 0, device="cuda"):
+        self.rows, self.cols = image_rows, image_cols
+        self.params = (ang_start_y, ang_res_y, ang_res_x, max_range, min_range)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("KittiRangeProjector runs on the GPU only (HIP kernel, no CPU fallback)")
+        self._winner = torch.full((image_rows * image_cols,), -1, dtype=torch.int32, device=self.device)
+
+    def __call__(self, points: torch.Tensor) -> torch.Tensor:
+        if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] != 4 or not points.is_cuda \
+                or not points.is_contiguous():
+            raise TypeError("points must be a contiguous (N,4) float32 device tensor")
+        out = torch.empty(self.rows, self.cols, 2, dtype=torch.float32, device=points.device)
+        ops.kitti_range_map(points, points.shape[0], self.rows, self.cols, *self.params, self._winner, out)
+        return out

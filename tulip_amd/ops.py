@@ -228,3 +228,9 @@ def chamfer_sq(a, na, b, nb, is_f64, dist_a, dist_b, scratch, out):
 def drop_path_scales(keep, scale, u_out, nslots, B, seed, counter):
     check(_lib.load().tulip_drop_path_scales(_p(keep), _p(scale), _p(u_out), nslots, B, int(seed) & (2 ** 64 - 1),
                                              _p(counter), _stream()), "tulip_drop_path_scales")
+
+
+def kitti_range_map(points, n, rows, cols, ang_start_y, ang_res_y, ang_res_x, max_range, min_range, winner, out):
+    check(_lib.load().tulip_kitti_range_map(_p(points), n, rows, cols, float(ang_start_y), float(ang_res_y),
+                                            float(ang_res_x), float(max_range), float(min_range), _p(winner), _p(out),
+                                            _stream()), "tulip_kitti_range_map")
