@@ -263,6 +263,24 @@ int tulip_kitti_range_map(const float* points, int64_t n, int rows, int cols, fl
                           float ang_res_x, float max_range, float min_range, int32_t* winner, float* out,
                           hipStream_t stream);
 
+/* Forward of one whole Swin block at embed width 96 (3 heads x 32, window 2x8, MLP 96->384->96) in ONE launch:
+ * SwinTransformerBlock.forward (tulip.py:338-352) = norm1 -> WindowAttention.forward (:282-324, shifted when
+ * shift_h/shift_w != 0, mask when `masked`) -> +DropPath residual -> norm2 -> Mlp.forward (:194-200) -> +residual.
+ * Tokens (B,H,W,96) fp32, H even, W % 32 == 0.  Every tensor the backward reads is written exactly as the separate
+ * kernels write it: xn1 [M][96] bf16, qkv [M][288] bf16, attn_out [M][96] bf16, x1 [M][96] fp32, xn2 [M][96] bf16,
+ * fc1_pre / fc1_act [M][384] bf16, mean/rstd [M] fp32.  drop_scale_* : per-sample DropPath multipliers or NULL. */
+typedef struct tulip_swin96_desc {
+    const float* x_in; float* x1; float* x_out;
+    void* xn1; void* qkv; void* attn_out; void* xn2; void* fc1_pre; void* fc1_act;
+    float* mean1; float* rstd1; float* mean2; float* rstd2;
+    const void* w_qkv; const void* w_proj; const void* w_fc1; const void* w_fc2;
+    const float* b_qkv; const float* b_proj; const float* b_fc1; const float* b_fc2;
+    const float* norm1_weight; const float* norm1_bias; const float* norm2_weight; const float* norm2_bias;
+    const float* bias_table; const int32_t* rel_index; const float* drop_scale_attn; const float* drop_scale_mlp;
+    int B; int H; int W; int shift_h; int shift_w; int masked; float eps;
+} tulip_swin96_desc;
+int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream);
+
 /* library self-description */
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);

@@ -542,3 +542,63 @@ def test_drop_path_scales_kernel(ops):
     flat = U.reshape(400, -1)
     c = torch.corrcoef(torch.stack([flat[:-1].reshape(-1), flat[1:].reshape(-1)]))[0, 1].abs().item()
     assert c < 0.02
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted):
+    """tulip_swin96_block_fwd (one launch for a whole stage-0 Swin block) against the 7-kernel sequence it replaces, on
+    every tensor either path writes: identical up to fp32 summation order (LayerNorm statistics, K-split of the MFMAs),
+    i.e. equal except for isolated bf16 rounding flips."""
+    from tulip_amd.model.tulip import tulip_base
+    from tulip_amd import engine as E
+    torch.manual_seed(0)
+    m = tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), patch_size=(1, 4), in_chans=1, window_size=[2, 8],
+                   pixel_shuffle=True, circular_padding=True, log_transform=True, patch_unmerging=True).to(DEV).train()
+    with torch.no_grad():                                     # non-trivial norms / biases / bias tables
+        for n, p in m.named_parameters():
+            if p.ndim == 1 or "relative_position_bias_table" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    eng = m.engine()
+    eng.bind(torch.device(DEV, torch.cuda.current_device()))
+    saved, eng.fuse_block96 = getattr(eng, "fuse_block96", False), False
+    P = eng.plan(2)
+    sp = eng.enc_blocks[0][1 if shifted else 0]
+    assert sp.shift == shifted and sp.C == 96
+    M = 2 * sp.H * sp.W
+    x = torch.randn(M, 96, device=DEV) * 1.5 + 0.2
+    xin = P["enc0.in"]
+    xin.copy_(x.view_as(xin))
+    du = torch.rand(eng.n_drop_slots, 2, device=DEV)
+    du[:, 0] = 0.01                                           # sample 0: both branches of every block dropped
+    eng.draw_drop_scales(P, True, du)
+    out_ref = torch.empty(M, 96, device=DEV)
+    eng._block_fwd(P, sp, xin, out_ref)
+    p = sp.prefix
+    names = ["xn1", "mean1", "rstd1", "qkv", "o", "x1", "xn2", "mean2", "rstd2", "h", "g"]
+    ref = {k: P[p + "." + k].clone() for k in names}
+    ref["out"] = out_ref
+    W_ = eng.params
+    buf = {k: torch.full_like(v, float("nan") if v.dtype == torch.float32 else 0) for k, v in ref.items()}
+    ops.swin96_block_fwd(
+        x_in=xin, x1=buf["x1"], x_out=buf["out"], xn1=buf["xn1"], qkv=buf["qkv"], attn_out=buf["o"], xn2=buf["xn2"],
+        fc1_pre=buf["h"], fc1_act=buf["g"], mean1=buf["mean1"], rstd1=buf["rstd1"], mean2=buf["mean2"],
+        rstd2=buf["rstd2"], w_qkv=W_.p16(p + ".attn.qkv.weight"), w_proj=W_.p16(p + ".attn.proj.weight"),
+        w_fc1=W_.p16(p + ".mlp.fc1.weight"), w_fc2=W_.p16(p + ".mlp.fc2.weight"), b_qkv=W_.p32(p + ".attn.qkv.bias"),
+        b_proj=W_.p32(p + ".attn.proj.bias"), b_fc1=W_.p32(p + ".mlp.fc1.bias"), b_fc2=W_.p32(p + ".mlp.fc2.bias"),
+        norm1_weight=W_.p32(p + ".norm1.weight"), norm1_bias=W_.p32(p + ".norm1.bias"),
+        norm2_weight=W_.p32(p + ".norm2.weight"), norm2_bias=W_.p32(p + ".norm2.bias"),
+        bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=eng._rel32,
+        drop_scale_attn=eng._ds(P, sp, 0), drop_scale_mlp=eng._ds(P, sp, 1), B=2, H=sp.H, W=sp.W,
+        shift_h=sp.sft[0], shift_w=sp.sft[1], masked=int(sp.shift), eps=eng.eps)
+    torch.cuda.synchronize()
+    eng.fuse_block96 = saved
+    for k in names + ["out"]:
+        a, b = buf[k].float().reshape(-1), ref[k].float().reshape(-1)
+        assert torch.isfinite(a).all(), k
+        d = (a - b).abs()
+        tol = 1e-5 * (1 + b.abs()) if k in ("mean1", "rstd1") else 2 ** -6 * (0.05 + b.abs())
+        frac = (d > tol).float().mean().item()
+        assert frac <= 2e-3, (k, frac, d.max().item())
+        assert (d.norm() / (b.norm() + 1e-12)).item() <= 3e-3, k
+    if sp.slot >= 0:       # sample 0 had both branches dropped (block 0 of the network has DropPath rate 0: no slot)
+        assert torch.equal(buf["out"][: M // 2], x[: M // 2])

@@ -14,9 +14,19 @@ LIB_PATH = os.path.join(_PKG, "libtulip_hip.so")
 
 P, I, F, L, D = c_void_p, c_int, c_float, c_int64, c_double
 
+class Swin96Desc(ctypes.Structure):
+    """tulip_swin96_desc (include/tulip_hip.h)."""
+    _fields_ = [(n, P) for n in ("x_in", "x1", "x_out", "xn1", "qkv", "attn_out", "xn2", "fc1_pre", "fc1_act", "mean1",
+                                 "rstd1", "mean2", "rstd2", "w_qkv", "w_proj", "w_fc1", "w_fc2", "b_qkv", "b_proj",
+                                 "b_fc1", "b_fc2", "norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias",
+                                 "bias_table", "rel_index", "drop_scale_attn", "drop_scale_mlp")] + \
+               [(n, I) for n in ("B", "H", "W", "shift_h", "shift_w", "masked")] + [("eps", F)]
+
+
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P, L, P],
+    "tulip_swin96_block_fwd": [P, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],

@@ -2,6 +2,7 @@
 call is asynchronous on torch's current HIP stream (so it is captured by torch.cuda.graph)."""
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -234,3 +235,14 @@ def kitti_range_map(points, n, rows, cols, ang_start_y, ang_res_y, ang_res_x, ma
     check(_lib.load().tulip_kitti_range_map(_p(points), n, rows, cols, float(ang_start_y), float(ang_res_y),
                                             float(ang_res_x), float(max_range), float(min_range), _p(winner), _p(out),
                                             _stream()), "tulip_kitti_range_map")
+
+
+def swin96_block_fwd(**kw):
+    """tulip_swin96_block_fwd: keyword arguments are the fields of tulip_swin96_desc (tensors or addresses)."""
+    d = _lib.Swin96Desc()
+    for name, _t in _lib.Swin96Desc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    check(_lib.load().tulip_swin96_block_fwd(ctypes.byref(d), _stream()), "tulip_swin96_block_fwd")
