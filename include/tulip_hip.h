@@ -266,7 +266,7 @@ int tulip_kitti_range_map(const float* points, int64_t n, int rows, int cols, fl
 /* Forward of one whole Swin block at embed width 96 (3 heads x 32, window 2x8, MLP 96->384->96) in ONE launch:
  * SwinTransformerBlock.forward (tulip.py:338-352) = norm1 -> WindowAttention.forward (:282-324, shifted when
  * shift_h/shift_w != 0, mask when `masked`) -> +DropPath residual -> norm2 -> Mlp.forward (:194-200) -> +residual.
- * Tokens (B,H,W,96) fp32, H even, W % 32 == 0.  Every tensor the backward reads is written exactly as the separate
+ * Tokens (B,H,W,96) fp32, H even, W % 64 == 0.  Every tensor the backward reads is written exactly as the separate
  * kernels write it: xn1 [M][96] bf16, qkv [M][288] bf16, attn_out [M][96] bf16, x1 [M][96] fp32, xn2 [M][96] bf16,
  * fc1_pre / fc1_act [M][384] bf16, mean/rstd [M] fp32.  drop_scale_* : per-sample DropPath multipliers or NULL. */
 typedef struct tulip_swin96_desc {

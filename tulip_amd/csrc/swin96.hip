@@ -1,29 +1,34 @@
 // One launch for the forward of a whole Swin block at embed width 96 (stage 0 of every TULIP model: 3 heads x 32,
 // window 2x8, MLP 96 -> 384 -> 96; tulip.py:338-352 with :289-323 and :194-200 inside).
 //
-// A workgroup owns 4 neighbouring windows = 64 tokens, one window per wave, and never talks to another workgroup:
+// A workgroup owns 8 neighbouring windows = 128 tokens, one window per wave, and never talks to another workgroup:
 // norm1 -> qkv -> shifted-window attention -> proj -> +residual -> norm2 -> fc1 -> GELU -> fc2 -> +residual all stay
 // in registers.  The trick that makes the chain LDS-free for activations: with the MFMA issued as W . X^T, a lane of
 // the accumulator holds 4 consecutive output channels of ONE token (its column); two such accumulators, rounded to
 // bf16, are exactly a 32-deep operand fragment of the next GEMM up to a fixed permutation of k -- and a permutation
 // of k is free if the weight fragment is read with the same permutation (two 8-byte LDS reads instead of one
 // 16-byte read).  Only V goes through a 1-KiB per-wave LDS tile (transpose read for P.V), and the weights are
-// staged in LDS (W2 | {Wqkv,Wproj} then W1 in the same region: 159 KB of the 160 KB).
+// staged in LDS (W2 | {Wqkv,Wproj} then W1 in the same region, plus the bias / norm2 vectors: 163.7 of 163.8 KB).
 // Everything the backward needs (xn1, qkv, o, x1, xn2, h, g, the LayerNorm statistics) is written exactly as the
 // separate kernels write it, so the backward is unchanged.
+#include <cstdlib>
 #include "common.h"
 #include "tulip_hip.h"
 
 namespace {
 
 constexpr int C = 96, HID = 384;
-constexpr int PW = 208;                   // LDS pitch of a 96-wide bf16 weight row (192 B + 16): conflict-free 16-B reads
-constexpr int PW2 = 784;                  // LDS pitch of a 384-wide bf16 weight row (768 B + 16)
-constexpr int OFF_W2 = 0;                 // fc2.weight  [96][384]   75264 B
+constexpr int NW = 8;                     // windows (= waves) per workgroup: 128 tokens share one copy of the weights
+constexpr int NT = NW * 64;
+constexpr int PW = 200;                   // LDS pitch of a 96-wide bf16 weight row (192 B + 8): conflict-free 8-B reads
+constexpr int PW2 = 776;                  // LDS pitch of a 384-wide bf16 weight row (768 B + 8)
+constexpr int OFF_W2 = 0;                 // fc2.weight  [96][384]
 constexpr int OFF_A = 96 * PW2;           // phase 1: qkv.weight [288][96] | proj.weight [96][96]; phase 2: fc1.weight [384][96]
 constexpr int OFF_WPROJ = OFF_A + 288 * PW;
-constexpr int OFF_V = OFF_A + 384 * PW;   // 4 waves x 1 KiB V tiles
-constexpr int SMEM = OFF_V + 4 * 1024;    // 159232 B
+constexpr int OFF_V = OFF_A + 384 * PW;   // NW x 1 KiB V tiles
+constexpr int OFF_P = OFF_V + NW * 1024;  // fp32 vectors: b_fc1[384] b_qkv[288] b_proj[96] b_fc2[96] norm2.weight[96] norm2.bias[96]
+constexpr int P_B1 = 0, P_BQKV = 384, P_BPROJ = 672, P_B2 = 768, P_G2 = 864, P_BE2 = 960, P_N = 1056;
+constexpr int SMEM = OFF_P + P_N * 4;     // 163712 B of 163840
 
 struct Swin96Args {
     const float* xin; float* x1; float* xout;
@@ -35,6 +40,7 @@ struct Swin96Args {
     const float *ds0, *ds1;               // DropPath multipliers per sample (attention / MLP branch) or nullptr
     int B, H, W, sh, sw, masked;
     float eps, scale;
+    int stop;     // dev: return after phase N (0 = run everything)
 };
 
 __device__ __forceinline__ int region(int x, int X, int wsz, int ssz) {       // create_mask slices, tulip.py:261-266
@@ -54,79 +60,108 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
     asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
     return v;
 }
-// weight fragment with the chained-operand k order: k slots 0..3 <- columns c0..c0+3, slots 4..7 <- c0+16..c0+19
-__device__ __forceinline__ bf16x8 wfrag_perm(const unsigned char* rowp, int c0) {
+// weight fragment in the chained-operand k order: k slots 0..3 <- columns c0..c0+3, slots 4..7 <- c0+16..c0+19
+__device__ __forceinline__ bf16x8 wfrag(const unsigned char* rowp, int c0) {
     return cat8(*(const bf16x4*)(rowp + c0 * 2), *(const bf16x4*)(rowp + (c0 + 16) * 2));
 }
-// global [rows][cols] bf16 -> LDS rows of `pitch` bytes, 16-byte chunks, all 256 threads
-__device__ __forceinline__ void stage_weights(const bf16_t* __restrict__ w, int rows, int cols, unsigned char* dst,
-                                              int pitch, int tid) {
-    const int cpr = cols / 8, n = rows * cpr;
-    for (int c = tid; c < n; c += 256) {
-        const int r = c / cpr, k = c - r * cpr;
-        *(uint4*)(dst + r * pitch + k * 16) = *(const uint4*)(w + (size_t)r * cols + k * 8);
+// global [ROWS][COLS] bf16 -> LDS rows of PITCH bytes; every thread keeps PER 16-byte loads in flight
+template <int ROWS, int COLS, int PITCH>
+__device__ __forceinline__ void stage_weights(const bf16_t* __restrict__ w, unsigned char* dst, int tid) {
+    constexpr int CPR = COLS / 8, N = ROWS * CPR, PER = (N + NT - 1) / NT;
+    uint4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + i * NT;
+        if (N % NT == 0 || c < N) v[i] = *(const uint4*)(w + (size_t)(c / CPR) * COLS + (c % CPR) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + i * NT;
+        if (N % NT == 0 || c < N) {
+            unsigned char* d = dst + (c / CPR) * PITCH + (c % CPR) * 16;
+            *(uint2*)d = make_uint2(v[i].x, v[i].y);
+            *(uint2*)(d + 8) = make_uint2(v[i].z, v[i].w);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
+__global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
     unsigned char* ldsV = smem + OFF_V + wid * 1024;
+    float* prm = (float*)(smem + OFF_P);
 
     // ---- which window, which token (cyclic shift + window partition are address arithmetic, tulip.py:289-297)
-    const int nWx = a.W >> 3, nWy = a.H >> 1, gpr = nWx >> 2;
+    const int nWx = a.W >> 3, nWy = a.H >> 1, gpr = nWx / NW;
     int blk = blockIdx.x;
     const int b = blk / (nWy * gpr);
     blk -= b * nWy * gpr;
-    const int wy = blk / gpr, wx = (blk - wy * gpr) * 4 + wid;
+    const int wy = blk / gpr, wx = (blk - wy * gpr) * NW + wid;
     const int hs = wy * 2 + (t >> 3), ws = wx * 8 + (t & 7);
     int hh = hs + a.sh; if (hh >= a.H) hh -= a.H;
     int ww = ws + a.sw; if (ww >= a.W) ww -= a.W;
     const size_t row = ((size_t)b * a.H + hh) * a.W + ww;
     const int lab = 3 * region(hs, a.H, 2, a.sh) + region(ws, a.W, 8, a.sw);
 
-    stage_weights(a.wqkv, 288, C, smem + OFF_A, PW, tid);
-    stage_weights(a.wproj, C, C, smem + OFF_WPROJ, PW, tid);
-    stage_weights(a.w2, C, HID, smem + OFF_W2, PW2, tid);
+    // the token's row: lane owns channels 16n + 4gq .. +3 (n = 0..5) -- the accumulator layout of every GEMM below
+    f32x4 xv[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const float4 u = *(const float4*)(a.xin + row * C + 16 * n + 4 * gq);
+        xv[n] = (f32x4){u.x, u.y, u.z, u.w};
+    }
+    // relative-position bias of this lane's (query t, keys 4gq..4gq+3), all heads (tulip.py:304-308)
+    float rpb[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = a.rel_index[t * 16 + gq * 4 + r] * 3;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) rpb[h][r] = a.bias_table[e + h];
+    }
+    stage_weights<288, C, PW>(a.wqkv, smem + OFF_A, tid);
+    stage_weights<C, C, PW>(a.wproj, smem + OFF_WPROJ, tid);
+    stage_weights<C, HID, PW2>(a.w2, smem + OFF_W2, tid);
+    for (int i = tid; i < P_N; i += NT) {
+        float v;
+        if (i < P_BQKV) v = a.b1[i];
+        else if (i < P_BPROJ) v = a.bqkv[i - P_BQKV];
+        else if (i < P_B2) v = a.bproj[i - P_BPROJ];
+        else if (i < P_G2) v = a.b2[i - P_B2];
+        else if (i < P_BE2) v = a.g2[i - P_G2];
+        else v = a.be2[i - P_BE2];
+        prm[i] = v;
+    }
 
-    // ---- norm1 (tulip.py:340): lane owns channels 32s + 8gq .. +7 (s = 0..2) of its token = its operand fragments
+    // ---- norm1 (tulip.py:340)
     bf16x8 xfrag[3];
     {
-        float xv[3][8];
         float s1 = 0.f;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const float* p = a.xin + row * C + 32 * s + 8 * gq;
-            const float4 u = *(const float4*)p, v = *(const float4*)(p + 4);
-            xv[s][0] = u.x; xv[s][1] = u.y; xv[s][2] = u.z; xv[s][3] = u.w;
-            xv[s][4] = v.x; xv[s][5] = v.y; xv[s][6] = v.z; xv[s][7] = v.w;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s1 += xv[s][e];
-        }
+        for (int n = 0; n < 6; ++n) s1 += (xv[n][0] + xv[n][1]) + (xv[n][2] + xv[n][3]);
         s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
         const float mu = s1 * (1.0f / C);
         float s2 = 0.f;
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int n = 0; n < 6; ++n)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mu; s2 += d * d; }
+            for (int r = 0; r < 4; ++r) { const float d = xv[n][r] - mu; s2 += d * d; }
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
         if (gq == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+        bf16x4 p1[6];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int c0 = 32 * s + 8 * gq;
-            const float4 ga = *(const float4*)(a.g1 + c0), gb = *(const float4*)(a.g1 + c0 + 4);
-            const float4 ba = *(const float4*)(a.be1 + c0), bb = *(const float4*)(a.be1 + c0 + 4);
-            const bf16x4 lo = pack4((xv[s][0] - mu) * rs * ga.x + ba.x, (xv[s][1] - mu) * rs * ga.y + ba.y,
-                                    (xv[s][2] - mu) * rs * ga.z + ba.z, (xv[s][3] - mu) * rs * ga.w + ba.w);
-            const bf16x4 hi = pack4((xv[s][4] - mu) * rs * gb.x + bb.x, (xv[s][5] - mu) * rs * gb.y + bb.y,
-                                    (xv[s][6] - mu) * rs * gb.z + bb.z, (xv[s][7] - mu) * rs * gb.w + bb.w);
-            xfrag[s] = cat8(lo, hi);
-            *(bf16x8*)(a.xn1 + row * C + c0) = xfrag[s];
+        for (int n = 0; n < 6; ++n) {
+            const int c0 = 16 * n + 4 * gq;
+            const float4 ga = *(const float4*)(a.g1 + c0), be = *(const float4*)(a.be1 + c0);
+            p1[n] = pack4((xv[n][0] - mu) * rs * ga.x + be.x, (xv[n][1] - mu) * rs * ga.y + be.y,
+                          (xv[n][2] - mu) * rs * ga.z + be.z, (xv[n][3] - mu) * rs * ga.w + be.w);
+            *(bf16x4*)(a.xn1 + row * C + c0) = p1[n];
         }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
     }
-    __syncthreads();                                        // weights of phase 1 (and W2) are in LDS
+    __syncthreads();                                        // weights of phase 1, W2 and the parameter vectors are in LDS
+    if (a.stop == 1) return;
 
     // ---- qkv Linear (tulip.py:298): acc lane = 4 consecutive output channels 16j + 4gq + r of token t
     bf16x4 qkvp[18];
@@ -136,11 +171,12 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
         const unsigned char* wr = smem + OFF_A + (16 * j + t) * PW;
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wr + (32 * s + 8 * gq) * 2), xfrag[s], acc, 0, 0, 0);
-        const float4 bq = *(const float4*)(a.bqkv + 16 * j + 4 * gq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), xfrag[s], acc, 0, 0, 0);
+        const float4 bq = *(const float4*)(prm + P_BQKV + 16 * j + 4 * gq);
         qkvp[j] = pack4(acc[0] + bq.x, acc[1] + bq.y, acc[2] + bq.z, acc[3] + bq.w);
         *(bf16x4*)(a.qkv + row * 288 + 16 * j + 4 * gq) = qkvp[j];
     }
+    if (a.stop == 2) return;
 
     // ---- attention, one head at a time (tulip.py:300-317); scores issued as K.Q^T: lane = query t, keys 4gq + r
     bf16x8 ofrag[3];
@@ -155,7 +191,7 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
         float mx = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float x = sc[r] * a.scale + a.bias_table[a.rel_index[t * 16 + gq * 4 + r] * 3 + h];
+            float x = sc[r] * a.scale + rpb[h][r];
             if (a.masked) {
                 const int kl = __shfl(lab, gq * 4 + r, 64);
                 if (kl != lab) x += -100.0f;
@@ -183,10 +219,10 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
         }
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
+    if (a.stop == 3) return;
 
-    // ---- proj Linear + DropPath + residual (tulip.py:318,344), then norm2 (:347)
+    // ---- proj Linear + DropPath + residual (tulip.py:318,344), then norm2 (:347); x1 replaces x in xv
     const float s0 = a.ds0 ? a.ds0[b] : 1.0f, s1v = a.ds1 ? a.ds1[b] : 1.0f;
-    f32x4 x1v[6];
     bf16x8 x2frag[3];
     {
         float sum = 0.f;
@@ -196,14 +232,13 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
             const unsigned char* wr = smem + OFF_WPROJ + (16 * n2 + t) * PW;
 #pragma unroll
             for (int h = 0; h < 3; ++h)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_perm(wr, 32 * h + 4 * gq), ofrag[h], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * h + 4 * gq), ofrag[h], acc, 0, 0, 0);
             const int c0 = 16 * n2 + 4 * gq;
-            const float4 bp = *(const float4*)(a.bproj + c0);
-            const float4 xr = *(const float4*)(a.xin + row * C + c0);
-            x1v[n2] = (f32x4){xr.x + s0 * (acc[0] + bp.x), xr.y + s0 * (acc[1] + bp.y), xr.z + s0 * (acc[2] + bp.z),
-                              xr.w + s0 * (acc[3] + bp.w)};
-            *(float4*)(a.x1 + row * C + c0) = make_float4(x1v[n2][0], x1v[n2][1], x1v[n2][2], x1v[n2][3]);
-            sum += (x1v[n2][0] + x1v[n2][1]) + (x1v[n2][2] + x1v[n2][3]);
+            const float4 bp = *(const float4*)(prm + P_BPROJ + c0);
+            xv[n2] = (f32x4){xv[n2][0] + s0 * (acc[0] + bp.x), xv[n2][1] + s0 * (acc[1] + bp.y),
+                             xv[n2][2] + s0 * (acc[2] + bp.z), xv[n2][3] + s0 * (acc[3] + bp.w)};
+            *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
+            sum += (xv[n2][0] + xv[n2][1]) + (xv[n2][2] + xv[n2][3]);
         }
         sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
         const float mu = sum * (1.0f / C);
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = x1v[n2][r] - mu; s2 += d * d; }
+            for (int r = 0; r < 4; ++r) { const float d = xv[n2][r] - mu; s2 += d * d; }
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
         if (gq == 0) { a.mean2[row] = mu; a.rstd2[row] = rs; }
@@ -219,19 +254,21 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2) {
             const int c0 = 16 * n2 + 4 * gq;
-            const float4 ga = *(const float4*)(a.g2 + c0), be = *(const float4*)(a.be2 + c0);
-            p2[n2] = pack4((x1v[n2][0] - mu) * rs * ga.x + be.x, (x1v[n2][1] - mu) * rs * ga.y + be.y,
-                           (x1v[n2][2] - mu) * rs * ga.z + be.z, (x1v[n2][3] - mu) * rs * ga.w + be.w);
+            const float4 ga = *(const float4*)(prm + P_G2 + c0), be = *(const float4*)(prm + P_BE2 + c0);
+            p2[n2] = pack4((xv[n2][0] - mu) * rs * ga.x + be.x, (xv[n2][1] - mu) * rs * ga.y + be.y,
+                           (xv[n2][2] - mu) * rs * ga.z + be.z, (xv[n2][3] - mu) * rs * ga.w + be.w);
             *(bf16x4*)(a.xn2 + row * C + c0) = p2[n2];
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s) x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
+        for (int s = 0; s < 3; ++s) x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
     }
+    if (a.stop == 4) return;
 
     // ---- fc1 weights replace qkv/proj weights in LDS
     __syncthreads();
-    stage_weights(a.w1, HID, C, smem + OFF_A, PW, tid);
+    stage_weights<HID, C, PW>(a.w1, smem + OFF_A, tid);
     __syncthreads();
+    if (a.stop == 5) return;
 
     // ---- fc1 -> exact-erf GELU -> fc2 (tulip.py:195-198), 32 hidden channels at a time, chained in registers
     f32x4 acc3[6];
@@ -247,9 +284,9 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
             const unsigned char* wr = smem + OFF_A + (16 * j + t) * PW;
 #pragma unroll
             for (int s = 0; s < 3; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_perm(wr, 32 * s + 4 * gq), x2frag[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), x2frag[s], acc, 0, 0, 0);
             const int c0 = 16 * j + 4 * gq;
-            const float4 bb = *(const float4*)(a.b1 + c0);
+            const float4 bb = *(const float4*)(prm + P_B1 + c0);
             const bf16x4 hp = pack4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
             *(bf16x4*)(a.h + row * HID + c0) = hp;
             gp[jj] = pack4(gelu_exact(bf2f((bf16_t)hp[0])), gelu_exact(bf2f((bf16_t)hp[1])),
@@ -259,23 +296,23 @@ __global__ __launch_bounds__(256) void swin96_fwd_kernel(const Swin96Args a) {
         const bf16x8 gf = cat8(gp[0], gp[1]);
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
-            acc3[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_perm(smem + OFF_W2 + (16 * n2 + t) * PW2, 32 * p + 4 * gq),
-                                                               gf, acc3[n2], 0, 0, 0);
+            acc3[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(smem + OFF_W2 + (16 * n2 + t) * PW2, 32 * p + 4 * gq), gf,
+                                                               acc3[n2], 0, 0, 0);
     }
 #pragma unroll
     for (int n2 = 0; n2 < 6; ++n2) {
         const int c0 = 16 * n2 + 4 * gq;
-        const float4 bb = *(const float4*)(a.b2 + c0);
+        const float4 bb = *(const float4*)(prm + P_B2 + c0);
         *(float4*)(a.xout + row * C + c0) =
-            make_float4(x1v[n2][0] + s1v * (acc3[n2][0] + bb.x), x1v[n2][1] + s1v * (acc3[n2][1] + bb.y),
-                        x1v[n2][2] + s1v * (acc3[n2][2] + bb.z), x1v[n2][3] + s1v * (acc3[n2][3] + bb.w));
+            make_float4(xv[n2][0] + s1v * (acc3[n2][0] + bb.x), xv[n2][1] + s1v * (acc3[n2][1] + bb.y),
+                        xv[n2][2] + s1v * (acc3[n2][2] + bb.z), xv[n2][3] + s1v * (acc3[n2][3] + bb.w));
     }
 }
 
 }  // namespace
 
 extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream) {
-    if (!d || d->B <= 0 || d->H <= 0 || (d->H & 1) || d->W <= 0 || (d->W & 31) || d->shift_h < 0 ||
+    if (!d || d->B <= 0 || d->H <= 0 || (d->H & 1) || d->W <= 0 || (d->W & 63) || d->shift_h < 0 ||
         d->shift_h >= d->H || d->shift_w < 0 || d->shift_w >= d->W)
         return TULIP_ERR_ARG;
     Swin96Args a;
@@ -290,8 +327,9 @@ extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t st
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
-    const int blocks = d->B * (d->H / 2) * (d->W / 32);
-    hipLaunchKernelGGL(swin96_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    a.stop = getenv("TULIP_SWIN96_STOP") ? atoi(getenv("TULIP_SWIN96_STOP")) : 0;
+    const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
+    hipLaunchKernelGGL(swin96_fwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

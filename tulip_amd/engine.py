@@ -377,11 +377,30 @@ class TulipEngine:
             return None
         return P.drop_scale.data_ptr() + 4 * (sp.slot + branch) * P.B
 
+    fuse_block96 = os.environ.get("TULIP_FUSE_BLOCK96", "1") != "0"
+
     def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout):
         W_ = self.params
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
+        if (self.fuse_block96 and C == 96 and nh == 3 and Hd == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
+                and sp.H % 2 == 0):
+            # stage 0: the whole block in one launch (csrc/swin96.hip); writes the same tensors as the sequence below
+            ops.swin96_block_fwd(
+                x_in=xin, x1=P[p + ".x1"], x_out=xout, xn1=P[p + ".xn1"], qkv=P[p + ".qkv"], attn_out=P[p + ".o"],
+                xn2=P[p + ".xn2"], fc1_pre=P[p + ".h"], fc1_act=P[p + ".g"], mean1=P[p + ".mean1"],
+                rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
+                w_qkv=W_.p16(p + ".attn.qkv.weight"), w_proj=W_.p16(p + ".attn.proj.weight"),
+                w_fc1=W_.p16(p + ".mlp.fc1.weight"), w_fc2=W_.p16(p + ".mlp.fc2.weight"),
+                b_qkv=W_.p32(p + ".attn.qkv.bias"), b_proj=W_.p32(p + ".attn.proj.bias"),
+                b_fc1=W_.p32(p + ".mlp.fc1.bias"), b_fc2=W_.p32(p + ".mlp.fc2.bias"),
+                norm1_weight=W_.p32(p + ".norm1.weight"), norm1_bias=W_.p32(p + ".norm1.bias"),
+                norm2_weight=W_.p32(p + ".norm2.weight"), norm2_bias=W_.p32(p + ".norm2.bias"),
+                bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
+                drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=B, H=sp.H, W=sp.W,
+                shift_h=sp.sft[0], shift_w=sp.sft[1], masked=int(sp.shift), eps=self.eps)
+            return
         ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
                           P[p + ".mean1"], P[p + ".rstd1"], M, C, self.eps)
         self._gemm(P[p + ".xn1"], W_.p16(p + ".attn.qkv.weight"), M, 3 * C, C, lda=C, ldb=C, epi=EPI_BF16,
