@@ -281,6 +281,29 @@ typedef struct tulip_swin96_desc {
 } tulip_swin96_desc;
 int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream);
 
+/* Backward of the same block in ONE launch (replaces, for C = 96, the chain tulip_gemm_bf16(EPI_GELU_BWD) ->
+ * tulip_gemm_bf16 -> tulip_layernorm_bwd -> tulip_gemm_bf16 -> tulip_window_attn_bwd -> tulip_gemm_bf16 ->
+ * tulip_layernorm_bwd; autograd of tulip.py:338-352).  dx holds d(block output) on entry and d(block input) on
+ * return.  The kernel also writes the bf16 operands of the four weight-gradient GEMMs -- d_out_mlp = bf16(dx*s_mlp)
+ * [M][96], d_fc1_pre [M][384], d_out_attn = bf16(d(x1)*s_attn) [M][96], d_qkv [M][288] -- and ONE partial row per
+ * workgroup (tulip_swin96_bwd_partial_rows of them) for each of: norm1 / norm2 affine gradients ([rows][192] =
+ * d(weight) | d(bias), folded by tulip_reduce_rows2) and the dense relative-position-bias gradient ([rows][3*256],
+ * folded by tulip_reduce_rows_set + tulip_bias_table_scatter).  dx_bf16 (optional): bf16(dx * dx_bf16_scale[sample]). */
+typedef struct tulip_swin96_bwd_desc {
+    float* dx; const float* x_in; const float* x1;
+    const void* qkv; const void* fc1_pre;
+    const float* mean1; const float* rstd1; const float* mean2; const float* rstd2;
+    const void* w_qkv; const void* w_proj; const void* w_fc1; const void* w_fc2;
+    const float* norm1_weight; const float* norm2_weight;
+    const float* bias_table; const int32_t* rel_index; const float* drop_scale_attn; const float* drop_scale_mlp;
+    void* d_out_mlp; void* d_fc1_pre; void* d_out_attn; void* d_qkv;
+    void* dx_bf16; const float* dx_bf16_scale;
+    float* norm1_partials; float* norm2_partials; float* bias_partials;
+    int B; int H; int W; int shift_h; int shift_w; int masked;
+} tulip_swin96_bwd_desc;
+int tulip_swin96_bwd_partial_rows(int B, int H, int W);
+int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream);
+
 /* library self-description */
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);

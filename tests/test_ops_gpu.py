@@ -560,6 +560,8 @@ def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted):
                 p.add_(0.2 * torch.randn_like(p))
     eng = m.engine()
     eng.bind(torch.device(DEV, torch.cuda.current_device()))
+    eng.params.refresh_shadow()                                # bf16 weights the kernels read
+    assert eng.params.shadow.float().abs().sum().item() > 0
     saved, eng.fuse_block96 = getattr(eng, "fuse_block96", False), False
     P = eng.plan(2)
     sp = eng.enc_blocks[0][1 if shifted else 0]
@@ -602,3 +604,67 @@ def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted):
         assert (d.norm() / (b.norm() + 1e-12)).item() <= 3e-3, k
     if sp.slot >= 0:       # sample 0 had both branches dropped (block 0 of the network has DropPath rate 0: no slot)
         assert torch.equal(buf["out"][: M // 2], x[: M // 2])
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_swin96_fused_block_backward_matches_separate_kernels(ops, shifted):
+    """tulip_swin96_block_bwd (one launch for the data-gradient chain of a stage-0 Swin block) against the 7-kernel chain
+    it replaces: the input gradient, the four weight-gradient operands it hands to the side streams, and every
+    parameter gradient of the block after the folds."""
+    from tulip_amd.model.tulip import tulip_base
+    torch.manual_seed(1)
+    m = tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), patch_size=(1, 4), in_chans=1, window_size=[2, 8],
+                   pixel_shuffle=True, circular_padding=True, log_transform=True, patch_unmerging=True).to(DEV).train()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim == 1 or "relative_position_bias_table" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    eng = m.engine()
+    eng.bind(torch.device(DEV, torch.cuda.current_device()))
+    eng.params.refresh_shadow()
+    saved = (eng.fuse_block96, eng.fuse_block96_bwd, eng.overlap_wgrad)
+    eng.overlap_wgrad = False                                 # weight gradients and folds inline, on this stream
+    B = 2
+    P = eng.plan(B)
+    sp = eng.enc_blocks[0][1 if shifted else 0]
+    p = sp.prefix
+    M = B * sp.H * sp.W
+    xin = P["enc0.in"]
+    xin.copy_((torch.randn(M, 96, device=DEV) * 1.5 + 0.2).view_as(xin))
+    du = torch.rand(eng.n_drop_slots, 2, device=DEV)
+    du[:, 0] = 0.01
+    eng.draw_drop_scales(P, True, du)
+    out = torch.empty(M, 96, device=DEV)
+    eng.fuse_block96 = False
+    eng._block_fwd(P, sp, xin, out)
+    dy = torch.randn(M, 96, device=DEV)
+    cast_buf = torch.zeros(M, 96, device=DEV, dtype=torch.bfloat16)
+    res = {}
+    for fused in (False, True):
+        eng.fuse_block96_bwd = fused
+        gflat = torch.zeros(eng.params.total, device=DEV)
+        G = lambda name: gflat.data_ptr() + 4 * eng.params.offset[name]
+        dx = dy.clone()
+        cast_buf.zero_()
+        eng._pending, eng._lagged_hook = [], None
+        eng._block_bwd(P, sp, xin, dx, G, have_dyb=False, next_cast=(cast_buf, None, 1))
+        torch.cuda.synchronize()
+        r = {"dx": dx.clone(), "dx_bf16": cast_buf.float().clone(), "dh": P[p + ".dh"].float().clone(),
+             "dqkv": P[p + ".dqkv"].float().clone(), "dyb_a": P[p + ".dyb_a"].float().clone(),
+             "dyb_m": P[p + ".dyb_m"].float().clone()}
+        for n, q in m.named_parameters():
+            if n.startswith(p + "."):
+                o = eng.params.offset[n]
+                r["g:" + n[len(p) + 1:]] = gflat[o:o + q.numel()].clone()
+        res[fused] = r
+    eng.fuse_block96, eng.fuse_block96_bwd, eng.overlap_wgrad = saved
+    assert any(k.startswith("g:attn.relative_position_bias_table") for k in res[True])
+    for k, ref in res[False].items():
+        a, b = res[True][k].reshape(-1), ref.reshape(-1)
+        assert torch.isfinite(a).all(), k
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        assert b.norm().item() > 0, k
+        # the unfused chain rounds d(norm input) to bf16 between its kernels, the fused one keeps it in fp32
+        assert rel <= 6e-3, (k, rel)
+    if sp.slot >= 0:       # sample 0: both branches dropped -> the block is the identity there
+        assert torch.equal(res[True]["dx"][: M // 2], dy[: M // 2])

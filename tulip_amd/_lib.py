@@ -23,10 +23,21 @@ class Swin96Desc(ctypes.Structure):
                [(n, I) for n in ("B", "H", "W", "shift_h", "shift_w", "masked")] + [("eps", F)]
 
 
+class Swin96BwdDesc(ctypes.Structure):
+    """tulip_swin96_bwd_desc (include/tulip_hip.h)."""
+    _fields_ = [(n, P) for n in ("dx", "x_in", "x1", "qkv", "fc1_pre", "mean1", "rstd1", "mean2", "rstd2", "w_qkv",
+                                 "w_proj", "w_fc1", "w_fc2", "norm1_weight", "norm2_weight", "bias_table", "rel_index",
+                                 "drop_scale_attn", "drop_scale_mlp", "d_out_mlp", "d_fc1_pre", "d_out_attn", "d_qkv",
+                                 "dx_bf16", "dx_bf16_scale", "norm1_partials", "norm2_partials", "bias_partials")] + \
+               [(n, I) for n in ("B", "H", "W", "shift_h", "shift_w", "masked")]
+
+
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P, L, P],
     "tulip_swin96_block_fwd": [P, P],
+    "tulip_swin96_block_bwd": [P, P],
+    "tulip_swin96_bwd_partial_rows": [I, I, I],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],

@@ -309,6 +309,376 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     }
 }
 
+
+// =====================================================================================================================
+// backward of the same block in one launch: the whole chain fc2' -> GELU' -> fc1' -> norm2' -> proj' -> attention' ->
+// qkv' -> norm1' stays in registers, one window per wave.  The four data-gradient GEMMs contract over the OUTPUT
+// channels of their Linear, i.e. they need W^T as the MFMA A operand: the weights sit in LDS in their natural
+// [out][in] layout and are read through ds_read_b64_tr_b16 (rows padded to 32 B x odd so that the 16 x 32-byte
+// blocks of a transpose read are bank-conflict free).  What leaves the kernel: the input gradient (fp32, in place),
+// the bf16 operands of the four weight-gradient GEMMs (which run beside the chain as before), and one partial row per
+// workgroup for the LayerNorm affine gradients and the dense relative-position-bias gradient.
+constexpr int PT = 224;                          // 96-wide bf16 row read transposed
+constexpr int PT2 = 800;                         // 384-wide bf16 row read transposed
+constexpr int BOFF_W2 = 0;                       // MLP half: fc2.weight [96][384] | fc1.weight [384][96]
+constexpr int BOFF_W1 = 96 * PT2;
+constexpr int BOFF_WQKV = 0;                     // attention half: qkv.weight [288][96] | proj.weight [96][96]
+constexpr int BOFF_WPROJ = 288 * PT;
+constexpr int BOFF_T = BOFF_WPROJ + 96 * PT;     // NW x (Q | K | dO) 1-KiB tiles
+constexpr int BOFF_RED = BOFF_T + NW * 3072;     // fp32 [NW][192] norm2 | [NW][192] norm1 | [NW][768] bias partial sums
+constexpr int BOFF_GAM = BOFF_W1 + 384 * PT;     // 162816: norm2.weight[96] norm1.weight[96] fp32 (beyond both layouts)
+constexpr int BSMEM = BOFF_GAM + 2 * C * 4;
+static_assert(BOFF_RED + NW * (192 + 192 + 768) * 4 <= BOFF_GAM, "attention-half layout overlaps the norm weights");
+static_assert(BSMEM <= 163840, "LDS");
+
+struct Swin96BwdArgs {
+    float* dx;                                   // in: d(block output); out: d(block input)
+    const float *xin, *x1;
+    const bf16_t *qkv, *h;
+    const float *mean1, *rstd1, *mean2, *rstd2;
+    const bf16_t *wqkv, *wproj, *w1, *w2;
+    const float *g1, *g2;
+    const float* bias_table; const int* rel_index;
+    const float *ds0, *ds1;
+    bf16_t *dyb_m, *dh, *dyb_a, *dqkv;           // bf16 operands of the fc2 / fc1 / proj / qkv weight gradients
+    bf16_t* dx_bf16; const float* dx_scale;      // optional bf16(dx * per-sample scale) for the consumer of dx
+    float *lnpart1, *lnpart2, *biaspart;         // [workgroups][192], [workgroups][192], [workgroups][768]
+    int B, H, W, sh, sw, masked;
+    float scale;
+    int stop;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x4 trr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p);
+}
+// A fragment of W^T in the chained k order from W stored [k][n]: lane (t, gq) gets W[k0 + 4gq + e][n0 + t] in k slots
+// e = 0..3 and W[k0 + 16 + 4gq + e][n0 + t] in slots 4..7
+__device__ __forceinline__ bf16x8 wfrag_t(const unsigned char* w, int pitch, int k0, int n0, int t, int gq) {
+    const unsigned char* p = w + (k0 + 4 * gq + (t >> 2)) * pitch + (n0 + (t & 3) * 4) * 2;
+    return cat8(trr(p), trr(p + 16 * pitch));
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <int ROWS, int COLS>
+struct Staged { u32x4 v[(ROWS * COLS / 8 + NT - 1) / NT]; };
+template <int ROWS, int COLS>
+__device__ __forceinline__ void stage_load(const bf16_t* __restrict__ w, Staged<ROWS, COLS>& st, int tid) {
+    constexpr int CPR = COLS / 8, N = ROWS * CPR, PER = (N + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = (N % NT == 0 || tid + i * NT < N) ? tid + i * NT : N - 1;     // tail threads re-read the last chunk
+        st.v[i] = *(const u32x4*)(w + (size_t)(c / CPR) * COLS + (c % CPR) * 8);
+    }
+}
+template <int ROWS, int COLS, int PITCH>
+__device__ __forceinline__ void stage_store(const Staged<ROWS, COLS>& st, unsigned char* dst, int tid) {
+    constexpr int CPR = COLS / 8, N = ROWS * CPR, PER = (N + NT - 1) / NT;
+    static_assert(PITCH % 16 == 0, "16-byte LDS stores");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + i * NT;
+        if (N % NT == 0 || c < N) *(u32x4*)(dst + (c / CPR) * PITCH + (c % CPR) * 16) = st.v[i];
+    }
+}
+// one halving step of the 16-lane reduce-scatter: after the steps with m = 8, 4, 2, 1 on 48 values, lane t holds the
+// sums over the 16 token lanes of values 3t .. 3t+2 in v[0..2]
+template <int HALF, int M>
+__device__ __forceinline__ void halve(float (&v)[48], int t) {
+    const bool up = (t & M) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const float a = v[i], b = v[HALF + i];
+        v[i] = (up ? b : a) + __shfl_xor(up ? a : b, M, 64);
+    }
+}
+// LayerNorm backward of one token row held as 6 x 4 channels (16n + 4gq + r): d <- rstd*(d*gamma - m1 - xhat*m2);
+// the affine-gradient terms d*xhat | d of the 16 tokens of the wave are reduce-scattered into red[0..2]
+__device__ __forceinline__ void ln_bwd_row(f32x4 (&d)[6], const f32x4 (&xv)[6], float mu, float rs, const float* gam,
+                                           int t, int gq, float (&red)[3]) {
+    float v[48];
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 xh[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const float4 ga = *(const float4*)(gam + 16 * n + 4 * gq);
+        const float gv[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xh[n][r] = (xv[n][r] - mu) * rs;
+            v[4 * n + r] = d[n][r] * xh[n][r];
+            v[24 + 4 * n + r] = d[n][r];
+            d[n][r] *= gv[r];
+            s1 += d[n][r];
+            s2 += d[n][r] * xh[n][r];
+        }
+    }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[n][r] = rs * (d[n][r] - m1 - xh[n][r] * m2);
+    halve<24, 8>(v, t); halve<12, 4>(v, t); halve<6, 2>(v, t); halve<3, 1>(v, t);
+    red[0] = v[0]; red[1] = v[1]; red[2] = v[2];
+}
+// value q = 3t + i of the reduce-scatter is [d*xhat | d][channel 16n + 4gq + r] with q = 24*which + 4n + r
+__device__ __forceinline__ void put_red(float* row, const float (&red)[3], int t, int gq) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = 3 * t + i, which = q / 24, n = (q % 24) >> 2, r = q & 3;
+        row[which * C + 16 * n + 4 * gq + r] = red[i];
+    }
+}
+
+__global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BSMEM];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
+    float* gam = (float*)(smem + BOFF_GAM);
+
+    const int nWx = a.W >> 3, nWy = a.H >> 1, gpr = nWx / NW;
+    int blk = blockIdx.x;
+    const int b = blk / (nWy * gpr);
+    blk -= b * nWy * gpr;
+    const int wy = blk / gpr, wx = (blk - wy * gpr) * NW + wid;
+    const int hs = wy * 2 + (t >> 3), ws = wx * 8 + (t & 7);
+    int hh = hs + a.sh; if (hh >= a.H) hh -= a.H;
+    int ww = ws + a.sw; if (ww >= a.W) ww -= a.W;
+    const size_t row = ((size_t)b * a.H + hh) * a.W + ww;
+    const int lab = 3 * region(hs, a.H, 2, a.sh) + region(ws, a.W, 8, a.sw);
+    const float s0 = a.ds0 ? a.ds0[b] : 1.0f, s1v = a.ds1 ? a.ds1[b] : 1.0f;
+
+    // ---- stage fc2 / fc1 weights; meanwhile fetch the incoming gradient row and the norm2 input row
+    {
+        Staged<C, HID> w2s; Staged<HID, C> w1s;
+        stage_load<C, HID>(a.w2, w2s, tid);
+        stage_load<HID, C>(a.w1, w1s, tid);
+        stage_store<C, HID, PT2>(w2s, smem + BOFF_W2, tid);
+        stage_store<HID, C, PT>(w1s, smem + BOFF_W1, tid);
+    }
+    if (tid < 2 * C) gam[tid] = tid < C ? a.g2[tid] : a.g1[tid - C];
+    f32x4 dy[6], x1v[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const float4 u = *(const float4*)(a.dx + row * C + 16 * n + 4 * gq);
+        dy[n] = (f32x4){u.x, u.y, u.z, u.w};
+    }
+    bf16x8 dyf[3];
+    {
+        bf16x4 pk[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            pk[n] = pack4(dy[n][0] * s1v, dy[n][1] * s1v, dy[n][2] * s1v, dy[n][3] * s1v);
+            *(bf16x4*)(a.dyb_m + row * C + 16 * n + 4 * gq) = pk[n];
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dyf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
+    }
+    const float mu2 = a.mean2[row], rs2 = a.rstd2[row];
+    // relative-position bias seen from the query side (query t, key 4gq+r) and from the key side (query 4gq+r, key t)
+    float bias_q[3][4], bias_k[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int eq = a.rel_index[t * 16 + gq * 4 + r] * 3, ek = a.rel_index[(gq * 4 + r) * 16 + t] * 3;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) { bias_q[h][r] = a.bias_table[eq + h]; bias_k[h][r] = a.bias_table[ek + h]; }
+    }
+    __syncthreads();
+    if (a.stop == 1) return;
+
+    // ---- MLP half (tulip.py:346-351 backwards): per 32 hidden channels  dg = dy.W2 -> dh = dg*gelu'(h) -> dxn2 += dh.W1
+    f32x4 acc2[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) acc2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* hrow = a.h + row * HID + 4 * gq;
+    bf16x4 hn[2] = {*(const bf16x4*)(hrow), *(const bf16x4*)(hrow + 16)};
+#pragma unroll 2
+    for (int p = 0; p < 12; ++p) {
+        const bf16x4 hc[2] = {hn[0], hn[1]};
+        if (p + 1 < 12) { hn[0] = *(const bf16x4*)(hrow + 32 * (p + 1)); hn[1] = *(const bf16x4*)(hrow + 32 * (p + 1) + 16); }
+        bf16x4 dp[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j0 = 32 * p + 16 * jj;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_W2, PT2, 32 * s, j0, t, gq), dyf[s], acc, 0, 0, 0);
+            dp[jj] = pack4(acc[0] * gelu_exact_grad(bf2f((bf16_t)hc[jj][0])), acc[1] * gelu_exact_grad(bf2f((bf16_t)hc[jj][1])),
+                           acc[2] * gelu_exact_grad(bf2f((bf16_t)hc[jj][2])), acc[3] * gelu_exact_grad(bf2f((bf16_t)hc[jj][3])));
+            *(bf16x4*)(a.dh + row * HID + j0 + 4 * gq) = dp[jj];
+        }
+        const bf16x8 df = cat8(dp[0], dp[1]);
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+            acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_W1, PT, 32 * p, 16 * n, t, gq), df, acc2[n], 0, 0, 0);
+    }
+    if (a.stop == 2) return;
+
+    // ---- the attention-half weights are fetched while norm2 is differentiated
+    Staged<288, C> wqs; Staged<C, C> wps;
+    stage_load<288, C>(a.wqkv, wqs, tid);
+    stage_load<C, C>(a.wproj, wps, tid);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const float4 u = *(const float4*)(a.x1 + row * C + 16 * n + 4 * gq);
+        x1v[n] = (f32x4){u.x, u.y, u.z, u.w};
+    }
+    float red2[3];
+    ln_bwd_row(acc2, x1v, mu2, rs2, gam, t, gq, red2);
+    // dx1 = d(x1) = dy + norm2'(dxn2)   (residual, tulip.py:351); from here on dy holds dx1
+    bf16x8 daf[3];
+    {
+        bf16x4 pk[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            dy[n] += acc2[n];
+            pk[n] = pack4(dy[n][0] * s0, dy[n][1] * s0, dy[n][2] * s0, dy[n][3] * s0);
+            *(bf16x4*)(a.dyb_a + row * C + 16 * n + 4 * gq) = pk[n];
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) daf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
+    }
+    // q, k, v of this token, all heads, in the chained k order (dims 4gq.., 16+4gq.. of each head)
+    bf16x4 qkvr[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) qkvr[j] = *(const bf16x4*)(a.qkv + row * 288 + 16 * j + 4 * gq);
+    const float mu1 = a.mean1[row], rs1 = a.rstd1[row];
+    __syncthreads();                                          // every wave is done with fc1 / fc2 weights
+    stage_store<288, C, PT>(wqs, smem + BOFF_WQKV, tid);
+    stage_store<C, C, PT>(wps, smem + BOFF_WPROJ, tid);
+    float* redw = (float*)(smem + BOFF_RED);
+    put_red(redw + wid * 192, red2, t, gq);
+    __syncthreads();
+    if (a.stop == 3) return;
+
+    // ---- proj' : dO = dyb_a . Wproj   (tulip.py:318 backwards)
+    bf16x4 dop[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_WPROJ, PT, 32 * s, 16 * n, t, gq), daf[s], acc, 0, 0, 0);
+        dop[n] = pack4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    // ---- attention' per head (tulip.py:300-317 backwards; same algebra as attn_bwd_kernel)
+    unsigned char* ldsQ = smem + BOFF_T + wid * 3072;
+    unsigned char* ldsK = ldsQ + 1024;
+    unsigned char* ldsD = ldsK + 1024;
+    float* redb = redw + NW * 384 + wid * 768;
+    bf16x4 dqkvp[18];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const int troff = (gq * 4 + (t >> 2)) * 64 + (t & 3) * 8;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const bf16x8 qf = cat8(qkvr[2 * h], qkvr[2 * h + 1]);
+        const bf16x8 kf = cat8(qkvr[6 + 2 * h], qkvr[7 + 2 * h]);
+        const bf16x8 vf = cat8(qkvr[12 + 2 * h], qkvr[13 + 2 * h]);
+        const bf16x8 df = cat8(dop[2 * h], dop[2 * h + 1]);
+        const int o0 = t * 64 + (4 * gq) * 2, o1 = t * 64 + (16 + 4 * gq) * 2;
+        *(bf16x4*)(ldsQ + o0) = qkvr[2 * h];      *(bf16x4*)(ldsQ + o1) = qkvr[2 * h + 1];
+        *(bf16x4*)(ldsK + o0) = qkvr[6 + 2 * h];  *(bf16x4*)(ldsK + o1) = qkvr[7 + 2 * h];
+        *(bf16x4*)(ldsD + o0) = dop[2 * h];       *(bf16x4*)(ldsD + o1) = dop[2 * h + 1];
+        f32x4 sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);    // S[t][4gq+r]
+        f32x4 sk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);    // S[4gq+r][t]
+        f32x4 dpq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df, z, 0, 0, 0);   // dP[t][4gq+r]
+        f32x4 dpk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, z, 0, 0, 0);   // dP[4gq+r][t]
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float xq = sq[r] * a.scale + bias_q[h][r];
+            float xk = sk[r] * a.scale + bias_k[h][r];
+            if (a.masked) {
+                const int ol = __shfl(lab, gq * 4 + r, 64);
+                if (ol != lab) { xq += -100.0f; xk += -100.0f; }
+            }
+            sq[r] = xq; sk[r] = xk;
+            mx = fmaxf(mx, xq);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += __expf(sq[r] - mx);
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float lse = mx + __logf(sum);
+        float pq[4], pk[4], delta = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pq[r] = __expf(sq[r] - lse);
+            pk[r] = __expf(sk[r] - __shfl(lse, gq * 4 + r, 64));
+            delta += pq[r] * dpq[r];
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        float dsq[4], dsk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dsq[r] = pq[r] * (dpq[r] - delta);
+            dsk[r] = pk[r] * (dpk[r] - __shfl(delta, gq * 4 + r, 64));
+        }
+        *(float4*)(redb + h * 256 + t * 16 + gq * 4) = make_float4(dsq[0], dsq[1], dsq[2], dsq[3]);
+        const bf16x4 dsq_b = pack4(dsq[0], dsq[1], dsq[2], dsq[3]);
+        const bf16x4 dsk_b = pack4(dsk[0], dsk[1], dsk[2], dsk[3]);
+        const bf16x4 pk_b = pack4(pk[0], pk[1], pk[2], pk[3]);
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) {
+            const bf16x4 kt = trr(ldsK + troff + dc * 32);     // K[4gq+e][16dc+t]
+            const bf16x4 qt = trr(ldsQ + troff + dc * 32);
+            const bf16x4 dt = trr(ldsD + troff + dc * 32);
+            const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, dsq_b, z, 0, 0, 0);   // dQ[t][16dc+4gq+r] / scale
+            const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt, dsk_b, z, 0, 0, 0);
+            const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt, pk_b, z, 0, 0, 0);
+            dqkvp[2 * h + dc] = pack4(dq[0] * a.scale, dq[1] * a.scale, dq[2] * a.scale, dq[3] * a.scale);
+            dqkvp[6 + 2 * h + dc] = pack4(dk[0] * a.scale, dk[1] * a.scale, dk[2] * a.scale, dk[3] * a.scale);
+            dqkvp[12 + 2 * h + dc] = pack4(dv[0], dv[1], dv[2], dv[3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 18; ++j) *(bf16x4*)(a.dqkv + row * 288 + 16 * j + 4 * gq) = dqkvp[j];
+    if (a.stop == 4) return;
+
+    // ---- qkv' : dxn1 = dqkv . Wqkv  (tulip.py:298 backwards), then norm1' and the residual
+    f32x4 acc1[6], xv[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const float4 u = *(const float4*)(a.xin + row * C + 16 * n + 4 * gq);
+        xv[n] = (f32x4){u.x, u.y, u.z, u.w};
+        acc1[n] = z;
+    }
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const bf16x8 f = cat8(dqkvp[2 * s], dqkvp[2 * s + 1]);
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+            acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_WQKV, PT, 32 * s, 16 * n, t, gq), f, acc1[n], 0, 0, 0);
+    }
+    float red1[3];
+    ln_bwd_row(acc1, xv, mu1, rs1, gam + C, t, gq, red1);
+    const float cs = a.dx_scale ? a.dx_scale[b] : 1.0f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const f32x4 o = dy[n] + acc1[n];
+        *(float4*)(a.dx + row * C + 16 * n + 4 * gq) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.dx_bf16) *(bf16x4*)(a.dx_bf16 + row * C + 16 * n + 4 * gq) = pack4(o[0] * cs, o[1] * cs, o[2] * cs, o[3] * cs);
+    }
+    put_red(redw + NW * 192 + wid * 192, red1, t, gq);
+    __syncthreads();
+    // ---- one partial row per workgroup: waves summed in a fixed order
+    for (int i = tid; i < 192 + 192 + 768; i += NT) {
+        const float* src; float* dst; int stride;
+        if (i < 192) { src = redw + i; stride = 192; dst = a.lnpart2 + (size_t)blockIdx.x * 192 + i; }
+        else if (i < 384) { src = redw + NW * 192 + (i - 192); stride = 192; dst = a.lnpart1 + (size_t)blockIdx.x * 192 + (i - 192); }
+        else { src = redw + NW * 384 + (i - 384); stride = 768; dst = a.biaspart + (size_t)blockIdx.x * 768 + (i - 384); }
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sacc += src[w * stride];
+        *dst = sacc;
+    }
+}
+
 }  // namespace
 
 extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream) {
@@ -330,6 +700,36 @@ extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t st
     a.stop = getenv("TULIP_SWIN96_STOP") ? atoi(getenv("TULIP_SWIN96_STOP")) : 0;
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
     hipLaunchKernelGGL(swin96_fwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_swin96_bwd_partial_rows(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || (H & 1) || W <= 0 || (W & 63)) return 0;
+    return B * (H / 2) * (W / (8 * NW));
+}
+
+extern "C" int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream) {
+    if (!d || d->B <= 0 || d->H <= 0 || (d->H & 1) || d->W <= 0 || (d->W & 63) || d->shift_h < 0 ||
+        d->shift_h >= d->H || d->shift_w < 0 || d->shift_w >= d->W)
+        return TULIP_ERR_ARG;
+    Swin96BwdArgs a;
+    a.dx = d->dx; a.xin = d->x_in; a.x1 = d->x1;
+    a.qkv = (const bf16_t*)d->qkv; a.h = (const bf16_t*)d->fc1_pre;
+    a.mean1 = d->mean1; a.rstd1 = d->rstd1; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
+    a.wqkv = (const bf16_t*)d->w_qkv; a.wproj = (const bf16_t*)d->w_proj; a.w1 = (const bf16_t*)d->w_fc1;
+    a.w2 = (const bf16_t*)d->w_fc2;
+    a.g1 = d->norm1_weight; a.g2 = d->norm2_weight;
+    a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
+    a.dyb_m = (bf16_t*)d->d_out_mlp; a.dh = (bf16_t*)d->d_fc1_pre; a.dyb_a = (bf16_t*)d->d_out_attn;
+    a.dqkv = (bf16_t*)d->d_qkv;
+    a.dx_bf16 = (bf16_t*)d->dx_bf16; a.dx_scale = d->dx_bf16_scale;
+    a.lnpart1 = d->norm1_partials; a.lnpart2 = d->norm2_partials; a.biaspart = d->bias_partials;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
+    a.scale = 0.17677669529663687f;
+    a.stop = getenv("TULIP_SWIN96_STOP") ? atoi(getenv("TULIP_SWIN96_STOP")) : 0;
+    const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
+    hipLaunchKernelGGL(swin96_bwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

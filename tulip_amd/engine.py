@@ -378,14 +378,19 @@ class TulipEngine:
         return P.drop_scale.data_ptr() + 4 * (sp.slot + branch) * P.B
 
     fuse_block96 = os.environ.get("TULIP_FUSE_BLOCK96", "1") != "0"
+    fuse_block96_bwd = os.environ.get("TULIP_FUSE_BLOCK96_BWD", "1") != "0"
+
+    def _fusable96(self, sp: BlockSpec) -> bool:
+        """csrc/swin96.hip covers the embed-width-96 block: 3 heads x 32, window 2x8, MLP 96 -> 384 -> 96."""
+        return (sp.C == 96 and sp.nh == 3 and self.hidden(sp.C) == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
+                and sp.H % 2 == 0)
 
     def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout):
         W_ = self.params
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
-        if (self.fuse_block96 and C == 96 and nh == 3 and Hd == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
-                and sp.H % 2 == 0):
+        if self.fuse_block96 and self._fusable96(sp):
             # stage 0: the whole block in one launch (csrc/swin96.hip); writes the same tensors as the sequence below
             ops.swin96_block_fwd(
                 x_in=xin, x1=P[p + ".x1"], x_out=xout, xn1=P[p + ".xn1"], qkv=P[p + ".qkv"], attn_out=P[p + ".o"],
@@ -608,6 +613,8 @@ class TulipEngine:
 
     def _mlp_cast(self, P: Plan, sp: BlockSpec):
         """What the producer of this block's incoming gradient should emit: (dyb_m, DropPath scale, tokens)."""
+        if self.fuse_block96_bwd and self._fusable96(sp):
+            return None                     # the fused block backward forms its own operand from the fp32 gradient
         return (P[sp.prefix + ".dyb_m"], self._ds(P, sp, 1), sp.H * sp.W)
 
     def _block_bwd(self, P: Plan, sp: BlockSpec, xin, dx, G, have_dyb=False, next_cast=None):
@@ -620,6 +627,47 @@ class TulipEngine:
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
         dxn, dO, dh, dqkv = P["t.dxn"], P["t.do"], P[p + ".dh"], P[p + ".dqkv"]
         dyb = P[p + ".dyb_m"]
+        if self._fusable96(sp) and self.fuse_block96_bwd:
+            # the whole data-gradient chain of the block in one launch (csrc/swin96.hip); the weight gradients and the
+            # folds of its per-workgroup partial rows run beside the chain exactly as for the unfused sequence
+            cb, cs, ct = next_cast if next_cast is not None else (None, None, tok)
+            if cs is not None and ct != tok:
+                raise ValueError("fused block backward: the cast scale must be per sample")
+            R = ops.swin96_bwd_partial_rows(B, sp.H, sp.W)
+            ln1, ln2 = P.scratch("lnp." + p + ".1", R * 2 * C), P.scratch("lnp." + p + ".2", R * 2 * C)
+            apart, dense = P.scratch("apart." + p, R * nh * 256), P.scratch("adense." + p, nh * 256)
+            ops.swin96_block_bwd(
+                dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=P[p + ".qkv"], fc1_pre=P[p + ".h"], mean1=P[p + ".mean1"],
+                rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
+                w_qkv=W_.p16(p + ".attn.qkv.weight"), w_proj=W_.p16(p + ".attn.proj.weight"),
+                w_fc1=W_.p16(p + ".mlp.fc1.weight"), w_fc2=W_.p16(p + ".mlp.fc2.weight"),
+                norm1_weight=W_.p32(p + ".norm1.weight"), norm2_weight=W_.p32(p + ".norm2.weight"),
+                bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
+                drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), d_out_mlp=dyb, d_fc1_pre=dh,
+                d_out_attn=P[p + ".dyb_a"], d_qkv=dqkv, dx_bf16=cb, dx_bf16_scale=cs, norm1_partials=ln1,
+                norm2_partials=ln2, bias_partials=apart, B=B, H=sp.H, W=sp.W, shift_h=sp.sft[0], shift_w=sp.sft[1],
+                masked=int(sp.shift))
+            self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
+            self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
+            self._wgrad(P[p + ".dyb_a"], C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
+            self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
+            g1w, g1b, g2w, g2b = (G(p + ".norm1.weight"), G(p + ".norm1.bias"), G(p + ".norm2.weight"),
+                                  G(p + ".norm2.bias"))
+            gtab, rel32 = G(p + ".attn.relative_position_bias_table"), self._rel32
+
+            def folds():
+                ops.reduce_rows2(ln2, 2 * C, g2w, C, ln2 + 4 * C, 2 * C, g2b, C, R)
+                ops.reduce_rows2(ln1, 2 * C, g1w, C, ln1 + 4 * C, 2 * C, g1b, C, R)
+                ops.reduce_rows_set(apart, nh * 256, dense, nh * 256, R)
+                ops.bias_table_scatter(dense, rel32, gtab, nh, 16)
+
+            self._side(folds)
+            if self._lagged_hook is not None:
+                fn, self._lagged_hook = self._lagged_hook, None
+                fn()
+            if self.flush_per_block:
+                self._flush_wgrads()
+            return
         # ---- MLP branch (tulip.py:346-351)
         if not have_dyb:
             ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)

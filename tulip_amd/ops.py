@@ -246,3 +246,18 @@ def swin96_block_fwd(**kw):
     if kw:
         raise TypeError(f"unknown fields {sorted(kw)}")
     check(_lib.load().tulip_swin96_block_fwd(ctypes.byref(d), _stream()), "tulip_swin96_block_fwd")
+
+
+def swin96_bwd_partial_rows(B, H, W) -> int:
+    return _lib.load().tulip_swin96_bwd_partial_rows(B, H, W)
+
+
+def swin96_block_bwd(**kw):
+    """tulip_swin96_block_bwd: keyword arguments are the fields of tulip_swin96_bwd_desc (tensors or addresses)."""
+    d = _lib.Swin96BwdDesc()
+    for name, _t in _lib.Swin96BwdDesc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    check(_lib.load().tulip_swin96_block_bwd(ctypes.byref(d), _stream()), "tulip_swin96_block_bwd")
