@@ -54,6 +54,32 @@ int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb,
                     const float* rowscale, int rows_per_sample, int accumulate, int psH, int psW, int splits,
                     void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* Up to TULIP_REDUCE_REGIONS_MAX row reductions in one launch:  out[i] (+)= sum_{s<rows} partials[s*stride + i],
+ * i < n (n, stride multiples of 4).  With scatter_index != NULL the region is the dense [scatter_nh][scatter_len]
+ * relative-position-bias gradient and its sums are added to out[scatter_index[ij]*scatter_nh + h] instead
+ * (tulip.py:304-308 backwards; replaces tulip_reduce_rows_set + tulip_bias_table_scatter). */
+#define TULIP_REDUCE_REGIONS_MAX 16
+typedef struct tulip_reduce_region {
+    const float* partials; float* out;
+    int64_t stride; int64_t n;
+    int rows; int overwrite;
+    const int32_t* scatter_index; int scatter_nh; int scatter_len;
+} tulip_reduce_region;
+int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream);
+
+/* The weight (and bias) gradients of up to TULIP_WGRAD_GROUP_MAX Linear layers in TWO launches (autograd of
+ * nn.Linear, tulip.py:298,318,195,198):  dW[Nw][Kw] += dY[Mtok][Nw]^T . X[Mtok][Kw],  db[Nw] += sum_tokens dY.
+ * One grouped GEMM launch covers all items (token dimension cut `splits` ways into fp32 slabs in `workspace`, or
+ * accumulated in place when splits == 1), one tulip_reduce_rows_multi launch folds the slabs -- and the `extra`
+ * regions (LayerNorm / bias-table partial rows of the same block) ride along in that launch. */
+#define TULIP_WGRAD_GROUP_MAX 4
+typedef struct tulip_wgrad_item {
+    const void* dY; const void* X; float* dW; float* db;
+    int ldy; int ldx; int Nw; int Kw; int Mtok; int splits;
+} tulip_wgrad_item;
+int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
+                      void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);
 

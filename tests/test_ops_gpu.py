@@ -668,3 +668,50 @@ def test_swin96_fused_block_backward_matches_separate_kernels(ops, shifted):
         assert rel <= 6e-3, (k, rel)
     if sp.slot >= 0:       # sample 0: both branches dropped -> the block is the identity there
         assert torch.equal(res[True]["dx"][: M // 2], dy[: M // 2])
+
+
+def test_wgrad_group_and_multi_region_fold(ops):
+    """tulip_wgrad_group: several weight/bias gradients in one grouped GEMM launch + one fold launch that also carries
+    extra partial-row regions (plain and scattered through the relative-position index)."""
+    torch.manual_seed(3)
+    shapes = [(2048, 96, 384, 4), (2048, 384, 96, 2), (1024, 288, 96, 1), (512, 96, 96, 3)]   # Mtok, Nw, Kw, splits
+    items, refs = [], []
+    for Mtok, Nw, Kw, sp in shapes:
+        dY = (torch.randn(Mtok, Nw, device=DEV) * 0.5).bfloat16()
+        X = torch.randn(Mtok, Kw, device=DEV).bfloat16()
+        dW0, db0 = torch.randn(Nw, Kw, device=DEV), torch.randn(Nw, device=DEV)
+        dW, db = dW0.clone(), db0.clone()
+        items.append((ops.wgrad_item(dY, Nw, X, Kw, Nw, Kw, Mtok, dW, db, sp), dY, X, dW, db))
+        refs.append((dW0 + dY.float().t() @ X.float(), db0 + dY.float().sum(0)))
+    R, C, nh = 37, 96, 3
+    part = torch.randn(R, 2 * C, device=DEV)
+    gw0, gb0 = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    gw, gb = gw0.clone(), gb0.clone()
+    apart = torch.randn(R, nh * 256, device=DEV)
+    rel = torch.randint(0, 45, (256,), device=DEV, dtype=torch.int32)
+    tab0 = torch.randn(45, nh, device=DEV)
+    tab = tab0.clone()
+    setbuf = torch.full((2 * C,), 7.0, device=DEV)
+    extra = [ops.reduce_region(part, 2 * C, gw, C, R), ops.reduce_region(part.data_ptr() + 4 * C, 2 * C, gb, C, R),
+             ops.reduce_region(apart, nh * 256, tab, nh * 256, R, scatter_index=rel, scatter_nh=nh, scatter_len=256),
+             ops.reduce_region(part, 2 * C, setbuf, 2 * C, R, overwrite=True)]
+    ws = torch.empty(8 << 20, device=DEV)
+    ops.wgrad_group([it[0] for it in items], extra, ws, ws.numel() * 4)
+    torch.cuda.synchronize()
+    for (it, dY, X, dW, db), (rW, rb) in zip(items, refs):
+        assert (dW - rW).norm() / rW.norm() < 1e-5
+        assert (db - rb).norm() / rb.norm() < 1e-5
+    assert torch.allclose(gw, gw0 + part[:, :C].sum(0), atol=1e-4)
+    assert torch.allclose(gb, gb0 + part[:, C:].sum(0), atol=1e-4)
+    assert torch.allclose(setbuf, part.sum(0), atol=1e-4)
+    dense = apart.sum(0).view(nh, 256)
+    rt = tab0.clone()
+    rt.index_put_((rel.long().repeat(nh), torch.arange(nh, device=DEV).repeat_interleave(256)), dense.reshape(-1),
+                  accumulate=True)
+    assert torch.allclose(tab, rt, atol=2e-3)
+    # the fold alone, more regions than one weight-gradient group carries
+    outs = [torch.zeros(C, device=DEV) for _ in range(16)]
+    ops.reduce_rows_multi([ops.reduce_region(part.data_ptr() + 4 * (k % 2) * C, 2 * C, outs[k], C, R) for k in range(16)])
+    torch.cuda.synchronize()
+    for k in range(16):
+        assert torch.allclose(outs[k], part[:, (k % 2) * C:(k % 2 + 1) * C].sum(0), atol=1e-4)

@@ -32,6 +32,20 @@ class Swin96BwdDesc(ctypes.Structure):
                [(n, I) for n in ("B", "H", "W", "shift_h", "shift_w", "masked")]
 
 
+class ReduceRegion(ctypes.Structure):
+    """tulip_reduce_region (include/tulip_hip.h)."""
+    _fields_ = [("partials", P), ("out", P), ("stride", L), ("n", L), ("rows", I), ("overwrite", I),
+                ("scatter_index", P), ("scatter_nh", I), ("scatter_len", I)]
+
+
+class WgradItem(ctypes.Structure):
+    """tulip_wgrad_item (include/tulip_hip.h)."""
+    _fields_ = [("dY", P), ("X", P), ("dW", P), ("db", P), ("ldy", I), ("ldx", I), ("Nw", I), ("Kw", I), ("Mtok", I),
+                ("splits", I)]
+
+
+REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX = 16, 4
+
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P, L, P],
@@ -57,6 +71,8 @@ SIGNATURES = {
     "tulip_reduce_splits": [P, P, L, I, P],
     "tulip_reduce_rows2": [P, L, P, L, P, L, P, L, I, P],
     "tulip_reduce_rows_set": [P, L, P, L, I, P],
+    "tulip_reduce_rows_multi": [P, I, P],
+    "tulip_wgrad_group": [P, I, P, I, P, L, P],
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],

@@ -186,6 +186,62 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ReduceRegion r0, Reduc
     }
 }
 
+// up to TULIP_REDUCE_REGIONS_MAX independent row reductions in one launch; a region may scatter its sums through
+// the relative-position index (bias-table gradient) instead of adding them in place
+struct MultiRegion {
+    const float* part; float* out; const int* scatter;
+    int64_t stride, n4;
+    int first_block, rows, overwrite, rl, nh, LL;
+};
+struct MultiRegions { MultiRegion r[TULIP_REDUCE_REGIONS_MAX]; int n; };
+__global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegions R) {
+    __shared__ float4 red[256];
+    int i = 0;
+    while (i + 1 < R.n && (int)blockIdx.x >= R.r[i + 1].first_block) ++i;
+    const MultiRegion r = R.r[i];
+    const int RL = r.rl, CT = 256 / RL, S = r.rows;
+    const int ct = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int64_t col = (int64_t)(blockIdx.x - r.first_block) * CT + ct;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < r.n4) {
+        const float* base = r.part + col * 4;
+        for (int s = rl; s < S; s += RL * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ss = s + u * RL;
+                v[u] = ss < S ? *(const float4*)(base + (int64_t)ss * r.stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    if (RL > 1) {                                   // block-uniform
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0 && col < r.n4) {
+            for (int k = 1; k < RL; ++k) {
+                const float4 v = red[k * CT + ct];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    if (rl == 0 && col < r.n4) {
+        if (r.scatter) {
+            const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = (int)col * 4 + e, h = idx / r.LL, ij = idx - h * r.LL;
+                atomicAdd(r.out + r.scatter[ij] * r.nh + h, v[e]);
+            }
+        } else {
+            float4 o = r.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(r.out + col * 4);
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            *(float4*)(r.out + col * 4) = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- loss (tulip.py:690-700)
 constexpr int LOSS_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
@@ -431,6 +487,31 @@ extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* ou
 extern "C" int tulip_reduce_rows_set(const float* part, int64_t stride, float* out, int64_t n, int nrows,
                                      hipStream_t stream) {
     return reduce_rows_impl(part, stride, out, n, nullptr, 0, nullptr, 0, nrows, 1, stream);
+}
+
+extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream) {
+    if (n < 0 || n > TULIP_REDUCE_REGIONS_MAX || (n && !regions)) return TULIP_ERR_ARG;
+    MultiRegions R;
+    R.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const tulip_reduce_region& g = regions[i];
+        if (g.n <= 0 || g.rows <= 0) continue;
+        if ((g.n & 3) || (g.stride & 3) || !g.partials || !g.out) return TULIP_ERR_ARG;
+        if (g.scatter_index && (g.scatter_nh <= 0 || g.scatter_len <= 0 || g.n != (int64_t)g.scatter_nh * g.scatter_len))
+            return TULIP_ERR_ARG;
+        MultiRegion& r = R.r[R.n++];
+        r.part = g.partials; r.out = g.out; r.scatter = g.scatter_index; r.stride = g.stride; r.n4 = g.n / 4;
+        r.rows = g.rows; r.overwrite = g.overwrite; r.nh = g.scatter_nh; r.LL = g.scatter_len;
+        r.rl = (r.n4 >= 8192 || g.rows < 8) ? 1 : 16;     // many columns or few rows: one thread per float4 column
+        r.first_block = blocks;
+        const int ct = 256 / r.rl;
+        blocks += (int)((r.n4 + ct - 1) / ct);
+    }
+    if (blocks == 0) return TULIP_OK;
+    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(blocks), dim3(256), 0, stream, R);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
 }
 
 extern "C" int tulip_reduce_splits(const float* slabs, float* out, int64_t n, int splits, hipStream_t stream) {

@@ -249,8 +249,9 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
     }
 }
 
+// one output tile (bx, by) of K range bz: the body of both the plain and the grouped launch
 template <int BM, bool A_T, bool B_T, int KSUB>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz) {
     constexpr int FM = BM / 32;  // 16-row fragments per wave in M
     constexpr int FN = 3;
     using SA = Stage<BM, A_T, KSUB>;
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg + BKS - 1) / BKS;
 
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int g = lane >> 4, li = lane & 15;
     // wgrad only: row sums of opA (= bias gradient, sum over tokens of dY) from one extra MFMA per
     // fragment against an all-ones operand, in the first column-tile's wn==0 waves.
-    const bool do_rowsum = A_T && p.out2 != nullptr && blockIdx.x == 0 && wn == 0 &&
+    const bool do_rowsum = A_T && p.out2 != nullptr && bx == 0 && wn == 0 &&
                            (p.epi == TULIP_EPI_SPLIT_F32 || p.epi == TULIP_EPI_F32);
     f32x4 rsum[FM];
 #pragma unroll
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             if (m < p.M && n < p.N) {
                 const float4 lo = *(const float4*)(smem + rl * STG_PITCH + c8 * 32);
                 const float4 hi = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
-                epilogue8(p, m, n, lo, hi, blockIdx.z);
+                epilogue8(p, m, n, lo, hi, bz);
             }
         }
         if (ps + 1 < NPASS) __syncthreads();
@@ -389,11 +390,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wm * (BM / 2) + i * 16 + li;
             if (m >= p.M) continue;
-            if (p.epi == TULIP_EPI_SPLIT_F32) rs[(size_t)blockIdx.z * p.M + m] = rsum[i][0];
+            if (p.epi == TULIP_EPI_SPLIT_F32) rs[(size_t)bz * p.M + m] = rsum[i][0];
             else if (p.accumulate) rs[m] += rsum[i][0];
             else rs[m] = rsum[i][0];
         }
     }
+}
+
+template <int BM, bool A_T, bool B_T, int KSUB>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    gemm_tile<BM, A_T, B_T, KSUB>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent GEMMs in ONE launch (the weight gradients of a Swin block: each alone fills a fraction of the
+// chip and costs a launch on the side queue).  Workgroups [first[i], first[i+1]) belong to problem i.
+constexpr int GROUP_MAX = TULIP_WGRAD_GROUP_MAX;
+struct GemmGroup {
+    GemmArgs g[GROUP_MAX];
+    int first[GROUP_MAX + 1];
+    int gx[GROUP_MAX], gy[GROUP_MAX];
+    int n;
+};
+template <int BM, bool A_T, bool B_T, int KSUB>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
+    int i = 0;
+    while (i + 1 < G.n && (int)blockIdx.x >= G.first[i + 1]) ++i;
+    int b = blockIdx.x - G.first[i];
+    const int bx = b % G.gx[i];
+    b /= G.gx[i];
+    const GemmArgs p = G.g[i];
+    gemm_tile<BM, A_T, B_T, KSUB>(p, bx, b % G.gy[i], b / G.gy[i]);
 }
 
 // split-K for the ordinary epilogues: the GEMM wrote raw fp32 partial slabs [splits][M][N]; fold them
@@ -493,4 +519,63 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, p, (const float*)workspace, splits);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
+}
+
+extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream);
+
+extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
+                                 void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    if (n < 0 || n > GROUP_MAX || n_extra < 0 || n + n + n_extra > TULIP_REDUCE_REGIONS_MAX || (n && !items) ||
+        (n_extra && !extra))
+        return TULIP_ERR_ARG;
+    GemmGroup G;
+    tulip_reduce_region folds[TULIP_REDUCE_REGIONS_MAX];
+    int nf = 0;
+    int64_t ws_used = 0;                       // floats
+    float* ws = (float*)workspace;
+    G.n = 0;
+    G.first[0] = 0;
+    bool deep = true;
+    for (int i = 0; i < n; ++i) {
+        const tulip_wgrad_item& it = items[i];
+        if (it.Nw <= 0 || it.Kw <= 0 || it.Mtok <= 0) continue;
+        if ((it.Mtok & 7) || (it.Nw & 7) || (it.Kw & 7) || (it.ldy & 7) || (it.ldx & 7) || !it.dY || !it.X || !it.dW)
+            return TULIP_ERR_ARG;
+        int splits = it.splits < 1 ? 1 : it.splits;
+        const int kchunk = (((it.Mtok + splits - 1) / splits) + BK - 1) / BK * BK;
+        splits = (it.Mtok + kchunk - 1) / kchunk;
+        GemmArgs& p = G.g[G.n];
+        p.A = (const bf16_t*)it.dY; p.B = (const bf16_t*)it.X; p.lda = it.ldy; p.ldb = it.ldx;
+        p.M = it.Nw; p.N = it.Kw; p.K = it.Mtok; p.kchunk = kchunk;
+        p.bias = nullptr; p.ldo = it.Kw; p.ldo2 = 0; p.aux = nullptr; p.ldaux = 0; p.rowscale = nullptr;
+        p.rows_per_sample = 1; p.psH = 0; p.psW = 0;
+        if (splits > 1) {
+            const int64_t nw = (int64_t)it.Nw * it.Kw, need = (nw + (it.db ? it.Nw : 0)) * splits;
+            if (!ws || (ws_used + need) * 4 > workspace_bytes) return TULIP_ERR_ARG;
+            p.epi = TULIP_EPI_SPLIT_F32; p.accumulate = 0;
+            p.out = ws + ws_used;
+            p.out2 = it.db ? (void*)(ws + ws_used + nw * splits) : nullptr;
+            folds[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, 0, nullptr, 0, 0};
+            if (it.db) folds[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, 0, nullptr, 0, 0};
+            ws_used += need;
+        } else {
+            p.epi = TULIP_EPI_F32; p.accumulate = 1; p.out = it.dW; p.out2 = it.db;
+        }
+        G.gx[G.n] = (it.Kw + BN - 1) / BN;
+        G.gy[G.n] = (it.Nw + 63) / 64;
+        G.first[G.n + 1] = G.first[G.n] + G.gx[G.n] * G.gy[G.n] * splits;
+        deep = deep && kchunk >= 256;
+        ++G.n;
+    }
+    if (G.n > 0) {
+        static const int ksub_grid = getenv("TULIP_GEMM_KSUB_GRID") ? atoi(getenv("TULIP_GEMM_KSUB_GRID")) : 400;
+        const int blocks = G.first[G.n];
+        if (blocks <= ksub_grid && deep)
+            hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 4>), dim3(blocks), dim3(256), 0, stream, G);
+        else
+            hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 1>), dim3(blocks), dim3(256), 0, stream, G);
+        TULIP_CHECK_LAUNCH();
+    }
+    for (int i = 0; i < n_extra; ++i) folds[nf++] = extra[i];
+    return nf ? tulip_reduce_rows_multi(folds, nf, stream) : TULIP_OK;
 }

@@ -543,13 +543,57 @@ class TulipEngine:
             return self._wgrad_launch(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, self._ws_ptr)
         # queued: forks cost a few microseconds each inside a HIP graph, so a Swin block's four weight
         # gradients share ONE fork (their inputs are per-block buffers, so deferring them is hazard-free)
-        self._pending.append(lambda ws: self._wgrad_launch(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, ws))
+        self._pending.append(("w", (dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias)))
 
     def _side(self, fn):
-        """Queue work nothing in the backward chain waits for (gradient folds) for the side stream."""
+        """Queue work nothing in the backward chain waits for for the side stream."""
         if self.overlap_wgrad:
-            self._pending.append(lambda ws: fn())
+            self._pending.append(("f", fn))
         else:
+            fn()
+
+    def _fold(self, part, stride, out, n, rows, **kw):
+        """Queue a fold of per-workgroup partial rows: out[i] += sum_r part[r*stride + i] (LayerNorm affine gradients,
+        relative-position-bias gradients, ...).  Folds queued by one block leave in the same launch as the folds of
+        its weight-gradient slabs."""
+        r = ops.reduce_region(part, stride, out, n, rows, **kw)
+        if self.overlap_wgrad:
+            self._pending.append(("r", r))
+        else:
+            ops.reduce_rows_multi([r])
+
+    group_wgrad = os.environ.get("TULIP_GROUP_WGRAD", "1") != "0"
+
+    def _issue_pending(self, ws: int):
+        """Launch the queued side work on the current stream: weight gradients as grouped GEMMs (<= 4 per launch), every
+        fold in the launch that folds the slabs, other closures last."""
+        items = [a for k, a in self._pending if k == "w"]
+        regions = [a for k, a in self._pending if k == "r"]
+        fns = [a for k, a in self._pending if k == "f"]
+        ws_bytes = (self.WS_ELEMS + (1 << 20)) * 4
+        if not self.group_wgrad:
+            for a in items:
+                self._wgrad_launch(*a, ws)
+            items = []
+        from . import _lib
+        while items:
+            grp, used = [], 0
+            while items and len(grp) < _lib.WGRAD_GROUP_MAX:
+                dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias = items[0]
+                sp = self._splits(Nw, Kw, Mtok)
+                need = (Nw * Kw + Nw) * sp * 4 if sp > 1 else 0
+                if grp and used + need > ws_bytes:
+                    break
+                used += need
+                grp.append(ops.wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, sp))
+                items.pop(0)
+            room = _lib.REDUCE_REGIONS_MAX - 2 * len(grp)
+            extra, regions = regions[:room], regions[room:]
+            ops.wgrad_group(grp, extra, ws, ws_bytes)
+        while regions:
+            ops.reduce_rows_multi(regions[:_lib.REDUCE_REGIONS_MAX])
+            regions = regions[_lib.REDUCE_REGIONS_MAX:]
+        for fn in fns:
             fn()
 
     def _flush_wgrads(self, advance: bool = True):
@@ -563,8 +607,7 @@ class TulipEngine:
             self._side_rr += 1              # the same stream
         st.wait_stream(main)
         with torch.cuda.stream(st):
-            for fn in self._pending:
-                fn(ws)
+            self._issue_pending(ws)
         self._pending = []
         self._side_dirty = True
 
@@ -609,7 +652,8 @@ class TulipEngine:
         part = P.scratch("lnp." + tag, nrows * 2 * C)
         ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
                           param_partials=part, dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
-        self._side(lambda: ops.reduce_rows2(part, 2 * C, gw, C, part + 4 * C, 2 * C, gb, C, nrows))
+        self._fold(part, 2 * C, gw, C, nrows)
+        self._fold(part + 4 * C, 2 * C, gb, C, nrows)
 
     def _mlp_cast(self, P: Plan, sp: BlockSpec):
         """What the producer of this block's incoming gradient should emit: (dyb_m, DropPath scale, tokens)."""
@@ -635,7 +679,7 @@ class TulipEngine:
                 raise ValueError("fused block backward: the cast scale must be per sample")
             R = ops.swin96_bwd_partial_rows(B, sp.H, sp.W)
             ln1, ln2 = P.scratch("lnp." + p + ".1", R * 2 * C), P.scratch("lnp." + p + ".2", R * 2 * C)
-            apart, dense = P.scratch("apart." + p, R * nh * 256), P.scratch("adense." + p, nh * 256)
+            apart = P.scratch("apart." + p, R * nh * 256)
             ops.swin96_block_bwd(
                 dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=P[p + ".qkv"], fc1_pre=P[p + ".h"], mean1=P[p + ".mean1"],
                 rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
@@ -651,17 +695,12 @@ class TulipEngine:
             self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
             self._wgrad(P[p + ".dyb_a"], C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
             self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
-            g1w, g1b, g2w, g2b = (G(p + ".norm1.weight"), G(p + ".norm1.bias"), G(p + ".norm2.weight"),
-                                  G(p + ".norm2.bias"))
-            gtab, rel32 = G(p + ".attn.relative_position_bias_table"), self._rel32
-
-            def folds():
-                ops.reduce_rows2(ln2, 2 * C, g2w, C, ln2 + 4 * C, 2 * C, g2b, C, R)
-                ops.reduce_rows2(ln1, 2 * C, g1w, C, ln1 + 4 * C, 2 * C, g1b, C, R)
-                ops.reduce_rows_set(apart, nh * 256, dense, nh * 256, R)
-                ops.bias_table_scatter(dense, rel32, gtab, nh, 16)
-
-            self._side(folds)
+            self._fold(ln2, 2 * C, G(p + ".norm2.weight"), C, R)
+            self._fold(ln2 + 4 * C, 2 * C, G(p + ".norm2.bias"), C, R)
+            self._fold(ln1, 2 * C, G(p + ".norm1.weight"), C, R)
+            self._fold(ln1 + 4 * C, 2 * C, G(p + ".norm1.bias"), C, R)
+            self._fold(apart, nh * 256, G(p + ".attn.relative_position_bias_table"), nh * 256, R,
+                       scatter_index=self._rel32, scatter_nh=nh, scatter_len=256)
             if self._lagged_hook is not None:
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
@@ -691,16 +730,10 @@ class TulipEngine:
         self._wgrad(dyb, C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
         R = ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, nh, sp.win)
         apart = P.scratch("apart." + p, R * nh * 256)
-        dense = P.scratch("adense." + p, nh * 256)
         ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
                             apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
-        gtab, rel32 = G(p + ".attn.relative_position_bias_table"), self._rel32
-
-        def fold_bias():
-            ops.reduce_rows_set(apart, nh * 256, dense, nh * 256, R)
-            ops.bias_table_scatter(dense, rel32, gtab, nh, 16)
-
-        self._side(fold_bias)
+        self._fold(apart, nh * 256, G(p + ".attn.relative_position_bias_table"), nh * 256, R,
+                   scatter_index=self._rel32, scatter_nh=nh, scatter_len=256)
         self._gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
                  out=dxn, ldo=C)
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
@@ -777,7 +810,7 @@ class TulipEngine:
                      W_.p32("decoder_pred.weight"), P.pred, P["tail.dz"], tpart, B, H0, W0, E, target=P.target,
                      gscale_dev=gscale_dev, gscale=gscale)     # L1 backward (tulip.py:692-693) formed in-kernel
         gdw = G("decoder_pred.weight")
-        self._side(lambda: ops.reduce_rows2(tpart, 128, gdw, E, None, 0, None, 0, (M0 + 31) // 32))
+        self._fold(tpart, 128, gdw, E, (M0 + 31) // 32)
         self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),
                     G("ps_head.conv_expand.0.bias"))
         self._gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
@@ -853,7 +886,7 @@ class TulipEngine:
                             m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
                             self.eps, partial_stride=P.embed_stride)
         gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
-        self._side(lambda: ops.reduce_rows2(ep, P.embed_stride, gpe, P.embed_stride, None, 0, None, 0, nbe))
+        self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge

@@ -72,6 +72,31 @@ def reduce_rows_set(part, stride, out, n, nrows):
     check(_lib.load().tulip_reduce_rows_set(_p(part), stride, _p(out), n, nrows, _stream()), "tulip_reduce_rows_set")
 
 
+def reduce_region(part, stride, out, n, rows, overwrite=False, scatter_index=None, scatter_nh=0, scatter_len=0):
+    """One tulip_reduce_region: out[i] (+)= sum_s part[s*stride + i]; see include/tulip_hip.h."""
+    return _lib.ReduceRegion(_p(part), _p(out), stride, n, rows, int(overwrite), _p(scatter_index), scatter_nh,
+                             scatter_len)
+
+
+def wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, dW, db=None, splits=1):
+    return _lib.WgradItem(_p(dY), _p(X), _p(dW), _p(db), ldy, ldx, Nw, Kw, Mtok, splits)
+
+
+def reduce_rows_multi(regions):
+    if len(regions) > _lib.REDUCE_REGIONS_MAX:
+        raise ValueError("too many regions for one launch")
+    arr = (_lib.ReduceRegion * max(len(regions), 1))(*regions)
+    check(_lib.load().tulip_reduce_rows_multi(arr, len(regions), _stream()), "tulip_reduce_rows_multi")
+
+
+def wgrad_group(items, extra, workspace, workspace_bytes):
+    """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions."""
+    ia = (_lib.WgradItem * max(len(items), 1))(*items)
+    ea = (_lib.ReduceRegion * max(len(extra), 1))(*extra)
+    check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, _stream()),
+          "tulip_wgrad_group")
+
+
 def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False, B=0, H=0, W=0):
     rc = _lib.load().tulip_layernorm_bwd_params(_p(dy), _p(x), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), rows, C,
                                                 int(merge), B, H, W, _stream())
