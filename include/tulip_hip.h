@@ -71,14 +71,15 @@ int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream
  * nn.Linear, tulip.py:298,318,195,198):  dW[Nw][Kw] += dY[Mtok][Nw]^T . X[Mtok][Kw],  db[Nw] += sum_tokens dY.
  * One grouped GEMM launch covers all items (token dimension cut `splits` ways into fp32 slabs in `workspace`, or
  * accumulated in place when splits == 1), one tulip_reduce_rows_multi launch folds the slabs -- and the `extra`
- * regions (LayerNorm / bias-table partial rows of the same block) ride along in that launch. */
+ * regions (LayerNorm / bias-table partial rows of the same block) ride along in that launch.  fold = 0 skips the
+ * second launch and leaves the slabs in the workspace (profiling the GEMM alone). */
 #define TULIP_WGRAD_GROUP_MAX 4
 typedef struct tulip_wgrad_item {
     const void* dY; const void* X; float* dW; float* db;
     int ldy; int ldx; int Nw; int Kw; int Mtok; int splits;
 } tulip_wgrad_item;
 int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
-                      void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                      void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream);
 
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);

@@ -23,9 +23,9 @@ print(f"TOTAL over run: fetch {tot_f:.0f} MB (x2 corrected), write {tot_w:.0f} M
 # GEMM-family aggregate for bench.py's roofline.traffic (optional 3rd argument: output json)
 if len(sys.argv) > 3:
     import json
-    gf = sum(v[1] for k, v in f.items() if k.startswith("gemm_kernel")) * 1024.0 * 2.0
-    gw = sum(v[1] for k, v in w.items() if k.startswith("gemm_kernel")) * 1024.0
-    n = sum(v[0] for k, v in f.items() if k.startswith("gemm_kernel"))
+    gf = sum(v[1] for k, v in f.items() if k.startswith(("gemm_kernel", "gemm_group_kernel"))) * 1024.0 * 2.0
+    gw = sum(v[1] for k, v in w.items() if k.startswith(("gemm_kernel", "gemm_group_kernel"))) * 1024.0
+    n = sum(v[0] for k, v in f.items() if k.startswith(("gemm_kernel", "gemm_group_kernel")))
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 2; "
                          "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md HBM section); "
                          "WRITE_SIZE uncorrected",

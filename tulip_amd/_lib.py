@@ -72,7 +72,7 @@ SIGNATURES = {
     "tulip_reduce_rows2": [P, L, P, L, P, L, P, L, I, P],
     "tulip_reduce_rows_set": [P, L, P, L, I, P],
     "tulip_reduce_rows_multi": [P, I, P],
-    "tulip_wgrad_group": [P, I, P, I, P, L, P],
+    "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],

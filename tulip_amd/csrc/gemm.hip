@@ -524,7 +524,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
 extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream);
 
 extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
-                                 void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                                 void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream) {
     if (n < 0 || n > GROUP_MAX || n_extra < 0 || n + n + n_extra > TULIP_REDUCE_REGIONS_MAX || (n && !items) ||
         (n_extra && !extra))
         return TULIP_ERR_ARG;
@@ -576,6 +576,7 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
             hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 1>), dim3(blocks), dim3(256), 0, stream, G);
         TULIP_CHECK_LAUNCH();
     }
+    if (!fold) return TULIP_OK;
     for (int i = 0; i < n_extra; ++i) folds[nf++] = extra[i];
     return nf ? tulip_reduce_rows_multi(folds, nf, stream) : TULIP_OK;
 }

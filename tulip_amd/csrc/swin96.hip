@@ -11,7 +11,6 @@
 // staged in LDS (W2 | {Wqkv,Wproj} then W1 in the same region, plus the bias / norm2 vectors: 163.7 of 163.8 KB).
 // Everything the backward needs (xn1, qkv, o, x1, xn2, h, g, the LayerNorm statistics) is written exactly as the
 // separate kernels write it, so the backward is unchanged.
-#include <cstdlib>
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -40,7 +39,6 @@ struct Swin96Args {
     const float *ds0, *ds1;               // DropPath multipliers per sample (attention / MLP branch) or nullptr
     int B, H, W, sh, sw, masked;
     float eps, scale;
-    int stop;     // dev: return after phase N (0 = run everything)
 };
 
 __device__ __forceinline__ int region(int x, int X, int wsz, int ssz) {       // create_mask slices, tulip.py:261-266
@@ -161,7 +159,6 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         for (int s = 0; s < 3; ++s) xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
     }
     __syncthreads();                                        // weights of phase 1, W2 and the parameter vectors are in LDS
-    if (a.stop == 1) return;
 
     // ---- qkv Linear (tulip.py:298): acc lane = 4 consecutive output channels 16j + 4gq + r of token t
     bf16x4 qkvp[18];
@@ -176,7 +173,6 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         qkvp[j] = pack4(acc[0] + bq.x, acc[1] + bq.y, acc[2] + bq.z, acc[3] + bq.w);
         *(bf16x4*)(a.qkv + row * 288 + 16 * j + 4 * gq) = qkvp[j];
     }
-    if (a.stop == 2) return;
 
     // ---- attention, one head at a time (tulip.py:300-317); scores issued as K.Q^T: lane = query t, keys 4gq + r
     bf16x8 ofrag[3];
@@ -219,7 +215,6 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         }
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
-    if (a.stop == 3) return;
 
     // ---- proj Linear + DropPath + residual (tulip.py:318,344), then norm2 (:347); x1 replaces x in xv
     const float s0 = a.ds0 ? a.ds0[b] : 1.0f, s1v = a.ds1 ? a.ds1[b] : 1.0f;
@@ -262,13 +257,11 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
     }
-    if (a.stop == 4) return;
 
     // ---- fc1 weights replace qkv/proj weights in LDS
     __syncthreads();
     stage_weights<HID, C, PW>(a.w1, smem + OFF_A, tid);
     __syncthreads();
-    if (a.stop == 5) return;
 
     // ---- fc1 -> exact-erf GELU -> fc2 (tulip.py:195-198), 32 hidden channels at a time, chained in registers
     f32x4 acc3[6];
@@ -345,7 +338,6 @@ struct Swin96BwdArgs {
     float *lnpart1, *lnpart2, *biaspart;         // [workgroups][192], [workgroups][192], [workgroups][768]
     int B, H, W, sh, sw, masked;
     float scale;
-    int stop;
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -484,7 +476,6 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int h = 0; h < 3; ++h) { bias_q[h][r] = a.bias_table[eq + h]; bias_k[h][r] = a.bias_table[ek + h]; }
     }
     __syncthreads();
-    if (a.stop == 1) return;
 
     // ---- MLP half (tulip.py:346-351 backwards): per 32 hidden channels  dg = dy.W2 -> dh = dg*gelu'(h) -> dxn2 += dh.W1
     f32x4 acc2[6];
@@ -513,7 +504,6 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int n = 0; n < 6; ++n)
             acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_W1, PT, 32 * p, 16 * n, t, gq), df, acc2[n], 0, 0, 0);
     }
-    if (a.stop == 2) return;
 
     // ---- the attention-half weights are fetched while norm2 is differentiated
     Staged<288, C> wqs; Staged<C, C> wps;
@@ -550,7 +540,6 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     float* redw = (float*)(smem + BOFF_RED);
     put_red(redw + wid * 192, red2, t, gq);
     __syncthreads();
-    if (a.stop == 3) return;
 
     // ---- proj' : dO = dyb_a . Wproj   (tulip.py:318 backwards)
     bf16x4 dop[6];
@@ -638,7 +627,6 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 18; ++j) *(bf16x4*)(a.dqkv + row * 288 + 16 * j + 4 * gq) = dqkvp[j];
-    if (a.stop == 4) return;
 
     // ---- qkv' : dxn1 = dqkv . Wqkv  (tulip.py:298 backwards), then norm1' and the residual
     f32x4 acc1[6], xv[6];
@@ -697,7 +685,6 @@ extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t st
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
-    a.stop = getenv("TULIP_SWIN96_STOP") ? atoi(getenv("TULIP_SWIN96_STOP")) : 0;
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
     hipLaunchKernelGGL(swin96_fwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
@@ -727,7 +714,6 @@ extern "C" int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_
     a.lnpart1 = d->norm1_partials; a.lnpart2 = d->norm2_partials; a.biaspart = d->bias_partials;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.scale = 0.17677669529663687f;
-    a.stop = getenv("TULIP_SWIN96_STOP") ? atoi(getenv("TULIP_SWIN96_STOP")) : 0;
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
     hipLaunchKernelGGL(swin96_bwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();

@@ -89,12 +89,12 @@ def reduce_rows_multi(regions):
     check(_lib.load().tulip_reduce_rows_multi(arr, len(regions), _stream()), "tulip_reduce_rows_multi")
 
 
-def wgrad_group(items, extra, workspace, workspace_bytes):
+def wgrad_group(items, extra, workspace, workspace_bytes, fold=True):
     """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions."""
     ia = (_lib.WgradItem * max(len(items), 1))(*items)
     ea = (_lib.ReduceRegion * max(len(extra), 1))(*extra)
-    check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, _stream()),
-          "tulip_wgrad_group")
+    check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, int(fold),
+                                        _stream()), "tulip_wgrad_group")
 
 
 def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False, B=0, H=0, W=0):
