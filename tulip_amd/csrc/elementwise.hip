@@ -1,5 +1,6 @@
 // HBM-bound helpers: fp32->bf16 casts (with DropPath row scale / concat / inverse pixel shuffle),
 // column sums (bias gradients), L1 loss forward/backward, fused AdamW.   gfx950 only.
+#include <cstdlib>
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -503,7 +504,11 @@ extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n
         MultiRegion& r = R.r[R.n++];
         r.part = g.partials; r.out = g.out; r.scatter = g.scatter_index; r.stride = g.stride; r.n4 = g.n / 4;
         r.rows = g.rows; r.overwrite = g.overwrite; r.nh = g.scatter_nh; r.LL = g.scatter_len;
-        r.rl = (r.n4 >= 8192 || g.rows < 8) ? 1 : 16;     // many columns or few rows: one thread per float4 column
+        // one thread per float4 column when there are few rows; otherwise spread the rows over 2..16 row lanes until
+        // the region has enough workgroups to hide the strided loads (32-row slabs of a 37k-column weight gradient
+        // took 50-80 us with one thread per column)
+        r.rl = 1;
+        while (r.rl < 16 && r.rl * 8 <= g.rows && (r.n4 * r.rl + 255) / 256 < 512) r.rl *= 2;
         r.first_block = blocks;
         const int ct = 256 / r.rl;
         blocks += (int)((r.n4 + ct - 1) / ct);

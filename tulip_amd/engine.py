@@ -518,15 +518,18 @@ class TulipEngine:
                 return
         ops.gemm(A, B, M, N, K, **kw)
 
-    flush_per_block = True
+    flush_per_block = os.environ.get("TULIP_FLUSH_PER_BLOCK", "1") != "0"
     early_flush = frozenset()   # block prefixes with a mid-block side flush (set in bind())
     lag_bucket_join = os.environ.get("TULIP_LAG_BUCKET_JOIN", "1") != "0"
     _lagged_hook = None
-    # Side streams, used round-robin by Swin block.  Measured on MI355X / ROCm 7.2 (graph replay, B=8):
-    # 1 stream 4.63 ms, 2: 4.46, 3: 4.82, 4: 4.05, 5: 4.63, 6: 4.33, 8: 4.05, 12: 4.08, 16: 4.05 -- the HIP graph
-    # executor spreads the captured branches over 4 hardware queues, and branch counts that are not a multiple
-    # of that alias side work into the main chain's queue.
-    n_side = int(os.environ.get("TULIP_SIDE_STREAMS", "4"))
+    # Side streams.  How the HIP graph executor (ROCm 7.2) turns captured branches into hardware-queue work decides what
+    # a fork costs the chain: it walks the graph depth first along each node's FIRST-created successor and gives every
+    # other successor a new run list on another queue.  With the side kernels enqueued right at the fork (defer_side
+    # off) they are the first successor, so the chain itself changes queue at every fork (~12 us each; then 4, 8, 12...
+    # side streams used round-robin are best: 1 stream 4.63 ms, 2: 4.46, 3: 4.82, 4: 4.05, 8: 4.05 at the time).  With
+    # defer_side the chain's next kernel is created first, the chain stays on one queue for the whole step, and a
+    # single side stream is best (1: 3.32 ms, 2: 3.59, 3: 3.63, 4: 3.67, 8: 3.63; 3.42 for the old layout).
+    n_side = int(os.environ.get("TULIP_SIDE_STREAMS", "1" if os.environ.get("TULIP_DEFER_SIDE", "1") != "0" else "4"))
     overlap_wgrad = True   # run the weight-gradient branch on a second HIP stream (forked inside the graph)
 
     def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
@@ -564,12 +567,13 @@ class TulipEngine:
 
     group_wgrad = os.environ.get("TULIP_GROUP_WGRAD", "1") != "0"
 
-    def _issue_pending(self, ws: int):
+    def _issue_pending(self, ws: int, pending=None):
         """Launch the queued side work on the current stream: weight gradients as grouped GEMMs (<= 4 per launch), every
         fold in the launch that folds the slabs, other closures last."""
-        items = [a for k, a in self._pending if k == "w"]
-        regions = [a for k, a in self._pending if k == "r"]
-        fns = [a for k, a in self._pending if k == "f"]
+        pending = self._pending if pending is None else pending
+        items = [a for k, a in pending if k == "w"]
+        regions = [a for k, a in pending if k == "r"]
+        fns = [a for k, a in pending if k == "f"]
         ws_bytes = (self.WS_ELEMS + (1 << 20)) * 4
         if not self.group_wgrad:
             for a in items:
@@ -605,14 +609,37 @@ class TulipEngine:
         st, ws = self._side_streams[k], self._ws_sides[k].data_ptr()
         if advance:                         # advance=False: a mid-block flush, the block's remainder follows on
             self._side_rr += 1              # the same stream
+        if self.defer_side and advance:
+            # the fork point is HERE, but the side kernels are enqueued only after the chain's next kernel (see
+            # _release_deferred): the graph executor keeps a node's first-created successor on the node's queue
+            self._release_deferred()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._deferred = (ev, st, ws, self._pending)
+            self._pending = []
+            self._side_dirty = True
+            return
         st.wait_stream(main)
         with torch.cuda.stream(st):
             self._issue_pending(ws)
         self._pending = []
         self._side_dirty = True
 
+    defer_side = os.environ.get("TULIP_DEFER_SIDE", "1") != "0"
+    _deferred = None
+
+    def _release_deferred(self):
+        d, self._deferred = self._deferred, None
+        if d is None:
+            return
+        ev, st, ws, pending = d
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            self._issue_pending(ws, pending)
+
     def _wait_side(self):
         """The current stream waits for everything issued on the side streams so far (queued work stays queued)."""
+        self._release_deferred()
         if getattr(self, "_side_dirty", False):
             for st in self._side_streams:
                 torch.cuda.current_stream().wait_stream(st)
@@ -620,6 +647,7 @@ class TulipEngine:
 
     def _join_side(self):
         self._flush_wgrads()
+        self._release_deferred()
         if getattr(self, "_side_dirty", False):
             for st in self._side_streams:
                 torch.cuda.current_stream().wait_stream(st)
@@ -691,6 +719,7 @@ class TulipEngine:
                 d_out_attn=P[p + ".dyb_a"], d_qkv=dqkv, dx_bf16=cb, dx_bf16_scale=cs, norm1_partials=ln1,
                 norm2_partials=ln2, bias_partials=apart, B=B, H=sp.H, W=sp.W, shift_h=sp.sft[0], shift_w=sp.sft[1],
                 masked=int(sp.shift))
+            self._release_deferred()
             self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
             self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
             self._wgrad(P[p + ".dyb_a"], C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
@@ -712,6 +741,7 @@ class TulipEngine:
             ops.cast_f32_bf16(dx, dyb, M, C, self._ds(P, sp, 1), tok)
         self._gemm(dyb, W_.p16(p + ".mlp.fc2.weight"), M, Hd, C, lda=C, ldb=Hd, b_trans=True, epi=EPI_GELU_BWD, out=dh,
                  ldo=Hd, aux=P[p + ".h"], ldaux=Hd)
+        self._release_deferred()
         self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
         self._gemm(dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, lda=Hd, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn,
                  ldo=C)
@@ -763,6 +793,7 @@ class TulipEngine:
         M = B * H * W
         dz = P[f"lvl{s}.dz2"]
         ops.unshuffle2_cast(dfine, dz, B, H, W, C // 2)
+        self._release_deferred()
         self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), G(prefix + ".expand.bias"))
         self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
                  out=dx_out, ldo=C)
@@ -775,7 +806,7 @@ class TulipEngine:
         m, W_ = self.model, self.params
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
-        self._pending, self._lagged_hook = [], None     # nothing survives from an aborted earlier call
+        self._pending, self._lagged_hook, self._deferred = [], None, None     # nothing survives from an aborted earlier call
         gbase = gflat.data_ptr()
         G = lambda name: gbase + 4 * W_.offset[name]
         user_hook = bucket_hook or (lambda tag: None)
