@@ -123,10 +123,11 @@ int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, const float* 
                                float* dbeta, int rows, int C, int merge, int B, int H, int W, hipStream_t stream);
 
 /* PatchEmbedding (tulip.py:63-73): optional circular W padding by (2,2), Conv2d(Cin->E,(p0,kw),
- * stride (p0,p1)), BCHW->BHWC, LayerNorm(E).  img (B,Cin,Hin,Win) fp32 -> out (B,Hin/p0,Win/p1,E). */
+ * stride (p0,p1)), BCHW->BHWC, LayerNorm(E).  img (B,Cin,Hin,Win) fp32 -> out (B,Hin/p0,Win/p1,E).
+ * out_bf16 (optional): the same rows in bf16 with row pitch ld_bf16 (x_save half of the first skip concat, tulip.py:715). */
 int tulip_patch_embed_fwd(const float* img, const float* w, const float* b, const float* gamma, const float* beta,
                           float* out, int B, int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular,
-                          float eps, hipStream_t stream);
+                          float eps, uint16_t* out_bf16, int ld_bf16, hipStream_t stream);
 /* parameter gradients of the above (the input image needs no gradient).  partial_stride > 0: dw/db/dgamma/
  * dbeta point into row 0 of a [tulip_patch_embed_bwd_blocks(ntok)][partial_stride] partial buffer (plain
  * stores; fold with tulip_reduce_rows2); partial_stride == 0: accumulate atomically into the gradients. */

@@ -56,7 +56,7 @@ SIGNATURES = {
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],
     "tulip_layernorm_bwd_params": [P, P, P, P, P, P, I, I, I, I, I, I, P],
-    "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P],
+    "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P, I, P],
     "tulip_patch_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "tulip_patch_embed_bwd_blocks": [I],
     "tulip_window_attn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],

@@ -213,25 +213,33 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
             }
             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            // ldo2 > 0: a bf16 copy for the next GEMM on the path (out2 with ldo2 == 0 is the wgrad row-sum output)
+            if (p.out2 && p.ldo2 > 0) *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(v);
         } break;
         case TULIP_EPI_RESID_F32: {
             const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
             const float* a = (const float*)p.aux + (size_t)m * p.ldaux + n;
             const float4 q0 = *(const float4*)a, q1 = *(const float4*)(a + 4);
             float* o = (float*)p.out + (size_t)m * p.ldo + n;
-            *(float4*)o = make_float4(q0.x + s * v[0], q0.y + s * v[1], q0.z + s * v[2], q0.w + s * v[3]);
-            *(float4*)(o + 4) = make_float4(q1.x + s * v[4], q1.y + s * v[5], q1.z + s * v[6], q1.w + s * v[7]);
+            const float r[8] = {q0.x + s * v[0], q0.y + s * v[1], q0.z + s * v[2], q0.w + s * v[3],
+                                q1.x + s * v[4], q1.y + s * v[5], q1.z + s * v[6], q1.w + s * v[7]};
+            *(float4*)o = make_float4(r[0], r[1], r[2], r[3]);
+            *(float4*)(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            if (p.out2 && p.ldo2 > 0) *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(r);
         } break;
         case TULIP_EPI_PIXSHUF2_F32: {
             // token m=(b*H+h)*W+w, column n=4c+2i+j  ->  out[b, 2h+i, 2w+j, c], C_out = N/4
             const int w = m % p.psW, t = m / p.psW;
             const int h = t % p.psH, b = t / p.psH;
             const int co = p.N >> 2;
-            float* o = (float*)p.out;
+            float* o = (float*)p.out;               // fp32 (B,2H,2W,C_out), optional
+            bf16_t* o2 = (bf16_t*)p.out2;           // bf16 with row pitch ldo2 (e.g. the first half of a concat buffer)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int c = (n + r) >> 2, i = (r >> 1) & 1, j = r & 1;
-                o[(((size_t)b * 2 * p.psH + 2 * h + i) * (2 * p.psW) + 2 * w + j) * co + c] = v[r];
+                const size_t tok = ((size_t)b * 2 * p.psH + 2 * h + i) * (2 * p.psW) + 2 * w + j;
+                if (o) o[tok * co + c] = v[r];
+                if (o2) o2[tok * p.ldo2 + c] = f2bf(v[r]);
             }
         } break;
         case TULIP_EPI_SPLIT_F32: {

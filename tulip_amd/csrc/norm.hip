@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
                                                               const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ out,
-                                                              EmbedGeom g, float eps) {
+                                                              bf16_t* __restrict__ out16, int ld16, EmbedGeom g,
+                                                              float eps) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int ntok = g.B * g.Ho * g.Wo;
@@ -302,8 +303,13 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
         const float mu = group_sum<64>((v0 ? a0 : 0.f) + (v1 ? a1 : 0.f)) * invE;
         const float d0 = v0 ? a0 - mu : 0.f, d1 = v1 ? a1 - mu : 0.f;
         const float rs = rsqrtf(group_sum<64>(d0 * d0 + d1 * d1) * invE + eps);
-        if (v0) out[(size_t)tok * g.E + c0] = d0 * rs * ga0 + be0;
-        if (v1) out[(size_t)tok * g.E + c1] = d1 * rs * ga1 + be1;
+        const float y0 = d0 * rs * ga0 + be0, y1 = d1 * rs * ga1 + be1;
+        if (v0) out[(size_t)tok * g.E + c0] = y0;
+        if (v1) out[(size_t)tok * g.E + c1] = y1;
+        if (out16) {                                  // bf16 copy (x_save half of the first skip concat)
+            if (v0) out16[(size_t)tok * ld16 + c0] = f2bf(y0);
+            if (v1) out16[(size_t)tok * ld16 + c1] = f2bf(y1);
+        }
     }
 }
 
@@ -581,7 +587,8 @@ extern "C" int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, co
 
 extern "C" int tulip_patch_embed_fwd(const float* img, const float* w, const float* b, const float* gamma,
                                      const float* beta, float* out, int B, int Cin, int Hin, int Win, int E, int p0,
-                                     int p1, int kw, int circular, float eps, hipStream_t stream) {
+                                     int p1, int kw, int circular, float eps, uint16_t* out_bf16, int ld_bf16,
+                                     hipStream_t stream) {
     EmbedGeom g;
     if (!embed_geom(g, B, Cin, Hin, Win, E, p0, p1, kw, circular)) return TULIP_ERR_ARG;
     const int ntok = g.B * g.Ho * g.Wo;
@@ -589,10 +596,10 @@ extern "C" int tulip_patch_embed_fwd(const float* img, const float* w, const flo
     const int grid = std::min((ntok + 3) / 4, 256 * 8);
     if (g.taps <= EMB_MAXT)
         hipLaunchKernelGGL(patch_embed_fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, beta, out,
-                           g, eps);
+                           (bf16_t*)out_bf16, ld_bf16, g, eps);
     else
         hipLaunchKernelGGL(patch_embed_fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, beta, out,
-                           g, eps);
+                           (bf16_t*)out_bf16, ld_bf16, g, eps);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

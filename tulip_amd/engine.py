@@ -191,12 +191,11 @@ class Plan:
                 self.f32(f"enc{s}.mmean", Ms // 4)
                 self.f32(f"enc{s}.mrstd", Ms // 4)
                 self.f32(f"dec{s}.in", Ms, Cs)     # skip-linear output = decoder stage input
-                self.f32(f"dec{s}.xu", Ms, Cs)     # unmerged stream arriving from the coarser level
                 self.f32(f"dec{s}.dxu", Ms, Cs)
                 self.f32(f"dec{s}.dx", Ms, Cs)
                 self.b16(f"dec{s}.cat", Ms, 2 * Cs)
                 self.b16(f"dec{s}.dyskip", Ms, Cs)
-            self.b16(f"lvl{s}.xb", Ms, Cs)         # bf16 cast feeding a PatchUnmerging expand
+            self.b16(f"lvl{s}.xb", Ms, Cs)         # bf16 copy of the stage output feeding a PatchUnmerging expand
         for spec in eng.blocks:
             M, C = B * spec.H * spec.W, spec.C
             Hd = eng.hidden(C)
@@ -385,7 +384,8 @@ class TulipEngine:
         return (sp.C == 96 and sp.nh == 3 and self.hidden(sp.C) == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
                 and sp.H % 2 == 0)
 
-    def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout):
+    def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout, out_bf16=None):
+        """out_bf16: the block output also leaves as a bf16 [M][C] copy (operand of a PatchUnmerging GEMM)."""
         W_ = self.params
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
@@ -405,6 +405,8 @@ class TulipEngine:
                 bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=B, H=sp.H, W=sp.W,
                 shift_h=sp.sft[0], shift_w=sp.sft[1], masked=int(sp.shift), eps=self.eps)
+            if out_bf16 is not None:
+                ops.cast_f32_bf16(xout, out_bf16, M, C)
             return
         ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
                           P[p + ".mean1"], P[p + ".rstd1"], M, C, self.eps)
@@ -421,24 +423,26 @@ class TulipEngine:
                  bias=W_.p32(p + ".mlp.fc1.bias"), out=P[p + ".h"], out2=P[p + ".g"], ldo2=Hd)
         self._gemm(P[p + ".g"], W_.p16(p + ".mlp.fc2.weight"), M, C, Hd, lda=Hd, ldb=Hd, epi=EPI_RESID_F32,
                  bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], ldaux=C,
-                 rowscale=self._ds(P, sp, 1), rows_per_sample=tok)
+                 rowscale=self._ds(P, sp, 1), rows_per_sample=tok, out2=out_bf16, ldo2=C if out_bf16 is not None else 0)
 
-    def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin):
+    def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin, out_bf16=None):
+        """out_bf16: bf16 copy of the stage output, written by the last block's fc2 epilogue."""
         x = xin
-        for sp in specs:
-            self._block_fwd(P, sp, x, P[sp.prefix + ".out"])
+        for k, sp in enumerate(specs):
+            self._block_fwd(P, sp, x, P[sp.prefix + ".out"], out_bf16 if k == len(specs) - 1 else None)
             x = P[sp.prefix + ".out"]
         return x
 
-    def _unmerge_fwd(self, P: Plan, prefix: str, s: int, x, out):
-        """PatchUnmerging (tulip.py:117-123) of level-s stream x -> level s-1 stream `out`."""
+    def _unmerge_fwd(self, P: Plan, prefix: str, s: int):
+        """PatchUnmerging (tulip.py:117-123) of the level-s stream (its bf16 copy lvl{s}.xb, written by the producing
+        stage) -> first half of the level s-1 concat buffer (tulip.py:715), bf16, straight from the PixelShuffle
+        epilogue: the fp32 unmerged stream has no other reader."""
         m, W_ = self.model, self.params
         B = P.B
         H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
         M = B * H * W
-        ops.cast_f32_bf16(x, P[f"lvl{s}.xb"], M, C)
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
-                 bias=W_.p32(prefix + ".expand.bias"), out=out, psH=H, psW=W)
+                 bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
     def run_forward(self, P: Plan, with_loss: bool = True):
         """TULIP.forward (tulip.py:702-737) on P.x_in / P.target -> P.pred, P.losses."""
@@ -451,10 +455,14 @@ class TulipEngine:
         ops.patch_embed_fwd(P.x_in, W_.p32("patch_embed.proj.weight"), W_.p32("patch_embed.proj.bias"),
                             W_.p32("patch_embed.norm.weight"), W_.p32("patch_embed.norm.bias"), P["enc0.in"], B,
                             m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
-                            m.circular_padding, self.eps)
+                            m.circular_padding, self.eps,
+                            out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E)
+        # every encoder stage input is x_save[s]: its bf16 copy goes straight into the second half of the level's
+        # concat buffer (tulip.py:715) from the kernel that produces it
         x = None
         for s in range(nl):
-            x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"])
+            x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"],
+                                out_bf16=P[f"lvl{s}.xb"] if (s == nl - 1 and nl > 1) else None)
             if s < nl - 1:  # PatchMerging (tulip.py:101-106)
                 Hs, Ws, Cs = H0 >> s, W0 >> s, E << s
                 rows = B * (Hs // 2) * (Ws // 2)
@@ -462,20 +470,24 @@ class TulipEngine:
                 ops.layernorm_fwd(x, W_.p32(pre + ".norm.weight"), W_.p32(pre + ".norm.bias"), P[f"enc{s}.xm"],
                                   P[f"enc{s}.mmean"], P[f"enc{s}.mrstd"], rows, 4 * Cs, self.eps, merge=True, B=B,
                                   H=Hs, W=Ws)
+                save16 = (P[f"dec{s + 1}.cat"].data_ptr() + 2 * (2 * Cs)) if s + 1 < nl - 1 else None
                 self._gemm(P[f"enc{s}.xm"], W_.p16(pre + ".reduction.weight"), rows, 2 * Cs, 4 * Cs, lda=4 * Cs,
-                         ldb=4 * Cs, epi=EPI_F32, out=P[f"enc{s + 1}.in"])
-        self._unmerge_fwd(P, "first_patch_expanding", nl - 1, x, P[f"dec{nl - 2}.xu"])
+                         ldb=4 * Cs, epi=EPI_F32, out=P[f"enc{s + 1}.in"], out2=save16,
+                         ldo2=4 * Cs if save16 is not None else 0)
+        if nl > 1:
+            self._unmerge_fwd(P, "first_patch_expanding", nl - 1)
         for i in range(nl - 1):
             s = nl - i - 2
             Cs = E << s
             Ms = B * (H0 >> s) * (W0 >> s)
             pre = f"skip_connection_layers.{i}"
-            ops.concat_cast(P[f"dec{s}.xu"], P[f"enc{s}.in"], P[f"dec{s}.cat"], Ms, Cs)      # tulip.py:715
+            # dec{s}.cat = cat[unmerged stream, x_save[s]] (tulip.py:715) was filled by its two producers
             self._gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
                      bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"])
-            x = self._stage_fwd(P, self.dec_blocks[i], P[f"dec{s}.in"])
+            x = self._stage_fwd(P, self.dec_blocks[i], P[f"dec{s}.in"],
+                                out_bf16=P[f"lvl{s}.xb"] if i < nl - 2 else None)
             if i < nl - 2:
-                self._unmerge_fwd(P, f"layers_up.{i}.upsample", s, x, P[f"dec{s - 1}.xu"])
+                self._unmerge_fwd(P, f"layers_up.{i}.upsample", s)
         M0 = B * H0 * W0
         ops.layernorm_fwd(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), P["tail.xn"], P["tail.mean"],
                           P["tail.rstd"], M0, E, self.eps)

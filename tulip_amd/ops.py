@@ -103,9 +103,10 @@ def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False,
     check(rc, "tulip_layernorm_bwd_params")
 
 
-def patch_embed_fwd(img, w, b, gamma, beta, out, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps):
+def patch_embed_fwd(img, w, b, gamma, beta, out, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps, out_bf16=None,
+                    ld_bf16=0):
     rc = _lib.load().tulip_patch_embed_fwd(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, Hin, Win, E,
-                                           p0, p1, kw, int(circular), eps, _stream())
+                                           p0, p1, kw, int(circular), eps, _p(out_bf16), ld_bf16, _stream())
     check(rc, "tulip_patch_embed_fwd")
 
 
