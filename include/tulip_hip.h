@@ -37,6 +37,11 @@ typedef struct ihipStream_t* hipStream_t;
 #define TULIP_EPI_PIXSHUF2_F32 5 /* PatchUnmerging scatter: PixelShuffle(2) + BCHW->BHWC (tulip.py:120-122) */
 #define TULIP_EPI_ATOMIC_F32 6   /* out_f32 += acc (split-K weight gradients, atomics)                  */
 #define TULIP_EPI_SPLIT_F32 7    /* out_f32[split][M][ldo] = acc : split-K partial slabs (deterministic) */
+#define TULIP_EPI_UNSHUF2_BF16 8 /* inverse of 5, bf16: row m = fine token (b,2h+i,2w+j), column c -> out[(b,h,w)][4c+2i+j]
+                                    with psH, psW = the COARSE grid, N = fine channels (backward of PixelShuffle(2)) */
+/* TULIP_EPI_F32 / TULIP_EPI_RESID_F32 with out2 != NULL and ldo2 > 0 additionally store bf16(result * rowscale)
+ * at out2[m*ldo2 + n] (the operand of the next GEMM on the path); TULIP_EPI_PIXSHUF2_F32 stores fp32 to `out`
+ * and/or bf16 to `out2` (row pitch ldo2), whichever is non-NULL. */
 
 /* C[M,N] = opA[M,K] . opB[N,K]^T, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
  * a_trans=0: A is [M][lda]; a_trans=1: A is [K][lda] (A^T stored).  Same for B ([N][ldb] / [K][ldb]).

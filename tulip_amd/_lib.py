@@ -95,7 +95,7 @@ SIGNATURES = {
 }
 
 (EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, EPI_ATOMIC_F32,
- EPI_SPLIT_F32) = range(8)
+ EPI_SPLIT_F32, EPI_UNSHUF2_BF16) = range(9)
 
 _lib = None
 

@@ -213,8 +213,13 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
             }
             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            // ldo2 > 0: a bf16 copy for the next GEMM on the path (out2 with ldo2 == 0 is the wgrad row-sum output)
-            if (p.out2 && p.ldo2 > 0) *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(v);
+            // ldo2 > 0: a bf16 copy for the next GEMM on the path (out2 with ldo2 == 0 is the wgrad row-sum output),
+            // times the DropPath scale of the branch it enters
+            if (p.out2 && p.ldo2 > 0) {
+                const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+                const float r[8] = {v[0] * s, v[1] * s, v[2] * s, v[3] * s, v[4] * s, v[5] * s, v[6] * s, v[7] * s};
+                *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(r);
+            }
         } break;
         case TULIP_EPI_RESID_F32: {
             const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
@@ -241,6 +246,15 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
                 if (o) o[tok * co + c] = v[r];
                 if (o2) o2[tok * p.ldo2 + c] = f2bf(v[r]);
             }
+        } break;
+        case TULIP_EPI_UNSHUF2_BF16: {
+            // fine token m=(b*2H+2h+i)*2W+2w+j, column n=c  ->  out[(b*H+h)*W+w][4c+2i+j], row pitch ldo
+            const int W2 = 2 * p.psW, H2 = 2 * p.psH;
+            const int wf = m % W2, t = m / W2;
+            const int hf = t % H2, b = t / H2;
+            bf16_t* o = (bf16_t*)p.out + (((size_t)b * p.psH + (hf >> 1)) * p.psW + (wf >> 1)) * p.ldo + 2 * (hf & 1) + (wf & 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[4 * (n + r)] = f2bf(v[r]);
         } break;
         case TULIP_EPI_SPLIT_F32: {
             // split-K partial slab: out is [splits][M][ldo], folded by tulip_reduce_rows2 / splitk_epilogue

@@ -26,6 +26,7 @@ import torch
 
 from . import ops
 from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32,
+                   EPI_UNSHUF2_BF16,
                    EPI_SPLIT_F32)
 
 ALIGN = 64  # floats; every parameter starts on a 256-byte boundary of the flat buffer
@@ -191,7 +192,6 @@ class Plan:
                 self.f32(f"enc{s}.mmean", Ms // 4)
                 self.f32(f"enc{s}.mrstd", Ms // 4)
                 self.f32(f"dec{s}.in", Ms, Cs)     # skip-linear output = decoder stage input
-                self.f32(f"dec{s}.dxu", Ms, Cs)
                 self.f32(f"dec{s}.dx", Ms, Cs)
                 self.b16(f"dec{s}.cat", Ms, 2 * Cs)
                 self.b16(f"dec{s}.dyskip", Ms, Cs)
@@ -796,19 +796,20 @@ class TulipEngine:
             self._block_bwd(P, specs[k], xin, dx, G, have_dyb=have_dyb, next_cast=nc)
             have_dyb = True
 
-    def _unmerge_bwd(self, P: Plan, prefix: str, s: int, dfine, dx_out, G):
-        """Backward of PatchUnmerging from the fine-level grad `dfine` (level s-1 layout) into
-        dx_out (level s, fp32, overwritten)."""
+    def _unmerge_bwd(self, P: Plan, prefix: str, s: int, dx_out, G, cast=None):
+        """Backward of PatchUnmerging: lvl{s}.dz2 (the fine-level gradient, already un-shuffled to bf16 by the epilogue
+        of the GEMM that produced it) -> dx_out (level s, fp32, overwritten).  cast = (bf16 buffer, DropPath scale,
+        tokens per sample): the operand of the next GEMM on the chain, written by the same epilogue."""
         m, W_ = self.model, self.params
         B = P.B
         H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
         M = B * H * W
         dz = P[f"lvl{s}.dz2"]
-        ops.unshuffle2_cast(dfine, dz, B, H, W, C // 2)
-        self._release_deferred()
+        cb, cs, ct = cast if cast is not None else (None, None, 1)
         self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), G(prefix + ".expand.bias"))
         self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
-                 out=dx_out, ldo=C)
+                 out=dx_out, ldo=C, out2=cb, ldo2=C if cb is not None else 0, rowscale=cs, rows_per_sample=ct)
+        self._release_deferred()
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
                      join_tags=None):
@@ -872,33 +873,38 @@ class TulipEngine:
             dx = P[f"dec{s}.dx"]
             if i < nl - 2:
                 # dx currently holds nothing for this level: pull the grad down from the finer level
-                self._unmerge_bwd(P, f"layers_up.{i}.upsample", s, P[f"dec{s - 1}.dxu"], dx, G)
+                self._unmerge_bwd(P, f"layers_up.{i}.upsample", s, dx, G,
+                                  cast=self._mlp_cast(P, self.dec_blocks[i][-1]))
             dys = P[f"dec{s}.dyskip"]
-            self._stage_bwd(P, self.dec_blocks[i], P[f"dec{s}.in"], dx, G, have_dyb=(i == nl - 2),
+            self._stage_bwd(P, self.dec_blocks[i], P[f"dec{s}.in"], dx, G, have_dyb=True,
                             next_cast=(dys, None, 1))          # the skip Linear's dgrad/wgrad operand
             pre = f"skip_connection_layers.{i}"
             self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
-            # grad w.r.t. the first concat half (the unmerged stream); the x_save half is deferred
-            self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32,
-                     out=P[f"dec{s}.dxu"], ldo=Cs)
+            # grad w.r.t. the first concat half (the unmerged stream), un-shuffled to the coarser level's layout in bf16 by
+            # the epilogue: it is the operand of that level's PatchUnmerging backward; the x_save half is deferred
+            self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_UNSHUF2_BF16,
+                     out=P[f"lvl{s + 1}.dz2"], ldo=4 * Cs, psH=H0 >> (s + 1), psW=W0 >> (s + 1))
             hook(f"dec{i}")
         # ---- bottleneck unmerge
         dx = P[f"enc{nl - 1}.dx"]
         if nl > 1:
-            self._unmerge_bwd(P, "first_patch_expanding", nl - 1, P[f"dec{nl - 2}.dxu"], dx, G)
+            self._unmerge_bwd(P, "first_patch_expanding", nl - 1, dx, G,
+                              cast=self._mlp_cast(P, self.enc_blocks[nl - 1][-1]))
         # ---- encoder, coarse -> fine
         for s in reversed(range(nl)):
             dx = P[f"enc{s}.dx"]
             bottom_to_merge = (s == nl - 1 and s > 0)
-            self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G, have_dyb=(s < nl - 1),
+            self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G, have_dyb=(nl > 1),
                             next_cast=(P[f"enc{s}.dyb"], None, 1) if bottom_to_merge else None)
             if s < nl - 1:
                 # deferred skip-connection gradient w.r.t. x_save[s] (second concat half, tulip.py:715)
                 Cs = E << s
                 Ms = B * (H0 >> s) * (W0 >> s)
                 i = nl - s - 2
+                # (for 0 < s the sum is also what the PatchMerging backward below consumes: bf16 copy from the epilogue)
                 self._gemm(P[f"dec{s}.dyskip"], W_.p16(f"skip_connection_layers.{i}.weight") + 2 * Cs, Ms, Cs, Cs,
-                         lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32, out=dx, ldo=Cs, accumulate=True)
+                         lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32, out=dx, ldo=Cs, accumulate=True,
+                         out2=P[f"enc{s}.dyb"] if s > 0 else None, ldo2=Cs if s > 0 else 0)
             if s > 0:
                 # PatchMerging backward of level s-1
                 Cp = E << (s - 1)
@@ -906,8 +912,6 @@ class TulipEngine:
                 rows = B * (Hp // 2) * (Wp // 2)
                 pre = f"layers.{s - 1}.downsample"
                 dyb, dxm = P[f"enc{s}.dyb"], P["t.dxm"]
-                if not bottom_to_merge:      # dx was modified by the deferred skip gradient after the last LN backward
-                    ops.cast_f32_bf16(dx, dyb, rows, 2 * Cp)
                 self._wgrad(dyb, 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows,
                             G(pre + ".reduction.weight"))
                 self._gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,

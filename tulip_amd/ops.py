@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL,  # noqa: F401
-                   EPI_PIXSHUF2_F32, EPI_RESID_F32, EPI_SPLIT_F32, check)
+                   EPI_PIXSHUF2_F32, EPI_RESID_F32, EPI_SPLIT_F32, EPI_UNSHUF2_BF16, check)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
