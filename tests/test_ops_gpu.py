@@ -715,3 +715,59 @@ def test_wgrad_group_and_multi_region_fold(ops):
     torch.cuda.synchronize()
     for k in range(16):
         assert torch.allclose(outs[k], part[:, (k % 2) * C:(k % 2 + 1) * C].sum(0), atol=1e-4)
+
+
+def test_gemm_bf16_copies_for_the_next_gemm(ops):
+    """The second outputs that replace stand-alone cast / concat / un-shuffle launches: bf16(result * rowscale) of
+    EPI_F32 (also when accumulating) and EPI_RESID_F32, the bf16 PixelShuffle scatter into a wider (concat) buffer, and
+    the inverse scatter EPI_UNSHUF2_BF16 (backward of nn.PixelShuffle(2), tulip.py:120-122)."""
+    M, N, K, rps = 256, 96, 384, 64
+    A, B, bias = bf(rnd(M, K)), bf(rnd(N, K, scale=0.05)), rnd(N, scale=0.1)
+    rs = torch.tensor([0.0, 1.25, 1.0, 1.25], device=DEV)
+    acc0 = rnd(M, N, seed=7)
+    out, cp = acc0.clone(), torch.zeros(M, 2 * N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_F32, out=out, accumulate=True, out2=cp.data_ptr() + 2 * N,
+             ldo2=2 * N, rowscale=rs, rows_per_sample=rps)
+    ref = acc0 + A.float() @ B.float().t()
+    close(out, ref, 1e-5, 1e-4, "f32 accumulate")
+    assert torch.equal(cp[:, N:], (out * rs.repeat_interleave(rps)[:, None]).bfloat16())   # copy of what was stored
+    assert not cp[:, :N].any()
+    resid = rnd(M, N, seed=5)
+    out, cp = torch.empty(M, N, device=DEV), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(A, B, M, N, K, lda=K, ldb=K, epi=ops.EPI_RESID_F32, bias=bias, out=out, aux=resid, ldaux=N, rowscale=rs,
+             rows_per_sample=rps, out2=cp, ldo2=N)
+    assert torch.equal(cp, out.bfloat16())
+    # PixelShuffle(2) scatter in bf16 into the first half of a concat buffer, no fp32 output at all
+    Bn, H, W, C = 2, 4, 8, 96
+    Mc, Nc = Bn * H * W, 2 * C
+    A2, Wt, b2 = bf(rnd(Mc, C)), bf(rnd(Nc, C, scale=0.05)), rnd(Nc, scale=0.1)
+    cat = torch.zeros(Bn * 2 * H * 2 * W, C, device=DEV, dtype=torch.bfloat16)          # [tokens][2 * C/2]
+    ops.gemm(A2, Wt, Mc, Nc, C, lda=C, ldb=C, epi=ops.EPI_PIXSHUF2_F32, bias=b2, out=None, out2=cat, ldo2=C, psH=H,
+             psW=W)
+    z = (A2.float() @ Wt.float().t() + b2).reshape(Bn, H, W, Nc).permute(0, 3, 1, 2)
+    ref = F.pixel_shuffle(z, 2).permute(0, 2, 3, 1).reshape(-1, C // 2)
+    close(cat[:, :C // 2], ref, 2 ** -7, 1e-4, "pixshuf2 bf16")
+    assert not cat[:, C // 2:].any()
+    # inverse: rows are fine tokens (b, 2h+i, 2w+j), columns fine channels c -> [(b,h,w)][4c+2i+j]
+    Cf = 96
+    Mf = Bn * 2 * H * 2 * W
+    A3, W3 = bf(rnd(Mf, 64)), bf(rnd(Cf, 64, scale=0.1))
+    dz = torch.zeros(Bn * H * W, 4 * Cf, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(A3, W3, Mf, Cf, 64, lda=64, ldb=64, epi=ops.EPI_UNSHUF2_BF16, out=dz, ldo=4 * Cf, psH=H, psW=W)
+    y = (A3.float() @ W3.float().t()).reshape(Bn, 2 * H, 2 * W, Cf).permute(0, 3, 1, 2)
+    ref = F.pixel_unshuffle(y, 2).permute(0, 2, 3, 1).reshape(Bn * H * W, 4 * Cf)
+    close(dz, ref, 2 ** -7, 1e-4, "unshuf2 bf16")
+
+
+def test_patch_embed_bf16_copy(ops):
+    """tulip_patch_embed_fwd's optional second output: the same rows in bf16 at a caller-chosen pitch."""
+    B, Hin, Win, E = 2, 16, 64, 96
+    img = rnd(B, 1, Hin, Win)
+    w, b, g, be = rnd(E, 8, scale=0.3), rnd(E, scale=0.1), 1 + rnd(E, scale=0.1), rnd(E, scale=0.1)
+    ntok = B * Hin * (Win // 4)
+    out = torch.empty(ntok, E, device=DEV)
+    cat = torch.zeros(ntok, 2 * E, device=DEV, dtype=torch.bfloat16)
+    ops.patch_embed_fwd(img, w, b, g, be, out, B, 1, Hin, Win, E, 1, 4, 8, True, 1e-6,
+                        out_bf16=cat.data_ptr() + 2 * E, ld_bf16=2 * E)
+    torch.cuda.synchronize()
+    assert torch.equal(cat[:, E:], out.bfloat16()) and not cat[:, :E].any()
