@@ -259,7 +259,7 @@ def test_layernorm_merge(ops, B, H, W, Cin):
 
 # ------------------------------------------------------------------ patch embedding
 @pytest.mark.parametrize("circular", [True, False])
-@pytest.mark.parametrize("E,Hin,Win", [(96, 16, 1024), (48, 8, 256)])
+@pytest.mark.parametrize("E,Hin,Win", [(96, 16, 1024), (48, 8, 256), (96, 3, 20)])
 def test_patch_embed(ops, circular, E, Hin, Win):
     B = 2
     cfg = O.TulipConfig(img_size=(Hin, Win), embed_dim=E, circular_padding=circular)

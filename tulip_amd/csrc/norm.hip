@@ -313,6 +313,79 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
     }
 }
 
+// Single-channel images with one-row patches (every range-image configuration of the reference: in_chans 1, patch
+// (1,4), KW = 8 taps with circular padding or 4 without): a tap is just a column offset, and a wave works on 4
+// consecutive tokens at once so that their loads / two LayerNorm reductions / stores are 4 independent chains (the
+// generic kernel spends most of its 30 us in per-tap index arithmetic and one dependent chain per token).
+template <int KW>
+__global__ __launch_bounds__(256) void patch_embed_fwd_row_kernel(const float* __restrict__ img,
+                                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ out,
+                                                                  bf16_t* __restrict__ out16, int ld16, EmbedGeom g,
+                                                                  float eps) {
+    constexpr int UNR = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int ntok = g.B * g.Ho * g.Wo;
+    const int c0 = lane, c1 = lane + 64;
+    const bool v0 = c0 < g.E, v1 = c1 < g.E;
+    const float invE = 1.0f / (float)g.E;
+    float w0[KW], w1[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        w0[t] = v0 ? w[c0 * KW + t] : 0.f;
+        w1[t] = v1 ? w[c1 * KW + t] : 0.f;
+    }
+    const float b0 = v0 ? bias[c0] : 0.f, b1 = v1 ? bias[c1] : 0.f;
+    const float ga0 = v0 ? gamma[c0] : 0.f, ga1 = v1 ? gamma[c1] : 0.f;
+    const float be0 = v0 ? beta[c0] : 0.f, be1 = v1 ? beta[c1] : 0.f;
+    for (int tok0 = wave * UNR; tok0 < ntok; tok0 += nwaves * UNR) {
+        float xt[UNR][KW];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int tok = min(tok0 + u, ntok - 1);
+            const int wq = tok % g.Wo;
+            const float* rowp = img + (size_t)(tok / g.Wo) * g.Win;          // Cin == 1, p0 == 1: image row = b*Ho + h
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                int col = g.p1 * wq + k;
+                if (g.circular) { col -= 2; if (col < 0) col += g.Win; if (col >= g.Win) col -= g.Win; }
+                xt[u][k] = rowp[col];
+            }
+        }
+        float a0[UNR], a1[UNR], mu[UNR], rs[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            a0[u] = b0; a1[u] = b1;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { a0[u] += w0[k] * xt[u][k]; a1[u] += w1[k] * xt[u][k]; }
+            mu[u] = (v0 ? a0[u] : 0.f) + (v1 ? a1[u] : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) mu[u] = group_sum<64>(mu[u]) * invE;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            a0[u] = v0 ? a0[u] - mu[u] : 0.f; a1[u] = v1 ? a1[u] - mu[u] : 0.f;
+            rs[u] = a0[u] * a0[u] + a1[u] * a1[u];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) rs[u] = rsqrtf(group_sum<64>(rs[u]) * invE + eps);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int tok = tok0 + u;
+            if (tok >= ntok) break;
+            const float y0 = a0[u] * rs[u] * ga0 + be0, y1 = a1[u] * rs[u] * ga1 + be1;
+            if (v0) out[(size_t)tok * g.E + c0] = y0;
+            if (v1) out[(size_t)tok * g.E + c1] = y1;
+            if (out16) {
+                if (v0) out16[(size_t)tok * ld16 + c0] = f2bf(y0);
+                if (v1) out16[(size_t)tok * ld16 + c1] = f2bf(y1);
+            }
+        }
+    }
+}
+
 template <bool INREG>
 __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ img,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
@@ -594,6 +667,17 @@ extern "C" int tulip_patch_embed_fwd(const float* img, const float* w, const flo
     const int ntok = g.B * g.Ho * g.Wo;
     if (ntok <= 0) return TULIP_OK;
     const int grid = std::min((ntok + 3) / 4, 256 * 8);
+    if (g.Cin == 1 && g.p0 == 1 && g.taps == g.kw && (g.kw == 8 || g.kw == 4) && E <= 128) {
+        const int grid4 = std::min((ntok + 15) / 16, 256 * 2);   // 8 waves per CU, each amortises its weight loads
+        if (g.kw == 8)
+            hipLaunchKernelGGL(patch_embed_fwd_row_kernel<8>, dim3(grid4), dim3(256), 0, stream, img, w, b, gamma, beta,
+                               out, (bf16_t*)out_bf16, ld_bf16, g, eps);
+        else
+            hipLaunchKernelGGL(patch_embed_fwd_row_kernel<4>, dim3(grid4), dim3(256), 0, stream, img, w, b, gamma, beta,
+                               out, (bf16_t*)out_bf16, ld_bf16, g, eps);
+        TULIP_CHECK_LAUNCH();
+        return TULIP_OK;
+    }
     if (g.taps <= EMB_MAXT)
         hipLaunchKernelGGL(patch_embed_fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, img, w, b, gamma, beta, out,
                            (bf16_t*)out_bf16, ld_bf16, g, eps);
