@@ -63,3 +63,30 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU or PyTorch fallback" in str(e)
     else:
         raise AssertionError("loading a missing library must raise")
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The descriptor structs passed by pointer (tulip_swin96_desc, tulip_swin96_bwd_desc, tulip_reduce_region,
+    tulip_wgrad_item): size and every field offset of the ctypes mirror against what a C compiler makes of the header."""
+    import ctypes
+    import subprocess
+    structs = {"tulip_swin96_desc": _lib.Swin96Desc, "tulip_swin96_bwd_desc": _lib.Swin96BwdDesc,
+               "tulip_reduce_region": _lib.ReduceRegion, "tulip_wgrad_item": _lib.WgradItem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tulip_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _t in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _t in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    # and the compile-time limits the Python side mirrors
+    hdr = open(os.path.join(ROOT, "include", "tulip_hip.h")).read()
+    assert int(re.search(r"#define TULIP_REDUCE_REGIONS_MAX (\d+)", hdr).group(1)) == _lib.REDUCE_REGIONS_MAX
+    assert int(re.search(r"#define TULIP_WGRAD_GROUP_MAX (\d+)", hdr).group(1)) == _lib.WGRAD_GROUP_MAX
