@@ -47,16 +47,43 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // erf-GELU (nn.GELU default, tulip.py:183,196) and its derivative.  erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, two orders below the bf16 rounding of the stored result): one exp, one rcp, six
-// FMAs -- libm's erff was ~40 % of the fc1-forward / fc2-dgrad GEMM time.  exp(-z^2), z = x/sqrt(2), is
+// (|abs err| <= 1.5e-7 (+ 1 ulp of the hardware reciprocal), two orders below the bf16 rounding of the stored result):
+// one exp, one rcp, six FMAs -- libm's erff was ~40 % of the fc1-forward / fc2-dgrad GEMM time.  exp(-z^2), z = x/sqrt(2), is
 // shared between erf and the Gaussian term of the derivative.
 __device__ __forceinline__ void gelu_terms(float x, float& erf_z, float& gauss) {
     const float z = x * 0.70710678118654752440f;
     const float az = fabsf(z);
-    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));   // v_rcp_f32 (1 ulp); the IEEE divide is 10 more instructions
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     gauss = __expf(-az * az);                       // = exp(-x^2/2)
     erf_z = copysignf(1.0f - poly * gauss, z);
+}
+// two elements per lane: the polynomial / product chain maps onto v_pk_fma_f32 / v_pk_mul_f32 (rcp and exp stay scalar)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_terms2(f32x2 x, f32x2& erf_z, f32x2& gauss) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    const f32x2 az = __builtin_elementwise_abs(z);
+    const f32x2 den = __builtin_elementwise_fma(az, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
+    poly = poly * t;
+    const f32x2 m = -az * az;
+    gauss = (f32x2){__expf(m.x), __expf(m.y)};
+    const f32x2 e = __builtin_elementwise_fma(-poly, gauss, (f32x2){1.0f, 1.0f});
+    erf_z = (f32x2){copysignf(e.x, z.x), copysignf(e.y, z.y)};
+}
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
+    f32x2 e, g;
+    gelu_terms2(x, e, g);
+    return x * 0.5f * (e + 1.0f);
+}
+__device__ __forceinline__ f32x2 gelu_exact_grad2(f32x2 x) {
+    f32x2 e, g;
+    gelu_terms2(x, e, g);
+    return __builtin_elementwise_fma(x * 0.39894228040143267794f, g, (e + 1.0f) * 0.5f);
 }
 __device__ __forceinline__ float gelu_exact(float x) {
     float e, g;

@@ -205,7 +205,10 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
             float h[8], g[8];
             unpack8(hb, h);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) g[r] = gelu_exact(h[r]);   // gelu of the *stored* (rounded) h
+            for (int r = 0; r < 8; r += 2) {                       // gelu of the *stored* (rounded) h
+                const f32x2 y = gelu_exact2((f32x2){h[r], h[r + 1]});
+                g[r] = y.x; g[r + 1] = y.y;
+            }
             *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = hb;
             *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(g);
         } break;
@@ -213,7 +216,10 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
             float h[8];
             unpack8(*(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), h);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] *= gelu_exact_grad(h[r]);
+            for (int r = 0; r < 8; r += 2) {
+                const f32x2 d = gelu_exact_grad2((f32x2){h[r], h[r + 1]});
+                v[r] *= d.x; v[r + 1] *= d.y;
+            }
             *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = pack8(v);
         } break;
         case TULIP_EPI_F32: {

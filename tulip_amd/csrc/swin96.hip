@@ -282,8 +282,9 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const float4 bb = *(const float4*)(prm + P_B1 + c0);
             const bf16x4 hp = pack4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
             *(bf16x4*)(a.h + row * HID + c0) = hp;
-            gp[jj] = pack4(gelu_exact(bf2f((bf16_t)hp[0])), gelu_exact(bf2f((bf16_t)hp[1])),
-                           gelu_exact(bf2f((bf16_t)hp[2])), gelu_exact(bf2f((bf16_t)hp[3])));   // GELU of the stored h
+            const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
+            const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
+            gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
             *(bf16x4*)(a.g + row * HID + c0) = gp[jj];
         }
         const bf16x8 gf = cat8(gp[0], gp[1]);
@@ -495,8 +496,9 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_W2, PT2, 32 * s, j0, t, gq), dyf[s], acc, 0, 0, 0);
-            dp[jj] = pack4(acc[0] * gelu_exact_grad(bf2f((bf16_t)hc[jj][0])), acc[1] * gelu_exact_grad(bf2f((bf16_t)hc[jj][1])),
-                           acc[2] * gelu_exact_grad(bf2f((bf16_t)hc[jj][2])), acc[3] * gelu_exact_grad(bf2f((bf16_t)hc[jj][3])));
+            const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hc[jj][0]), bf2f((bf16_t)hc[jj][1])});
+            const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hc[jj][2]), bf2f((bf16_t)hc[jj][3])});
+            dp[jj] = pack4(acc[0] * d01.x, acc[1] * d01.y, acc[2] * d23.x, acc[3] * d23.y);
             *(bf16x4*)(a.dh + row * HID + j0 + 4 * gq) = dp[jj];
         }
         const bf16x8 df = cat8(dp[0], dp[1]);
