@@ -46,9 +46,8 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
 }
 
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
-    bf16x4 r;
-    r[0] = (short)f2bf(a); r[1] = (short)f2bf(b); r[2] = (short)f2bf(c); r[3] = (short)f2bf(d);
-    return r;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    return __builtin_bit_cast(bf16x4, (u32x2_t){pack_bf16x2(a, b), pack_bf16x2(c, d)});
 }
 
 __device__ __forceinline__ void store4(bf16_t* p, f32x4 v, float s) {

@@ -45,9 +45,8 @@ __device__ __forceinline__ int region(int x, int X, int wsz, int ssz) {       //
     return (ssz == 0 || x >= X - ssz) ? 2 : (x >= X - wsz ? 1 : 0);
 }
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
-    bf16x4 r;
-    r[0] = (short)f2bf(a); r[1] = (short)f2bf(b); r[2] = (short)f2bf(c); r[3] = (short)f2bf(d);
-    return r;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    return __builtin_bit_cast(bf16x4, (u32x2_t){pack_bf16x2(a, b), pack_bf16x2(c, d)});
 }
 __device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
