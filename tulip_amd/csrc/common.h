@@ -30,6 +30,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
+// a / d for a >= 0, d > 0 with d uniform over the launch (a kernel argument): the token grids, tokens per sample etc.
+// are powers of two in every configuration of the reference, and a 32-bit integer divide is ~40 VALU instructions
+// (a 64-bit one > 100) -- the scalar test picks a shift when it can.
+__device__ __forceinline__ int fast_div(int a, int d) {
+    return (d & (d - 1)) == 0 ? a >> (31 - __builtin_clz(d)) : a / d;
+}
+
 // sum / max over a power-of-two group of WIDTH lanes (WIDTH <= 64)
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {

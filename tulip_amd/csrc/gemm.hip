@@ -234,13 +234,13 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
             // ldo2 > 0: a bf16 copy for the next GEMM on the path (out2 with ldo2 == 0 is the wgrad row-sum output),
             // times the DropPath scale of the branch it enters
             if (p.out2 && p.ldo2 > 0) {
-                const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+                const float s = p.rowscale ? p.rowscale[fast_div(m, p.rows_per_sample)] : 1.0f;
                 const float r[8] = {v[0] * s, v[1] * s, v[2] * s, v[3] * s, v[4] * s, v[5] * s, v[6] * s, v[7] * s};
                 *(uint4*)((bf16_t*)p.out2 + (size_t)m * p.ldo2 + n) = pack8(r);
             }
         } break;
         case TULIP_EPI_RESID_F32: {
-            const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+            const float s = p.rowscale ? p.rowscale[fast_div(m, p.rows_per_sample)] : 1.0f;
             const float* a = (const float*)p.aux + (size_t)m * p.ldaux + n;
             const float4 q0 = *(const float4*)a, q1 = *(const float4*)(a + 4);
             float* o = (float*)p.out + (size_t)m * p.ldo + n;
@@ -252,8 +252,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
         } break;
         case TULIP_EPI_PIXSHUF2_F32: {
             // token m=(b*H+h)*W+w, column n=4c+2i+j  ->  out[b, 2h+i, 2w+j, c], C_out = N/4
-            const int w = m % p.psW, t = m / p.psW;
-            const int h = t % p.psH, b = t / p.psH;
+            const int t = fast_div(m, p.psW), w = m - t * p.psW;
+            const int b = fast_div(t, p.psH), h = t - b * p.psH;
             const int co = p.N >> 2;
             float* o = (float*)p.out;               // fp32 (B,2H,2W,C_out), optional
             bf16_t* o2 = (bf16_t*)p.out2;           // bf16 with row pitch ldo2 (e.g. the first half of a concat buffer)
@@ -268,8 +268,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
         case TULIP_EPI_UNSHUF2_BF16: {
             // fine token m=(b*2H+2h+i)*2W+2w+j, column n=c  ->  out[(b*H+h)*W+w][4c+2i+j], row pitch ldo
             const int W2 = 2 * p.psW, H2 = 2 * p.psH;
-            const int wf = m % W2, t = m / W2;
-            const int hf = t % H2, b = t / H2;
+            const int t = fast_div(m, W2), wf = m - t * W2;
+            const int b = fast_div(t, H2), hf = t - b * H2;
             bf16_t* o = (bf16_t*)p.out + (((size_t)b * p.psH + (hf >> 1)) * p.psW + (wf >> 1)) * p.ldo + 2 * (hf & 1) + (wf & 1);
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[4 * (n + r)] = f2bf(v[r]);
@@ -465,9 +465,9 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, const float* __restrict__ slabs,
                                                               int splits) {
     const int n8 = p.N >> 3;
-    const int64_t total = (int64_t)p.M * n8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int m = (int)(i / n8), n = (int)(i - (int64_t)m * n8) * 8;
+    const int total = p.M * n8;                 // (the launcher only folds outputs of < 2^31 8-column chunks)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int m = fast_div(i, n8), n = (i - m * n8) * 8;
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
         for (int sidx = 0; sidx < splits; ++sidx) {
             const float* src = slabs + ((size_t)sidx * p.M + m) * p.N + n;
@@ -553,6 +553,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     else rc = launch<true, false>(q, splits, stream);
     if (rc != TULIP_OK || !fold) return rc;
     const int64_t work = (int64_t)M * (N >> 3);
+    if (work >= (int64_t)1 << 31) return TULIP_ERR_ARG;
     const int grid = (int)std::min<int64_t>((work + 255) / 256, 2048);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, p, (const float*)workspace, splits);
     TULIP_CHECK_LAUNCH();

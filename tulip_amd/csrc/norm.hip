@@ -18,10 +18,10 @@ struct RowGeom {
 __device__ __forceinline__ size_t src_off(const RowGeom& g, int row, int e) {
     if (!g.merge) return (size_t)row * g.C + e;
     const int cin = g.C >> 2;
-    const int q = e / cin, ci = e - q * cin;  // q: 0 (0,0) 1 (1,0) 2 (0,1) 3 (1,1)
+    const int q = fast_div(e, cin), ci = e - q * cin;  // q: 0 (0,0) 1 (1,0) 2 (0,1) 3 (1,1)
     const int w2 = g.W >> 1, h2 = g.H >> 1;
-    const int wq = row % w2, t = row / w2;
-    const int hq = t % h2, b = t / h2;
+    const int t = fast_div(row, w2), wq = row - t * w2;
+    const int b = fast_div(t, h2), hq = t - b * h2;
     const int h = 2 * hq + (q & 1), w = 2 * wq + (q >> 1);
     return (((size_t)b * g.H + h) * g.W + w) * cin + ci;
 }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 *(float4*)(dx + off) = o;
                 if (ycast) {
                     const int cdx = g.merge ? (g.C >> 2) : g.C;          // channels of the dx tensor
-                    const float sc = cscale ? cscale[(int)(off / cdx) / crps] : 1.0f;
+                    const float sc = cscale ? cscale[fast_div(fast_div((int)off, cdx), crps)] : 1.0f;   // off < 2^31 (checked)
                     *(uint2*)(ycast + off) = make_uint2(pack_bf16x2(o.x * sc, o.y * sc), pack_bf16x2(o.z * sc, o.w * sc));
                 }
             }
@@ -623,6 +623,7 @@ extern "C" int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const flo
     if (rows <= 0) return TULIP_OK;
     if (!geom_ok(rows, C, merge, B, H, W)) return TULIP_ERR_ARG;
     if (param_partials && ln_bwd_part_rows(rows, C) == 0) return TULIP_ERR_ARG;
+    if (dx_bf16 && cast_rowscale && (int64_t)rows * C >= (int64_t)1 << 31) return TULIP_ERR_ARG;   // 32-bit token index
     RowGeom g{C, merge, B, H, W};
     return dispatch_ln(C, [&](auto lpr, auto nch) {
         constexpr int LPR = decltype(lpr)::value, NCH = decltype(nch)::value;
