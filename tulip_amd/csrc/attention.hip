@@ -30,7 +30,7 @@ __device__ __forceinline__ int region(int x, int X, int wsz, int ssz) {
 }
 
 __device__ __forceinline__ void slot_info(const AttnGeom& g, int b, int wy, int wx, int s, int& row, int& label) {
-    const int i = s / g.ww, j = s - i * g.ww;
+    const int i = fast_div(s, g.ww), j = s - i * g.ww;
     const int hs = wy * g.wh + i, ws = wx * g.ww + j;  // coordinates in the rolled image
     int h = hs + g.sh; if (h >= g.H) h -= g.H;         // rolled[hs] = x[(hs+sh) mod H]
     int w = ws + g.sw; if (w >= g.W) w -= g.W;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int r = 0; r < 4; ++r) bias[r] = bias_table[rel_index[li * 16 + gq * 4 + r] * g.nh + h];
 
     for (int win = wm.grp; win < total; win += ngrp) {
-        const int b = win / nW, wloc = win - b * nW;
-        const int wy = wloc / g.nWx, wx = wloc - wy * g.nWx;
+        const int b = fast_div(win, nW), wloc = win - b * nW;
+        const int wy = fast_div(wloc, g.nWx), wx = wloc - wy * g.nWx;
         int row, lab;
         slot_info(g, b, wy, wx, li, row, lab);
         const bf16_t* src = qkv + (size_t)row * C3 + h * P + gq * 8;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mx); sum += s[r]; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         const bf16x4 pb = pack4(s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv);
         bf16_t* dst = out + (size_t)row * g.C + h * P + gq * 4;
 #pragma unroll
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
     for (int win = wm.grp; win < total; win += ngrp) {
-        const int b = win / nW, wloc = win - b * nW;
-        const int wy = wloc / g.nWx, wx = wloc - wy * g.nWx;
+        const int b = fast_div(win, nW), wloc = win - b * nW;
+        const int wy = fast_div(wloc, g.nWx), wx = wloc - wy * g.nWx;
         int row, lab;
         slot_info(g, b, wy, wx, li, row, lab);
         const bf16_t* src = qkv + (size_t)row * C3 + h * P + gq * 8;

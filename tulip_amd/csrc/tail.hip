@@ -50,8 +50,8 @@ __device__ __forceinline__ void expand_channel(const bf16_t* __restrict__ We, co
 }
 
 __device__ __forceinline__ size_t pred_off(const TailGeom& g, int tok, int i) {
-    const int w = tok % g.W, t = tok / g.W;
-    const int h = t % g.H, b = t / g.H;
+    const int t = fast_div(tok, g.W), w = tok - t * g.W;
+    const int b = fast_div(t, g.H), h = t - b * g.H;
     return ((size_t)b * 4 * g.H + 4 * h + i) * (4 * g.W) + 4 * w;
 }
 
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const bf16_t* __restrict_
         // wave-private tile: LDS ops of one wave execute in order, no barrier needed
         const int chunks = ng * 2;                      // 16-B chunks per token row
         for (int id = lane; id < 32 * chunks; id += 64) {
-            const int t = id / chunks, ch = id - t * chunks;
+            const int t = fast_div(id, chunks), ch = id - t * chunks;
             const int tok = m0 + t;
             if (tok < g.M)
                 *(uint4*)(dz + (size_t)tok * N + cg * 16 + ch * 8) = *(const uint4*)(tile + t * 72 + ch * 8);
