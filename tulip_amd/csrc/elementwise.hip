@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
     int i = 0;
     while (i + 1 < R.n && (int)blockIdx.x >= R.r[i + 1].first_block) ++i;
     const MultiRegion r = R.r[i];
-    const int RL = r.rl, CT = 256 / RL, S = r.rows;
-    const int ct = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int RL = r.rl, CT = 256 / RL, S = r.rows;        // RL, CT: powers of two
+    const int ct = threadIdx.x & (CT - 1), rl = threadIdx.x >> (31 - __builtin_clz(CT));
     const int64_t col = (int64_t)(blockIdx.x - r.first_block) * CT + ct;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < r.n4) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
             const float v[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int idx = (int)col * 4 + e, h = idx / r.LL, ij = idx - h * r.LL;
+                const int idx = (int)col * 4 + e, h = fast_div(idx, r.LL), ij = idx - h * r.LL;
                 atomicAdd(r.out + r.scatter[ij] * r.nh + h, v[e]);
             }
         } else {

@@ -244,8 +244,8 @@ struct EmbedGeom {
 
 __device__ __forceinline__ float embed_tap(const float* __restrict__ img, const EmbedGeom& g, int b, int h, int w,
                                            int t) {
-    const int k = t % g.kw, tt = t / g.kw;
-    const int i = tt % g.p0, ic = tt / g.p0;
+    const int tt = fast_div(t, g.kw), k = t - tt * g.kw;
+    const int ic = fast_div(tt, g.p0), i = tt - ic * g.p0;
     int col = g.p1 * w + k;
     if (g.circular) { col -= 2; if (col < 0) col += g.Win; if (col >= g.Win) col -= g.Win; }
     return img[(((size_t)b * g.Cin + ic) * g.Hin + (g.p0 * h + i)) * g.Win + col];
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
     const float ga0 = v0 ? gamma[c0] : 0.f, ga1 = v1 ? gamma[c1] : 0.f;
     const float be0 = v0 ? beta[c0] : 0.f, be1 = v1 ? beta[c1] : 0.f;
     for (int tok = wave; tok < ntok; tok += nwaves) {
-        const int wq = tok % g.Wo, t2 = tok / g.Wo;
-        const int h = t2 % g.Ho, b = t2 / g.Ho;
+        const int t2 = fast_div(tok, g.Wo), wq = tok - t2 * g.Wo;
+        const int b = fast_div(t2, g.Ho), h = t2 - b * g.Ho;
         float a0 = b0, a1 = b1;
         if (INREG) {
             float xt[EMB_MAXT];
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_row_kernel(const float* _
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int tok = min(tok0 + u, ntok - 1);
-            const int wq = tok % g.Wo;
-            const float* rowp = img + (size_t)(tok / g.Wo) * g.Win;          // Cin == 1, p0 == 1: image row = b*Ho + h
+            const int trow = fast_div(tok, g.Wo), wq = tok - trow * g.Wo;
+            const float* rowp = img + (size_t)trow * g.Win;                  // Cin == 1, p0 == 1: image row = b*Ho + h
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 int col = g.p1 * wq + k;
@@ -413,8 +413,8 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
     const float b0 = v0 ? bias[c0] : 0.f, b1 = v1 ? bias[c1] : 0.f;
     const float ga0 = v0 ? gamma[c0] : 0.f, ga1 = v1 ? gamma[c1] : 0.f;
     for (int tok = wave; tok < ntok; tok += nwaves) {
-        const int wq = tok % g.Wo, t2 = tok / g.Wo;
-        const int h = t2 % g.Ho, b = t2 / g.Ho;
+        const int t2 = fast_div(tok, g.Wo), wq = tok - t2 * g.Wo;
+        const int b = fast_div(t2, g.Ho), h = t2 - b * g.Ho;
         const float dy0 = v0 ? dout[(size_t)tok * g.E + c0] : 0.f, dy1 = v1 ? dout[(size_t)tok * g.E + c1] : 0.f;
         float xt[EMB_MAXT];
         float a0 = b0, a1 = b1;
@@ -512,8 +512,8 @@ __global__ __launch_bounds__(256) void patch_embed_bwd16_kernel(const float* __r
         br[k] = bias[c]; gar[k] = gamma[c]; ab[k] = 0.f; ag[k] = 0.f; abe[k] = 0.f;
     }
     for (int tok = group; tok < ntok; tok += ngroups) {
-        const int wq = tok % g.Wo, t2 = tok / g.Wo;
-        const int h = t2 % g.Ho, b = t2 / g.Ho;
+        const int t2 = fast_div(tok, g.Wo), wq = tok - t2 * g.Wo;
+        const int b = fast_div(t2, g.Ho), h = t2 - b * g.Ho;
         float xt[TAPS];
         #pragma unroll
         for (int t = 0; t < TAPS; ++t) xt[t] = (t < g.taps) ? embed_tap(img, g, b, h, wq, t) : 0.f;
