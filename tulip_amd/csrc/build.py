@@ -30,6 +30,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(HERE, s.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
                "-I", os.path.join(ROOT, "include"), "-I", HERE, "-c", os.path.join(HERE, s), "-o", o]
+        cmd += os.environ.get("TULIP_HIPCC_FLAGS", "").split()      # dev: e.g. -DTULIP_GEMM_WSK=0 for an A/B build
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
