@@ -38,17 +38,31 @@ __device__ __forceinline__ int fast_div(int a, int d) {
 }
 
 // sum / max over a power-of-two group of WIDTH lanes (WIDTH <= 64)
-template <int WIDTH>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// The exchange with lane ^ 1, ^ 2, and the two mirror steps that complete a 16-lane butterfly are DPP modifiers of a
+// VALU move (no LDS round trip; __shfl_xor is a ds_bpermute_b32, ~100 cycles of latency per step in a dependent
+// chain).  Only the steps across 16-lane rows (^ 16, ^ 32) still go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int WIDTH, class OP>
+__device__ __forceinline__ float group_reduce(float v, OP op) {
+    static_assert(WIDTH == 2 || WIDTH == 4 || WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "WIDTH");
+    v = op(v, dpp_move<0xB1>(v));                          // quad_perm [1,0,3,2]: lane ^ 1
+    if (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));          // quad_perm [2,3,0,1]: lane ^ 2
+    if (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));         // row_half_mirror: the other quad of the 8-lane half
+    if (WIDTH >= 16) v = op(v, dpp_move<0x140>(v));        // row_mirror: the other half of the 16-lane row
+    if (WIDTH >= 32) v = op(v, __shfl_xor(v, 16, 64));
+    if (WIDTH >= 64) v = op(v, __shfl_xor(v, 32, 64));
     return v;
 }
 template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+    return group_reduce<WIDTH>(v, [](float a, float b) { return a + b; });
+}
+template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return group_reduce<WIDTH>(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // erf-GELU (nn.GELU default, tulip.py:183,196) and its derivative.  erf by Abramowitz-Stegun 7.1.26
