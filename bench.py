@@ -56,9 +56,9 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
     eff = ops.gemm_effective_splits(K, splits)
     kchunk = -(-(-(-K // eff)) // 32) * 32
     gn = -(-N // 96)
-    if -(-M // 128) * gn * eff < int(os.environ.get("TULIP_GEMM_BIG_TILES", 2048)) or M <= 64:
+    if -(-M // 128) * gn * eff < 2048 or M <= 64:
         grid = gn * -(-M // 64) * eff
-        ksub = 4 if (grid <= int(os.environ.get("TULIP_GEMM_KSUB_GRID", 400)) and kchunk >= 256) else 1
+        ksub = 4 if (grid <= 400 and kchunk >= 256) else 1
         bm = 64
     else:
         bm, ksub = 128, 1
@@ -120,7 +120,7 @@ def gemm_roofline(trainer, reps=5):
             deep = deep and kchunk >= 256
             f += 2.0 * it.Nw * it.Kw * it.Mtok
             alg_bytes += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw * eff
-        ksub = 4 if (tiles <= int(os.environ.get("TULIP_GEMM_KSUB_GRID", 400)) and deep) else 1
+        ksub = 4 if (tiles <= 400 and deep) else 1
         d = by_inst.setdefault(f"gemm_group_kernel<64, true, true, {ksub}>", [0, 0.0, 0.0])
         d[0] += 1; d[1] += t; d[2] += f
         tot_t += t; tot_f += f

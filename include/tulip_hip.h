@@ -191,6 +191,26 @@ int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const float* be, cons
                    uint16_t* dz, float* dwd_partials, int B, int H, int W, int E, const float* target,
                    const float* gscale_dev, float gscale, hipStream_t stream);
 
+/* The non-default decoder alternates PatchExpanding (tulip.py:126-140, patch_unmerging=False; P = 2, Cn = C/2) and
+ * FinalPatchExpanding (tulip.py:144-159, pixel_shuffle=False; P = upscale_factor, Cn = embed_dim):
+ * Linear(no bias) -> 'B H W (P1 P2 C) -> B (H P1) (W P2) C' -> LayerNorm(Cn).  The Linear is tulip_gemm_bf16 with
+ * TULIP_EPI_F32 into y [B*H*W][P*P*Cn] fp32; a fine token is a contiguous Cn-slice of a row of y, so the rearrange is
+ * the OUTPUT addressing of these kernels.  fwd: LayerNorm of every slice -> out_bf16 (optional; fine-token order,
+ * row pitch ld, e.g. the first half of a skip-concat buffer, tulip.py:715) and/or pred[fine token] =
+ * sum_c dotw[c] * bf16(LayerNorm out)[c] (optional: decoder_pred, tulip.py:731, in_chans == 1, the (B,PH,PW,Cn)
+ * tensor is never stored).  mean / rstd: [B*H*W*P*P] in the (coarse token, p) order of y.
+ * bwd: upstream gradient either as bf16 rows dy_fine (fine-token order, row pitch ld) or, when dotw != NULL, as
+ * dpred[fine token] (then d(LayerNorm out)[c] = dpred * dotw[c]) -> dy_nat = bf16 d(y) in y's layout (operand of the
+ * Linear's dgrad / wgrad GEMMs) and tulip_expand_norm_bwd_partial_rows(...) partial rows of
+ * [dgamma[Cn] | dbeta[Cn] | d(dotw)[Cn]] (stride 3*Cn; fold with tulip_reduce_rows_multi).  Cn % 4 == 0, Cn <= 768. */
+int tulip_expand_norm_fwd(const float* y, const float* gamma, const float* beta, uint16_t* out_bf16, int ld,
+                          const float* dotw, float* pred, float* mean, float* rstd, int B, int H, int W, int P, int Cn,
+                          float eps, hipStream_t stream);
+int tulip_expand_norm_bwd(const uint16_t* dy_fine, int ld, const float* dpred, const float* dotw, const float* y,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta, uint16_t* dy_nat,
+                          float* partials, int B, int H, int W, int P, int Cn, hipStream_t stream);
+int tulip_expand_norm_bwd_partial_rows(int B, int H, int W, int P);
+
 /* forward_loss (tulip.py:690-700): losses[0]=mean|pred-target|, losses[1]=mean|expm1(pred)-expm1(target)|
  * (or a copy of losses[0] when log_transform==0).  partials: scratch of 2*1024 floats. Deterministic. */
 int tulip_l1_loss_fwd(const float* pred, const float* target, float* partials, float* losses, int64_t n,

@@ -199,7 +199,9 @@ def state_dict_spec(cfg: TulipConfig) -> "Dict[str, Tuple[Tuple[int, ...], str]]
     init), 'bias_table' (trunc-normal .02), 'index' (int64 buffer).  Matches the 226-entry
     state_dict of tulip_base; registration order follows
     TULIP.__init__ (tulip.py:555-582): layers, layers_up, first_patch_expanding,
-    skip_connection_layers, norm_up, patch_embed, decoder_pred, ps_head.
+    skip_connection_layers, norm_up, patch_embed, decoder_pred, ps_head (or
+    final_patch_expanding when pixel_shuffle=False; PatchExpanding instead of PatchUnmerging
+    when patch_unmerging=False).
     """
     E, wh, ww = cfg.embed_dim, cfg.window_size[0], cfg.window_size[1]
     L = wh * ww
@@ -223,6 +225,15 @@ def state_dict_spec(cfg: TulipConfig) -> "Dict[str, Tuple[Tuple[int, ...], str]]
         spec[f"{prefix}.mlp.fc2.weight"] = ((C, Hd), "linear_w")
         spec[f"{prefix}.mlp.fc2.bias"] = ((C,), "zeros")
 
+    def upsample(prefix: str, C: int):
+        if cfg.patch_unmerging:       # PatchUnmerging, tulip.py:109-115
+            spec[f"{prefix}.expand.weight"] = ((2 * C, C, 1, 1), "conv_w")
+            spec[f"{prefix}.expand.bias"] = ((2 * C,), "conv_b")
+        else:                         # PatchExpanding, tulip.py:126-132
+            spec[f"{prefix}.expand.weight"] = ((2 * C, C), "linear_w")
+            spec[f"{prefix}.norm.weight"] = ((C // 2,), "ones")
+            spec[f"{prefix}.norm.bias"] = ((C // 2,), "zeros")
+
     for s in range(nl):
         C = E * 2 ** s
         for b in range(cfg.depths[s]):
@@ -237,11 +248,8 @@ def state_dict_spec(cfg: TulipConfig) -> "Dict[str, Tuple[Tuple[int, ...], str]]
         for b in range(cfg.depths[s]):
             block(f"layers_up.{i}.blocks.{b}", C, cfg.num_heads[s])
         if i < nl - 2:
-            spec[f"layers_up.{i}.upsample.expand.weight"] = ((2 * C, C, 1, 1), "conv_w")
-            spec[f"layers_up.{i}.upsample.expand.bias"] = ((2 * C,), "conv_b")
-    Ct = E * 2 ** (nl - 1)
-    spec["first_patch_expanding.expand.weight"] = ((2 * Ct, Ct, 1, 1), "conv_w")
-    spec["first_patch_expanding.expand.bias"] = ((2 * Ct,), "conv_b")
+            upsample(f"layers_up.{i}.upsample", C)
+    upsample("first_patch_expanding", E * 2 ** (nl - 1))
     for i in range(nl - 1):
         C = E * 2 ** (nl - 2 - i)
         spec[f"skip_connection_layers.{i}.weight"] = ((C, 2 * C), "linear_w")
@@ -255,8 +263,13 @@ def state_dict_spec(cfg: TulipConfig) -> "Dict[str, Tuple[Tuple[int, ...], str]]
     spec["patch_embed.norm.bias"] = ((E,), "zeros")
     spec["decoder_pred.weight"] = ((cfg.in_chans, E, 1, 1), "conv_w")
     r2 = cfg.upscale_factor ** 2
-    spec["ps_head.conv_expand.0.weight"] = ((E * r2, E, 1, 1), "conv_w")
-    spec["ps_head.conv_expand.0.bias"] = ((E * r2,), "conv_b")
+    if cfg.pixel_shuffle:             # PixelShuffleHead, tulip.py:161-171
+        spec["ps_head.conv_expand.0.weight"] = ((E * r2, E, 1, 1), "conv_w")
+        spec["ps_head.conv_expand.0.bias"] = ((E * r2,), "conv_b")
+    else:                             # FinalPatchExpanding, tulip.py:144-150
+        spec["final_patch_expanding.expand.weight"] = ((E * r2, E), "linear_w")
+        spec["final_patch_expanding.norm.weight"] = ((E,), "ones")
+        spec["final_patch_expanding.norm.bias"] = ((E,), "zeros")
     return spec
 
 
@@ -440,6 +453,28 @@ def patch_unmerging(pr: _Prec, sd, prefix: str, x: Tensor) -> Tensor:
     return z.reshape(B, 2 * H, 2 * W, C // 2)
 
 
+def expand_rearrange(z: Tensor, P: int) -> Tensor:
+    """'B H W (P1 P2 C) -> B (H P1) (W P2) C' with P1 = P2 = P (tulip.py:136, :154-156)."""
+    B, H, W, PC = z.shape
+    C = PC // (P * P)
+    return z.reshape(B, H, W, P, P, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H * P, W * P, C)
+
+
+def patch_expanding(pr: _Prec, sd, prefix: str, cfg: TulipConfig, x: Tensor) -> Tensor:
+    """tulip.py:126-140 (patch_unmerging=False): Linear C->2C (no bias), 2x2 rearrange, LayerNorm(C/2)."""
+    z = expand_rearrange(linear(pr, x, sd[f"{prefix}.expand.weight"], None), 2)
+    return layer_norm(z, sd[f"{prefix}.norm.weight"], sd[f"{prefix}.norm.bias"], cfg.ln_eps)
+
+
+def final_expanding_and_pred(pr: _Prec, sd, cfg: TulipConfig, x: Tensor) -> Tensor:
+    """tulip.py:727-731 with pixel_shuffle=False: FinalPatchExpanding (Linear E->r^2 E no bias, r x r rearrange,
+    LayerNorm(E); tulip.py:144-159), 'B H W C -> B C H W', conv1x1 E->in_chans (no bias)."""
+    z = expand_rearrange(linear(pr, x, sd["final_patch_expanding.expand.weight"], None), cfg.upscale_factor)
+    z = pr.r(layer_norm(z, sd["final_patch_expanding.norm.weight"], sd["final_patch_expanding.norm.bias"], cfg.ln_eps))
+    wd = sd["decoder_pred.weight"].reshape(cfg.in_chans, cfg.embed_dim)
+    return torch.einsum("bhwc,oc->bohw", z, wd)
+
+
 def ps_head_and_pred(pr: _Prec, sd, cfg: TulipConfig, x: Tensor) -> Tensor:
     """tulip.py:720-731: conv1x1 E->E*r^2 (+bias), LeakyReLU(0.01), PixelShuffle(r),
     conv1x1 E->in_chans (no bias).  x:(B,H,W,E) is norm_up's output.  -> (B,in_chans,rH,rW)."""
@@ -474,15 +509,16 @@ def drop_path_keep(rate: float, u: Tensor) -> Optional[Tensor]:
 def tulip_forward(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Optional[Tensor],
                   lowp: bool = False, drop_u: Optional[Dict[str, Tensor]] = None,
                   taps: Optional[Dict[str, Tensor]] = None):
-    """TULIP.forward (tulip.py:702-737) for the default flag set
-    (pixel_shuffle, circular_padding or not, patch_unmerging).
+    """TULIP.forward (tulip.py:702-737), every flag combination of pixel_shuffle / patch_unmerging /
+    circular_padding.
 
     ``drop_u``: {block prefix: (2,B) uniform draws} enables train-mode DropPath with explicit
     randomness (None = eval / identity).  ``taps`` collects per-stage activations.
     Returns (pred, loss, pixel_loss), or pred alone when target is None (mc_drop path).
     """
-    assert cfg.pixel_shuffle and cfg.patch_unmerging, "oracle covers the default TULIP flag set"
     pr = _Prec(lowp)
+    up = (lambda prefix, t: patch_unmerging(pr, sd, prefix, t)) if cfg.patch_unmerging else \
+        (lambda prefix, t: patch_expanding(pr, sd, prefix, cfg, t))
     enc_rates, dec_rates = drop_path_rates(cfg)
     nl = cfg.num_layers
 
@@ -505,7 +541,7 @@ def tulip_forward(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Op
             x = patch_merging(pr, sd, f"layers.{s}.downsample", cfg, x)
         if taps is not None:
             taps[f"layers.{s}"] = x
-    x = patch_unmerging(pr, sd, "first_patch_expanding", x)
+    x = up("first_patch_expanding", x)
     for i in range(nl - 1):
         s = nl - i - 2
         cat = torch.cat([x, saved[len(saved) - i - 2]], -1)
@@ -514,11 +550,11 @@ def tulip_forward(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Op
             p = f"layers_up.{i}.blocks.{b}"
             x = swin_block(pr, sd, p, cfg, x, cfg.num_heads[s], b % 2 == 1, keep_for(p, dec_rates[i][b]))
         if i < nl - 2:
-            x = patch_unmerging(pr, sd, f"layers_up.{i}.upsample", x)
+            x = up(f"layers_up.{i}.upsample", x)
         if taps is not None:
             taps[f"layers_up.{i}"] = x
     x = pr.r(layer_norm(x, sd["norm_up.weight"], sd["norm_up.bias"], cfg.ln_eps))
-    pred = ps_head_and_pred(pr, sd, cfg, x)
+    pred = ps_head_and_pred(pr, sd, cfg, x) if cfg.pixel_shuffle else final_expanding_and_pred(pr, sd, cfg, x)
     if target is None:
         return pred
     loss, pixel = forward_loss(cfg, pred, target)

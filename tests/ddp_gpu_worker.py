@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     out_path, use_graph, steps = sys.argv[1], sys.argv[2] == "1", int(sys.argv[3])
     accum = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    diffseed = len(sys.argv) > 5 and sys.argv[5] == "diffseed"
     from oracle import tulip_oracle as O
     from tests.test_model_gpu import build
     from tulip_amd.trainer import Trainer
@@ -22,12 +23,18 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = O.tiny_config(drop_path_rate=0.0)
-    sd = O.key_seeded_state_dict(cfg, seed=3)
+    # diffseed: every rank starts from its own weights, as the reference's per-rank seeds do (main_lidar_upsampling.py:155);
+    # the Trainer must broadcast rank 0's, like DistributedDataParallel's constructor (main:277)
+    sd = O.key_seeded_state_dict(cfg, seed=3 + (rank if diffseed else 0))
     lo, hi = O.synthetic_batch(cfg, 2 * world, seed=77)
     m = build(cfg, sd, train=True)
     tr = Trainer(m, 2, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, use_graph=use_graph, bucket_mb=0.05,
                  accum_iter=accum)
     assert tr.world == world and len(tr.bucketer.buckets) >= 2
+    start = tr.eng.params.flat.clone()
+    first = [torch.empty_like(start) for _ in range(world)]
+    dist.all_gather(first, start)
+    same_start = all(torch.equal(first[0], f) for f in first)
     tr.load_batch(lo[2 * rank:2 * rank + 2].cuda(), hi[2 * rank:2 * rank + 2].cuda())
     losses = [tr.step().clone() for _ in range(steps * accum)]
     torch.cuda.synchronize()
@@ -36,7 +43,7 @@ def main():
     dist.all_gather(gathered, flat)
     if rank == 0:
         torch.save({"flat": flat.cpu(), "same_on_all_ranks": all(torch.equal(gathered[0], g) for g in gathered),
-                    "losses": torch.stack(losses).cpu(), "segments": len(tr._segments[True]) if use_graph else 0, "bucket_adamw": tr.bucket_adamw,
+                    "losses": torch.stack(losses).cpu(), "same_start": same_start, "segments": len(tr._segments[True]) if use_graph else 0, "bucket_adamw": tr.bucket_adamw,
                     "buckets": tr.bucketer.buckets}, out_path)
     dist.barrier()
     dist.destroy_process_group()

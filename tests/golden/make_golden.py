@@ -204,7 +204,10 @@ def golden_model(T, name, cfg: O.TulipConfig, batch, seed, with_grads, drop_path
         for k in ("patch_embed.proj.weight", "layers.0.blocks.1.attn.relative_position_bias_table",
                   "layers.0.blocks.0.attn.qkv.bias", "decoder_pred.weight", "norm_up.weight",
                   "layers.0.downsample.reduction.weight", "skip_connection_layers.0.weight",
-                  "first_patch_expanding.expand.bias"):
+                  "first_patch_expanding.expand.bias", "first_patch_expanding.expand.weight",
+                  "first_patch_expanding.norm.weight", "layers_up.0.upsample.norm.bias",
+                  "final_patch_expanding.expand.weight", "final_patch_expanding.norm.weight",
+                  "final_patch_expanding.norm.bias"):
             if k in ref_grads:
                 out["grad::" + k] = ref_grads[k].numpy().copy()
 
@@ -266,9 +269,25 @@ def golden_lr(T):
     print("LR schedule fixture:", len(rows), "rows")
 
 
+def golden_alternates(T):
+    """G12: the non-default decoder alternates (tulip.py:126-159): PatchExpanding (patch_unmerging=False) and
+    FinalPatchExpanding (pixel_shuffle=False), alone and together; a 3-level model so that a decoder stage's own
+    upsample (layers_up.0.upsample) is a PatchExpanding too."""
+    tiny3 = dict(depths=(2, 2, 2), num_heads=(3, 6, 12))
+    golden_model(T, "g12_tiny3_expanding", O.tiny_config(pixel_shuffle=False, patch_unmerging=False, **tiny3), batch=2,
+                 seed=5, with_grads=True, bf16_ref=False)
+    golden_model(T, "g12_tiny_patch_expanding", O.tiny_config(patch_unmerging=False), batch=2, seed=6, with_grads=True,
+                 bf16_ref=False)
+    golden_model(T, "g12_tiny_final_expanding", O.tiny_config(pixel_shuffle=False), batch=2, seed=7, with_grads=True,
+                 bf16_ref=False)
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     T = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "alternates":
+        golden_alternates(T)
+        return
     golden_index(T)
     golden_lr(T)
     golden_init(T)
@@ -285,6 +304,7 @@ def main():
     golden_model(T, "g4_kitti_base", O.tulip_base_config(), batch=2, seed=0, with_grads=False)
     large = O.tulip_large_config(img_size=(16, 2048), target_img_size=(64, 2048))
     golden_model(T, "g5_large_16x2048", large, batch=1, seed=0, with_grads=False, bf16_ref=False)
+    golden_alternates(T)
     print("done")
 
 

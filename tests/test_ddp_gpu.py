@@ -24,23 +24,27 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("use_graph,accum", [(True, 1), (False, 1), (True, 2)])
-def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph, accum):
+@pytest.mark.parametrize("use_graph,accum,bucket_adamw,diffseed", [(True, 1, False, True), (False, 1, False, False),
+                                                                  (True, 2, False, False), (True, 1, True, False)])
+def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph, accum, bucket_adamw, diffseed):
     from tests.test_model_gpu import build
     from tulip_amd.trainer import Trainer
     steps = 3
     out = tmp_path / "r0.pt"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), str(out),
-           "1" if use_graph else "0", str(steps), str(accum)]
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+           "1" if use_graph else "0", str(steps), str(accum), "diffseed" if diffseed else "same"]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", TULIP_BUCKET_ADAMW="1" if bucket_adamw else "0")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = torch.load(out)
+    assert got["same_start"]                                     # rank 0's parameters were broadcast at construction
     assert got["same_on_all_ranks"]                              # replicas stay bit-identical
+    assert got["bucket_adamw"] == bucket_adamw
     if use_graph:
-        # one graph segment per bucket; the optimizer runs per bucket behind its all-reduce (no AdamW segment)
-        assert got["bucket_adamw"] and got["segments"] == len(got["buckets"])
+        # one graph segment per bucket, then one AdamW segment behind the last all-reduce (the default), or the
+        # optimizer per bucket behind its own all-reduce (TULIP_BUCKET_ADAMW=1: no AdamW segment)
+        assert got["segments"] == len(got["buckets"]) + (0 if bucket_adamw else 1)
     cfg = O.tiny_config(drop_path_rate=0.0)
     sd = O.key_seeded_state_dict(cfg, seed=3)
     lo, hi = O.synthetic_batch(cfg, 4, seed=77)

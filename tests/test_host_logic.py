@@ -50,13 +50,41 @@ def test_constructor_quirks():
     with pytest.raises(AttributeError):          # the reference's swin_v2 branch crashes the same way
         T.TULIP(swin_v2=True, **{k: v for k, v in KW.items()})
     with pytest.raises(NotImplementedError):
-        T.TULIP(pixel_shuffle=False, patch_unmerging=True)
+        T.TULIP(patch_norm=False, **KW)
     m = T.tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), **KW)
     assert m.upscale_factor == 4 and m.drop_path == 0.1
     rates = [b.drop_path_rate for s in m.layers for b in s.blocks]
     enc, _ = O.drop_path_rates(O.tulip_base_config())
     assert rates == [r for s in enc for r in s]
     assert [b.drop_path_rate for b in m.layers_up[0].blocks] == enc[2]   # decoder reuses encoder slices
+
+
+def test_reference_default_flags_construct_with_the_reference_state_dict():
+    """TULIP() with the reference's own constructor defaults (tulip.py:531-535: pixel_shuffle=False,
+    patch_unmerging=False -> PatchExpanding / FinalPatchExpanding, tulip.py:126-159) and the two mixed flag sets: keys,
+    order and shapes of the state_dict are the reference's (the spec is pinned to the reference by the g12 fixtures)."""
+    ref_defaults = O.TulipConfig(img_size=(32, 2048), target_img_size=(128, 2048), patch_size=(4, 4), window_size=(4, 4),
+                                 depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), ln_eps=1e-5, pixel_shuffle=False,
+                                 circular_padding=False, log_transform=False, patch_unmerging=False)
+    m = T.TULIP()
+    spec = O.state_dict_spec(ref_defaults)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    assert all(tuple(sd[k].shape) == spec[k][0] for k in sd)
+    assert "final_patch_expanding.norm.weight" in sd and "first_patch_expanding.norm.bias" in sd
+    assert "layers_up.0.upsample.expand.weight" in sd and sd["layers_up.0.upsample.expand.weight"].ndim == 2
+    for ps, pu in [(True, False), (False, True), (False, False)]:
+        cfg = O.tiny_config(pixel_shuffle=ps, patch_unmerging=pu, depths=(2, 2, 2), num_heads=(3, 6, 12))
+        kw = dict(KW, pixel_shuffle=ps, patch_unmerging=pu)
+        m = T.TULIP(img_size=cfg.img_size, target_img_size=cfg.target_img_size, depths=cfg.depths, embed_dim=cfg.embed_dim,
+                    num_heads=cfg.num_heads, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw)
+        spec = O.state_dict_spec(cfg)
+        assert list(m.state_dict().keys()) == list(spec.keys())
+        assert all(tuple(v.shape) == spec[k][0] for k, v in m.state_dict().items())
+        # the flat layout orders every parameter of the alternates too
+        from tulip_amd.engine import FlatParams
+        order, marks = FlatParams._completion_order(m, dict(m.named_parameters()))
+        assert sorted(order) == sorted(dict(m.named_parameters()))
 
 
 def test_cpu_forward_is_refused():

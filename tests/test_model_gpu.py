@@ -43,8 +43,9 @@ def build(cfg: O.TulipConfig, sd, train=False):
     m = T.TULIP(img_size=cfg.img_size, target_img_size=cfg.target_img_size, patch_size=cfg.patch_size,
                 in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, window_size=list(cfg.window_size), depths=cfg.depths,
                 num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, drop_path_rate=cfg.drop_path_rate,
-                norm_layer=partial(nn.LayerNorm, eps=cfg.ln_eps), pixel_shuffle=True,
-                circular_padding=cfg.circular_padding, log_transform=cfg.log_transform, patch_unmerging=True)
+                norm_layer=partial(nn.LayerNorm, eps=cfg.ln_eps), pixel_shuffle=cfg.pixel_shuffle,
+                circular_padding=cfg.circular_padding, log_transform=cfg.log_transform,
+                patch_unmerging=cfg.patch_unmerging)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV)
     m.train(train)
@@ -87,8 +88,11 @@ def test_tiny_eval_forward_vs_golden_and_oracle(golden_dir):
     assert torch.equal(p3.cpu(), pred)
 
 
-@pytest.mark.parametrize("name", ["g3_tiny_fp32", "g3_tiny_droppath"])
+@pytest.mark.parametrize("name", ["g3_tiny_fp32", "g3_tiny_droppath", "g12_tiny3_expanding", "g12_tiny_patch_expanding",
+                                  "g12_tiny_final_expanding"])
 def test_tiny_gradients_vs_reference(golden_dir, name):
+    """g12_*: the reference's non-default decoder alternates, PatchExpanding / FinalPatchExpanding (tulip.py:126-159):
+    forward against the reference's fp32 prediction (fixture) and the same-rounding oracle, then every gradient."""
     z, meta, cfg = _load(golden_dir, name)
     sd = O.key_seeded_state_dict(cfg, seed=meta["seed"])
     lo, hi = O.synthetic_batch(cfg, meta["batch"], seed=1234 + meta["seed"])
@@ -108,6 +112,14 @@ def test_tiny_gradients_vs_reference(golden_dir, name):
     eng.run_forward(P)
     torch.cuda.synchronize()
     assert abs(P.losses[0].item() - float(z["loss"])) <= 1e-3 * float(z["loss"])
+    if name.startswith("g12"):
+        with torch.no_grad():
+            lp, ll, _ = O.tulip_forward(sd, cfg, lo, hi, lowp=True)
+        d = (P.pred.cpu() - lp).abs()
+        assert d.max().item() <= 4e-3 and d.mean().item() <= 4e-4, (d.max().item(), d.mean().item())
+        assert abs(P.losses[0].item() - ll.item()) <= 2e-4 * ll.item()
+        d = (P.pred.cpu() - torch.from_numpy(z["pred"])).abs()      # vs the reference's fp32 forward
+        assert d.max().item() <= 1.2e-2 and d.mean().item() <= 2e-3, (d.max().item(), d.mean().item())
     gflat = torch.zeros(eng.params.total, device=DEV)
     eng.run_backward(P, gflat)
     torch.cuda.synchronize()

@@ -93,8 +93,10 @@ def test_drop_path_rates():
     assert dec[0] == enc[2] and dec[1] == enc[1] and dec[2] == enc[0]
 
 
-@pytest.mark.parametrize("name", ["g3_tiny_fp32", "g3_tiny_droppath"])
+@pytest.mark.parametrize("name", ["g3_tiny_fp32", "g3_tiny_droppath", "g12_tiny3_expanding", "g12_tiny_patch_expanding",
+                                  "g12_tiny_final_expanding"])
 def test_tiny_model_forward_backward_vs_reference(golden_dir, name):
+    """g12_*: the PatchExpanding / FinalPatchExpanding alternates (patch_unmerging=False / pixel_shuffle=False)."""
     z, meta, cfg = _load(golden_dir, name)
     sd = O.key_seeded_state_dict(cfg, seed=meta["seed"])
     lo, hi = O.synthetic_batch(cfg, meta["batch"], seed=1234 + meta["seed"])

@@ -77,6 +77,9 @@ SIGNATURES = {
     "tulip_cast_flat": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],
     "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
+    "tulip_expand_norm_fwd": [P, P, P, P, I, P, P, P, P, I, I, I, I, I, F, P],
+    "tulip_expand_norm_bwd": [P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "tulip_expand_norm_bwd_partial_rows": [I, I, I, I],
     "tulip_l1_loss_fwd": [P, P, P, P, L, I, P],
     "tulip_l1_loss_bwd": [P, P, P, F, P, L, P],
     "tulip_adamw": [P, P, P, P, P, L, P, P, I, P],

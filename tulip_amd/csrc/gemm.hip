@@ -21,7 +21,6 @@
 // per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging), fp32 accumulate, and
 // split-K atomic accumulation (wgrad).
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "tulip_hip.h"
@@ -53,6 +52,9 @@ struct GemmArgs {
     int psH, psW;
 };
 
+// launch heuristics (compile-time; mirrored by bench.py's kernel-name bookkeeping)
+#define TULIP_GEMM_BIG_TILES 2048   // 128-row tiles only for launches with at least this many of them
+#define TULIP_GEMM_KSUB_GRID 400    // 128-deep k stages for grids up to this many workgroups
 #ifndef TULIP_WGRAD_RING
 #define TULIP_WGRAD_RING 3
 #endif
@@ -486,14 +488,12 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
     const int gn = (p.N + BN - 1) / BN;
     // 64-row tiles unless the launch already has thousands of 128-row tiles: at B=8 every GEMM of this model
     // is latency-bound per workgroup, and twice as many half-size workgroups in flight measured 4 % faster
-    // end to end (TULIP_GEMM_BIG_TILES: threshold in 128-row tiles, dev A/B switch)
-    static const int big_tiles = getenv("TULIP_GEMM_BIG_TILES") ? atoi(getenv("TULIP_GEMM_BIG_TILES")) : 2048;
-    const bool small = ((p.M + 127) / 128) * gn * splits < big_tiles;
+    // end to end
+    const bool small = ((p.M + 127) / 128) * gn * splits < TULIP_GEMM_BIG_TILES;
     if (small || p.M <= 64) {
         dim3 grid(gn, (p.M + 63) / 64, splits);
         // 128-deep k stages (80-150 KB LDS, 1-2 workgroups/CU) pay while the grid is at most ~1.5 waves of the chip
-        static const int ksub_grid = getenv("TULIP_GEMM_KSUB_GRID") ? atoi(getenv("TULIP_GEMM_KSUB_GRID")) : 400;
-        if ((int)(grid.x * grid.y * grid.z) <= ksub_grid && p.kchunk >= 256)
+        if ((int)(grid.x * grid.y * grid.z) <= TULIP_GEMM_KSUB_GRID && p.kchunk >= 256)
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 4>), grid, dim3(256), 0, stream, p);
         else
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
@@ -607,9 +607,8 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
         ++G.n;
     }
     if (G.n > 0) {
-        static const int ksub_grid = getenv("TULIP_GEMM_KSUB_GRID") ? atoi(getenv("TULIP_GEMM_KSUB_GRID")) : 400;
         const int blocks = G.first[G.n];
-        if (blocks <= ksub_grid && deep)
+        if (blocks <= TULIP_GEMM_KSUB_GRID && deep)
             hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 4>), dim3(blocks), dim3(256), 0, stream, G);
         else
             hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 1>), dim3(blocks), dim3(256), 0, stream, G);

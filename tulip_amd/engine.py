@@ -115,7 +115,7 @@ class FlatParams:
                             "attn.qkv", "norm1"):
                     add(f"{prefix}.blocks.{b}.{sub}")
 
-        add("decoder_pred."); add("ps_head."); add("norm_up.")
+        add("decoder_pred."); add("ps_head."); add("final_patch_expanding."); add("norm_up.")
         marks.append(("head", len(order)))
         for i in reversed(range(nl - 1)):
             add(f"layers_up.{i}.upsample.")
@@ -196,6 +196,10 @@ class Plan:
                 self.b16(f"dec{s}.cat", Ms, 2 * Cs)
                 self.b16(f"dec{s}.dyskip", Ms, Cs)
             self.b16(f"lvl{s}.xb", Ms, Cs)         # bf16 copy of the stage output feeding a PatchUnmerging expand
+            if s > 0 and not m.patch_unmerging:    # PatchExpanding (tulip.py:126-140): Linear output, statistics of the
+                self.f32(f"lvl{s}.ey", Ms, 2 * Cs)                              # 4 fine tokens per row, and the
+                self.f32(f"lvl{s}.emean", 4 * Ms); self.f32(f"lvl{s}.erstd", 4 * Ms)   # upstream gradient in fine order
+                self.b16(f"lvl{s}.dfine", 4 * Ms, Cs // 2)
         for spec in eng.blocks:
             M, C = B * spec.H * spec.W, spec.C
             Hd = eng.hidden(C)
@@ -223,6 +227,9 @@ class Plan:
         self.b16("t.dxm", big)                     # dgrad of a merge reduction [M/4][4C]
         self.b16("tail.xn", maxM, E); self.f32("tail.mean", maxM); self.f32("tail.rstd", maxM)
         self.b16("tail.dz", maxM, 16 * E)
+        if not m.pixel_shuffle:                    # FinalPatchExpanding (tulip.py:144-159)
+            r2 = m.upscale_factor ** 2
+            self.f32("tail.ey", maxM, r2 * E); self.f32("tail.emean", r2 * maxM); self.f32("tail.erstd", r2 * maxM)
         self.b16("tail.dxn", maxM, E)
         # partial-row workspaces of the atomic-free reductions
         self.f32("tail.dwd_part", (maxM + 31) // 32, 128)
@@ -441,6 +448,15 @@ class TulipEngine:
         B = P.B
         H, W, C = self.grid[0] >> s, self.grid[1] >> s, m.embed_dim << s
         M = B * H * W
+        if not m.patch_unmerging:
+            # PatchExpanding (tulip.py:126-140): Linear C->2C (no bias), 'B H W (P1 P2 C) -> B (H P1) (W P2) C' and
+            # LayerNorm(C/2); the rearrange is the output addressing of the LayerNorm kernel
+            self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_F32,
+                       out=P[f"lvl{s}.ey"])
+            ops.expand_norm_fwd(P[f"lvl{s}.ey"], W_.p32(prefix + ".norm.weight"), W_.p32(prefix + ".norm.bias"),
+                                P[f"lvl{s}.emean"], P[f"lvl{s}.erstd"], B, H, W, 2, C // 2, self.eps,
+                                out_bf16=P[f"dec{s - 1}.cat"], ld=C)
+            return
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
@@ -491,8 +507,19 @@ class TulipEngine:
         M0 = B * H0 * W0
         ops.layernorm_fwd(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), P["tail.xn"], P["tail.mean"],
                           P["tail.rstd"], M0, E, self.eps)
-        ops.tail_fwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
-                     W_.p32("decoder_pred.weight"), P.pred, B, H0, W0, E)
+        if m.pixel_shuffle:
+            ops.tail_fwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
+                         W_.p32("decoder_pred.weight"), P.pred, B, H0, W0, E)
+        else:
+            # FinalPatchExpanding (tulip.py:144-159) + decoder_pred (tulip.py:731): Linear E -> r^2 E, then one kernel
+            # for rearrange + LayerNorm(E) + the 1x1 conv as a per-row dot product
+            r = m.upscale_factor
+            pre = "final_patch_expanding"
+            self._gemm(P["tail.xn"], W_.p16(pre + ".expand.weight"), M0, r * r * E, E, lda=E, ldb=E, epi=EPI_F32,
+                       out=P["tail.ey"])
+            ops.expand_norm_fwd(P["tail.ey"], W_.p32(pre + ".norm.weight"), W_.p32(pre + ".norm.bias"), P["tail.emean"],
+                                P["tail.erstd"], B, H0, W0, r, E, self.eps, dotw=W_.p32("decoder_pred.weight"),
+                                pred=P.pred)
         if with_loss:
             ops.l1_loss_fwd(P.pred, P.target, P.partials, P.losses, P.pred.numel(), m.log_transform)
         P.generation += 1
@@ -806,7 +833,18 @@ class TulipEngine:
         M = B * H * W
         dz = P[f"lvl{s}.dz2"]
         cb, cs, ct = cast if cast is not None else (None, None, 1)
-        self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), G(prefix + ".expand.bias"))
+        gbias = G(prefix + ".expand.bias") if m.patch_unmerging else None
+        if not m.patch_unmerging:
+            # PatchExpanding: the fine-level gradient arrived in fine-token order (lvl{s}.dfine); LayerNorm backward
+            # writes it into dz in the Linear's own output layout
+            R = ops.expand_norm_bwd_partial_rows(B, H, W, 2)
+            Cn = C // 2
+            part = P.scratch("exp." + prefix, R * 3 * Cn)
+            ops.expand_norm_bwd(P[f"lvl{s}.ey"], P[f"lvl{s}.emean"], P[f"lvl{s}.erstd"], W_.p32(prefix + ".norm.weight"),
+                                dz, part, B, H, W, 2, Cn, dy_fine=P[f"lvl{s}.dfine"], ld=Cn)
+            self._fold(part, 3 * Cn, G(prefix + ".norm.weight"), Cn, R)
+            self._fold(part + 4 * Cn, 3 * Cn, G(prefix + ".norm.bias"), Cn, R)
+        self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), gbias)
         self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
                  out=dx_out, ldo=C, out2=cb, ldo2=C if cb is not None else 0, rowscale=cs, rows_per_sample=ct)
         self._release_deferred()
@@ -849,15 +887,32 @@ class TulipEngine:
                 user_hook(tag)
 
         M0 = B * H0 * W0
-        tpart = P["tail.dwd_part"]
-        ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
-                     W_.p32("decoder_pred.weight"), P.pred, P["tail.dz"], tpart, B, H0, W0, E, target=P.target,
-                     gscale_dev=gscale_dev, gscale=gscale)     # L1 backward (tulip.py:692-693) formed in-kernel
         gdw = G("decoder_pred.weight")
-        self._fold(tpart, 128, gdw, E, (M0 + 31) // 32)
-        self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G("ps_head.conv_expand.0.weight"),
-                    G("ps_head.conv_expand.0.bias"))
-        self._gemm(P["tail.dz"], W_.p16("ps_head.conv_expand.0.weight"), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
+        if m.pixel_shuffle:
+            tpart = P["tail.dwd_part"]
+            ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
+                         W_.p32("decoder_pred.weight"), P.pred, P["tail.dz"], tpart, B, H0, W0, E, target=P.target,
+                         gscale_dev=gscale_dev, gscale=gscale)     # L1 backward (tulip.py:692-693) formed in-kernel
+            self._fold(tpart, 128, gdw, E, (M0 + 31) // 32)
+            head_w = "ps_head.conv_expand.0.weight"
+            self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G(head_w), G("ps_head.conv_expand.0.bias"))
+        else:
+            # FinalPatchExpanding backward: d(pred) (L1, tulip.py:692-693) -> decoder_pred / LayerNorm backward per fine
+            # token -> tail.dz = d(Linear output) in the Linear's layout
+            r = m.upscale_factor
+            pre = "final_patch_expanding"
+            ops.l1_loss_bwd(P.pred, P.target, gscale_dev, gscale, P.dpred, P.pred.numel())
+            R = ops.expand_norm_bwd_partial_rows(B, H0, W0, r)
+            part = P.scratch("exp.final", R * 3 * E)
+            ops.expand_norm_bwd(P["tail.ey"], P["tail.emean"], P["tail.erstd"], W_.p32(pre + ".norm.weight"), P["tail.dz"],
+                                part, B, H0, W0, r, E, dpred=P.dpred, dotw=W_.p32("decoder_pred.weight"),
+                                beta=W_.p32(pre + ".norm.bias"))
+            self._fold(part, 3 * E, G(pre + ".norm.weight"), E, R)
+            self._fold(part + 4 * E, 3 * E, G(pre + ".norm.bias"), E, R)
+            self._fold(part + 8 * E, 3 * E, gdw, E, R)
+            head_w = pre + ".expand.weight"
+            self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G(head_w))
+        self._gemm(P["tail.dz"], W_.p16(head_w), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
                  epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
@@ -882,8 +937,12 @@ class TulipEngine:
             self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
             # grad w.r.t. the first concat half (the unmerged stream), un-shuffled to the coarser level's layout in bf16 by
             # the epilogue: it is the operand of that level's PatchUnmerging backward; the x_save half is deferred
-            self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_UNSHUF2_BF16,
-                     out=P[f"lvl{s + 1}.dz2"], ldo=4 * Cs, psH=H0 >> (s + 1), psW=W0 >> (s + 1))
+            if m.patch_unmerging:
+                self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True,
+                           epi=EPI_UNSHUF2_BF16, out=P[f"lvl{s + 1}.dz2"], ldo=4 * Cs, psH=H0 >> (s + 1), psW=W0 >> (s + 1))
+            else:       # PatchExpanding: fine-token order; its LayerNorm backward does the un-rearrange (_unmerge_bwd)
+                self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_BF16,
+                           out=P[f"lvl{s + 1}.dfine"], ldo=Cs)
             hook(f"dec{i}")
         # ---- bottleneck unmerge
         dx = P[f"enc{nl - 1}.dx"]
@@ -964,9 +1023,11 @@ class _TulipFn(torch.autograd.Function):
     def forward(ctx, eng: TulipEngine, P: Plan, *params):
         eng.run_forward(P)
         ctx.eng, ctx.P, ctx.gen = eng, P, P.generation
-        pred = P.pred.clone()
-        ctx.mark_non_differentiable(pred)
-        return pred, P.losses[0].clone(), P.losses[1].clone()
+        pred, pixel = P.pred.clone(), P.losses[1].clone()
+        # only total_loss carries a gradient (the reference back-propagates total_loss alone, misc.py:295); anything
+        # else would be silently dropped by backward() below, so autograd is told to refuse it
+        ctx.mark_non_differentiable(pred, pixel)
+        return pred, P.losses[0].clone(), pixel
 
     @staticmethod
     def backward(ctx, _dpred, dloss, _dpixel):

@@ -63,6 +63,22 @@ class PatchUnmerging(_ParamHolder):  # tulip.py:109-115
         self.upsample = nn.PixelShuffle(2)
 
 
+class PatchExpanding(_ParamHolder):  # tulip.py:126-132 (patch_unmerging=False)
+    def __init__(self, dim, norm_layer):
+        super().__init__()
+        self.dim = dim
+        self.expand = nn.Linear(dim, 2 * dim, bias=False)
+        self.norm = norm_layer(dim // 2)
+
+
+class FinalPatchExpanding(_ParamHolder):  # tulip.py:144-150 (pixel_shuffle=False)
+    def __init__(self, dim, norm_layer, upscale_factor):
+        super().__init__()
+        self.dim, self.upscale_factor = dim, upscale_factor
+        self.expand = nn.Linear(dim, (upscale_factor ** 2) * dim, bias=False)
+        self.norm = norm_layer(dim)
+
+
 class PixelShuffleHead(_ParamHolder):  # tulip.py:161-171
     def __init__(self, dim, upscale_factor):
         super().__init__()
@@ -149,10 +165,7 @@ class BasicBlockUp(_ParamHolder):  # tulip.py:441-475
             SwinTransformerBlock(dim, num_heads[index], window_size, i % 2 == 1, mlp_ratio, qkv_bias, drop_rate,
                                  attn_drop_rate, rates[i], norm_layer) for i in range(depths[index])])
         if patch_expanding:
-            if not patch_unmerging:
-                raise NotImplementedError("tulip_amd implements the PatchUnmerging decoder (--patch_unmerging), the "
-                                          "configuration every reference launch script uses")
-            self.upsample = PatchUnmerging(dim)
+            self.upsample = PatchUnmerging(dim) if patch_unmerging else PatchExpanding(dim, norm_layer)
         else:
             self.upsample = nn.Identity()
 
@@ -184,9 +197,9 @@ class TULIP(nn.Module):
         if drop_rate != 0.0 or attn_drop_rate != 0.0:
             raise NotImplementedError("tulip_amd: element dropout (drop_rate/attn_drop_rate) is 0 in every reference "
                                       "configuration (tulip.py:741-743) and is not implemented in the HIP path")
-        if not pixel_shuffle or not patch_unmerging:
-            raise NotImplementedError("tulip_amd implements the --pixel_shuffle --patch_unmerging architecture used by "
-                                      "every reference launch script (bash_scripts/*.sh)")
+        if not patch_norm:
+            raise NotImplementedError("tulip_amd: patch_norm=False is not implemented (the patch-embedding kernel fuses the "
+                                      "LayerNorm; every reference configuration keeps the default patch_norm=True)")
         if not isinstance(window_size, collections.abc.Iterable):
             window_size = (window_size, window_size)
         common = dict(embed_dim=embed_dim, window_size=window_size, depths=self.depths, num_heads=self.num_heads,
@@ -199,7 +212,8 @@ class TULIP(nn.Module):
         self.layers_up = nn.ModuleList([BasicBlockUp(index=i, patch_expanding=i < self.num_layers - 2,
                                                      patch_unmerging=patch_unmerging, **common)
                                         for i in range(self.num_layers - 1)])
-        self.first_patch_expanding = PatchUnmerging(dim=embed_dim * 2 ** (self.num_layers - 1))
+        top = embed_dim * 2 ** (self.num_layers - 1)
+        self.first_patch_expanding = PatchUnmerging(dim=top) if patch_unmerging else PatchExpanding(top, norm_layer)
         self.skip_connection_layers = nn.ModuleList([
             nn.Linear(2 * embed_dim * 2 ** (self.num_layers - 2 - i), embed_dim * 2 ** (self.num_layers - 2 - i))
             for i in range(self.num_layers - 1)])
@@ -209,10 +223,15 @@ class TULIP(nn.Module):
         self.decoder_pred = nn.Conv2d(embed_dim, in_chans, kernel_size=(1, 1), bias=False)
         self.upscale_factor = int(((target_img_size[0] * target_img_size[1]) / (img_size[0] * img_size[1])) ** 0.5) \
             * 2 * int(((patch_size[0] * patch_size[1]) // 4) ** 0.5)           # tulip.py:577
-        self.ps_head = PixelShuffleHead(embed_dim, self.upscale_factor)
+        if pixel_shuffle:
+            self.ps_head = PixelShuffleHead(embed_dim, self.upscale_factor)
+        else:
+            self.final_patch_expanding = FinalPatchExpanding(embed_dim, norm_layer, self.upscale_factor)
         self.apply(self.init_weights)
         self._engine = None
         self._ln_eps = float(self.norm_up.eps)
+        # load_state_dict / misc.load_model copy into the fp32 views of the flat buffer: the bf16 GEMM operands must follow
+        self.register_load_state_dict_post_hook(lambda module, _keys: module._mark_params_written())
 
     @staticmethod
     def init_weights(m):  # tulip.py:586-594
@@ -230,6 +249,11 @@ class TULIP(nn.Module):
             from ..engine import TulipEngine
             self._engine = TulipEngine(self)
         return self._engine
+
+    def _mark_params_written(self):
+        eng = getattr(self, "_engine", None)
+        if eng is not None and eng.params is not None:
+            eng.params.shadow_dirty = True
 
     def _apply(self, fn, *a, **k):
         # .to()/.cuda()/.float() re-create parameter storage: the engine re-flattens lazily

@@ -188,6 +188,23 @@ def tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E, target=None, gscale_dev
                                      _p(target), _p(gscale_dev), float(gscale), _stream()), "tulip_tail_bwd")
 
 
+def expand_norm_fwd(y, gamma, beta, mean, rstd, B, H, W, P, Cn, eps, out_bf16=None, ld=0, dotw=None, pred=None):
+    """PatchExpanding / FinalPatchExpanding rearrange + LayerNorm (+ decoder_pred dot), see include/tulip_hip.h."""
+    check(_lib.load().tulip_expand_norm_fwd(_p(y), _p(gamma), _p(beta), _p(out_bf16), ld, _p(dotw), _p(pred), _p(mean),
+                                            _p(rstd), B, H, W, P, Cn, eps, _stream()), "tulip_expand_norm_fwd")
+
+
+def expand_norm_bwd(y, mean, rstd, gamma, dy_nat, partials, B, H, W, P, Cn, dy_fine=None, ld=0, dpred=None, dotw=None,
+                    beta=None):
+    check(_lib.load().tulip_expand_norm_bwd(_p(dy_fine), ld, _p(dpred), _p(dotw), _p(y), _p(mean), _p(rstd), _p(gamma),
+                                            _p(beta), _p(dy_nat), _p(partials), B, H, W, P, Cn, _stream()),
+          "tulip_expand_norm_bwd")
+
+
+def expand_norm_bwd_partial_rows(B, H, W, P):
+    return _lib.load().tulip_expand_norm_bwd_partial_rows(B, H, W, P)
+
+
 def l1_loss_fwd(pred, target, partials, losses, n, log_transform):
     check(_lib.load().tulip_l1_loss_fwd(_p(pred), _p(target), _p(partials), _p(losses), n, int(log_transform),
                                         _stream()), "tulip_l1_loss_fwd")

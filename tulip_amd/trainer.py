@@ -69,13 +69,22 @@ class Trainer:
         # N > 1: each bucket is updated (fused AdamW on its slice) on a separate stream as soon as ITS all-reduce has
         # finished, beside the rest of the backward, instead of one update after the last bucket; nothing later in
         # the step reads a finished bucket's parameters or gradients.  The grad-norm read-out needs all gradients.
+        # Opt-in (TULIP_BUCKET_ADAMW=1): it relies on RCCL's stream-ordered work.wait(); the default is one update
+        # after the last bucket, the order the reference's DDP + optimizer.step() has.
         self.bucket_adamw = (self.world > 1 and not track_grad_norm
-                             and os.environ.get("TULIP_BUCKET_ADAMW", "1") != "0")
+                             and os.environ.get("TULIP_BUCKET_ADAMW", "0") == "1")
         self._opt_stream = torch.cuda.Stream(device=device) if self.bucket_adamw else None
         # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
         # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
         self._side = torch.cuda.Stream(device=device) if use_graph else None
+        self.process_group = process_group
+        if self.world > 1:
+            # DistributedDataParallel's constructor broadcasts rank 0's parameters and buffers (main_lidar_upsampling.py:277
+            # after per-rank seeds `args.seed + rank`, :155): without it every rank would start from its own init and
+            # apply identical averaged gradients to different weights.
+            src = 0 if process_group is None else dist.get_global_rank(process_group, 0)
+            dist.broadcast(W.flat, src=src, group=process_group)
         W.refresh_shadow()
 
     # ------------------------------------------------------------------ pieces
@@ -133,6 +142,36 @@ class Trainer:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
         ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=True)
+
+    # ------------------------------------------------------------------ checkpoint (misc.save_model / load_model keep
+    # {'model', 'optimizer', 'epoch', ...}: this is the 'optimizer' entry of the fused AdamW)
+    def state_dict(self) -> dict:
+        W = self.eng.params
+        cut = lambda flat, n: flat[W.offset[n]:W.offset[n] + W.numel[n]].view(W.shape[n]).clone()
+        return {"step": self.t, "micro": self.micro, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                "weight_decay": self.wd, "accum_iter": self.accum_iter,
+                "exp_avg": {n: cut(self.m, n) for n in W.names}, "exp_avg_sq": {n: cut(self.v, n) for n in W.names},
+                "grad": {n: cut(self.g, n) for n in W.names} if self.micro % self.accum_iter else None,
+                "drop_seed": int(self.eng._drop_seed), "drop_counter": int(self.eng._drop_counter.item())}
+
+    def load_state_dict(self, sd: dict) -> None:
+        W = self.eng.params
+        missing = [n for n in W.names if n not in sd["exp_avg"] or n not in sd["exp_avg_sq"]]
+        if missing:
+            raise KeyError(f"optimizer state lacks {len(missing)} parameters, e.g. {missing[:3]}")
+        put = lambda flat, n, t: flat[W.offset[n]:W.offset[n] + W.numel[n]].copy_(t.reshape(-1).to(flat.dtype))
+        for n in W.names:
+            put(self.m, n, sd["exp_avg"][n])
+            put(self.v, n, sd["exp_avg_sq"][n])
+        self.g.zero_()
+        if sd.get("grad") is not None:
+            for n in W.names:
+                put(self.g, n, sd["grad"][n])
+        self.t, self.micro, self.lr = int(sd["step"]), int(sd["micro"]), float(sd["lr"])
+        self.betas, self.eps, self.wd = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
+        self.eng._drop_seed = int(sd["drop_seed"])
+        self.eng._drop_counter.fill_(int(sd["drop_counter"]))
+        W.shadow_dirty = True          # the model's own load_state_dict normally precedes this; refresh either way
 
     # ------------------------------------------------------------------ graph capture
     def _capture(self, update: bool):
@@ -204,6 +243,10 @@ class Trainer:
         update = self.micro % self.accum_iter == 0
         if update:
             self._set_hyper()
+        if self.eng.params.shadow_dirty:
+            # parameters were written from outside (load_state_dict / misc.load_model after construction, a foreign
+            # optimizer): the bf16 GEMM operands are rebuilt here, outside the captured graphs
+            self.eng.params.refresh_shadow()
         if not self.use_graph:
             if update:
                 self._fwd_bwd(self._bucket_done)
@@ -261,6 +304,11 @@ def train_one_epoch(trainer: Trainer, data_loader: Iterable, epoch: int, args, l
             print("Total Loss is {}, stopping training".format(losses[0]))
             print("Pixel Loss is {}, stopping training".format(losses[1]))
             sys.exit(1)
+        if trainer.world > 1:
+            # misc.all_reduce_mean on the logged values (engine_upsampling.py:107-109): one 2-float collective
+            red = torch.tensor(losses, dtype=torch.float32, device=trainer.device)
+            dist.all_reduce(red, group=trainer.process_group)
+            losses = (red / trainer.world).tolist()
         tot, cnt = tot + losses[0], cnt + 1
         if log_every and (it + 1) % log_every == 0:
             print(f"Epoch: [{epoch}]  [{it + 1}/{n}]  lr: {lr:.6f}  loss: {losses[0]:.4f}")
