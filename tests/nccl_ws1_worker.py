@@ -1,0 +1,48 @@
+"""Worker of tests/test_rccl_gpu.py: ONE rank on the `nccl` backend (= RCCL on ROCm) with the N>1 step structure
+forced on (Trainer(force_segments=True)): graph segments cut at the bucket points, one real RCCL all-reduce per bucket
+issued between the replays, stream-ordered work.wait(), thread-local graph capture beside the RCCL watchdog thread, the
+optimizer either as its own segment behind the last all-reduce or per bucket on the optimizer stream.  A one-rank
+all-reduce is the identity, so the result must equal the plain single-process step bit for bit."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, steps = sys.argv[1], int(sys.argv[2])
+    from oracle import tulip_oracle as O
+    from tests.test_model_gpu import build
+    from tulip_amd.trainer import Trainer
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg = O.tiny_config()                                   # DropPath on: the counter-based draws replay identically
+    sd = O.key_seeded_state_dict(cfg, seed=3)
+    lo, hi = O.synthetic_batch(cfg, 4, seed=77)
+    res = {}
+    for name, kw in [("plain", dict()), ("segments", dict(force_segments=True, bucket_mb=0.05)),
+                     ("segments_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, bucket_adamw=True)),
+                     ("eager_plain", dict(use_graph=False)),
+                     ("eager_segments", dict(force_segments=True, bucket_mb=0.05, use_graph=False))]:
+        torch.manual_seed(11)
+        m = build(cfg, sd, train=True)
+        tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, **kw)
+        tr.load_batch(lo.cuda(), hi.cuda())
+        losses = [tr.step().clone() for _ in range(steps)]
+        torch.cuda.synchronize()
+        res[name] = {"flat": tr.eng.params.flat.cpu(), "losses": torch.stack(losses).cpu(),
+                     "segments": len(tr._segments[True]) if tr.use_graph else 0, "buckets": len(tr.bucketer.buckets),
+                     "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw}
+    res["backend"] = dist.get_backend()
+    torch.save(res, out_path)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""SURVEY 8(e) / main_lidar_upsampling.py:277 + util/misc.py:279-284 on ONE GPU: the RCCL (`nccl`) code path of the
+data-parallel step.  RCCL refuses two ranks on one device, so the multi-rank arithmetic is covered over gloo
+(tests/test_ddp_gpu.py) and the RCCL-specific mechanics -- collectives issued between HIP-graph segment replays,
+work.wait() as a stream dependency, capture beside the watchdog thread, the optimizer stream -- here with a one-rank
+group and the segmentation forced on."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
+    out = tmp_path / "ws1.pt"
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_ws1_worker.py"), str(out), "4"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    assert got["backend"] == "nccl"
+    plain = got["plain"]
+    assert not plain["segmented"] and plain["segments"] == 1
+    for name in ("segments", "segments_bucket_adamw", "eager_segments"):
+        g = got[name]
+        assert g["segmented"] and g["buckets"] >= 2
+        if name == "segments":
+            assert g["segments"] == g["buckets"] + 1 and not g["bucket_adamw"]
+        if name == "segments_bucket_adamw":
+            assert g["segments"] == g["buckets"] and g["bucket_adamw"]
+        # (the graphed trainers run one un-captured warm-up pass, which advances the DropPath counter: eager runs are
+        # compared with an eager plain step)
+        ref = got["eager_plain"] if name.startswith("eager") else plain
+        assert torch.equal(g["losses"], ref["losses"]), name
+        assert torch.equal(g["flat"], ref["flat"]), name

@@ -36,18 +36,21 @@ def plan_buckets(groups: Sequence[Tuple[str, int]], total: int, min_elems: int) 
 
 class GradBucketer:
     def __init__(self, groups: Sequence[Tuple[str, int]], total: int, bucket_mb: float = 16.0,
-                 process_group: Optional[dist.ProcessGroup] = None):
+                 process_group: Optional[dist.ProcessGroup] = None, force: bool = False):
+        """force: issue the collectives even in a one-rank group (exercises the N>1 code path -- graph segments,
+        stream-ordered work.wait(), per-bucket optimizer -- on a single GPU; needs an initialised process group)."""
         self.buckets = plan_buckets(groups, total, int(bucket_mb * (1 << 20) / 4))
         self.by_tag = {tag: (a, b) for tag, a, b in self.buckets}
         self.pg = process_group
         self.pending: List = []
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
 
     def on_group_done(self, tag: str, gflat: torch.Tensor, keep: bool = True):
         """Call after the launches producing group `tag` have been enqueued on the current stream.
         Returns (work, start, end) of the bucket's all-reduce, or None.  keep=False: the caller waits on the work
         itself (per-bucket optimizer), wait_all() will not."""
-        if self.world == 1 or tag not in self.by_tag:
+        if not self.active or tag not in self.by_tag:
             return None
         a, b = self.by_tag[tag]
         work = dist.all_reduce(gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

@@ -38,7 +38,11 @@ def cosine_lr(epoch_float: float, lr: float, min_lr: float, warmup_epochs: float
 class Trainer:
     def __init__(self, model, batch_size: int, lr: float = 5e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, device=None, use_graph: bool = True, process_group=None,
-                 bucket_mb: float = 16.0, accum_iter: int = 1, track_grad_norm: bool = False):
+                 bucket_mb: float = 16.0, accum_iter: int = 1, track_grad_norm: bool = False,
+                 force_segments: bool = False, bucket_adamw: Optional[bool] = None):
+        """force_segments: run the N>1 step structure (graph segments cut at the bucket points, one all-reduce per
+        bucket between replays) in a one-rank process group too -- how the RCCL path is exercised on a single GPU.
+        bucket_adamw: None = environment default (TULIP_BUCKET_ADAMW, off)."""
         self.model = model
         device = device or torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -64,15 +68,17 @@ class Trainer:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=device)
         self._norm_part = torch.zeros(1024, dtype=torch.float64, device=device)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.bucketer = GradBucketer(W.groups, W.total, bucket_mb, process_group)
+        self.bucketer = GradBucketer(W.groups, W.total, bucket_mb, process_group, force=force_segments)
+        self.segmented = self.bucketer.active          # the step is cut at the bucket points
         self.use_graph = use_graph
         # N > 1: each bucket is updated (fused AdamW on its slice) on a separate stream as soon as ITS all-reduce has
         # finished, beside the rest of the backward, instead of one update after the last bucket; nothing later in
         # the step reads a finished bucket's parameters or gradients.  The grad-norm read-out needs all gradients.
         # Opt-in (TULIP_BUCKET_ADAMW=1): it relies on RCCL's stream-ordered work.wait(); the default is one update
         # after the last bucket, the order the reference's DDP + optimizer.step() has.
-        self.bucket_adamw = (self.world > 1 and not track_grad_norm
-                             and os.environ.get("TULIP_BUCKET_ADAMW", "0") == "1")
+        if bucket_adamw is None:
+            bucket_adamw = os.environ.get("TULIP_BUCKET_ADAMW", "0") == "1"
+        self.bucket_adamw = self.segmented and not track_grad_norm and bool(bucket_adamw)
         self._opt_stream = torch.cuda.Stream(device=device) if self.bucket_adamw else None
         # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
         # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
@@ -110,7 +116,7 @@ class Trainer:
         eng.draw_drop_scales(P, self.model.training)
         eng.run_forward(P)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
-                         join_tags=set(self.bucketer.by_tag) if (self.world > 1 and update) else None)
+                         join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None)
 
     def _adamw_range(self, lo: int, hi: int):
         W = self.eng.params
@@ -169,7 +175,9 @@ class Trainer:
                 put(self.g, n, sd["grad"][n])
         self.t, self.micro, self.lr = int(sd["step"]), int(sd["micro"]), float(sd["lr"])
         self.betas, self.eps, self.wd = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
-        self.eng._drop_seed = int(sd["drop_seed"])
+        if int(sd["drop_seed"]) != int(self.eng._drop_seed):
+            self.eng._drop_seed = int(sd["drop_seed"])
+            self._segments = None          # the seed is a launch argument baked into the captured graphs: re-capture
         self.eng._drop_counter.fill_(int(sd["drop_counter"]))
         W.shadow_dirty = True          # the model's own load_state_dict normally precedes this; refresh either way
 
@@ -188,7 +196,7 @@ class Trainer:
 
             def hook(tag):
                 nonlocal cur
-                if update and self.world > 1 and tag in self.bucketer.by_tag:
+                if update and self.segmented and tag in self.bucketer.by_tag:
                     cur.capture_end()
                     segs.append((cur, tag))
                     cur = torch.cuda.CUDAGraph()
@@ -198,7 +206,7 @@ class Trainer:
             if not update:
                 cur.capture_end()
                 segs.append((cur, None))
-            elif self.world == 1:
+            elif not self.segmented:
                 self._adamw()
                 cur.capture_end()
                 segs.append((cur, None))
@@ -250,7 +258,7 @@ class Trainer:
         if not self.use_graph:
             if update:
                 self._fwd_bwd(self._bucket_done)
-                if self.world > 1:
+                if self.segmented:
                     self._finish_buckets()
                 else:
                     self._adamw()
@@ -258,12 +266,16 @@ class Trainer:
                 self._fwd_bwd(lambda tag: None, update=False)
             return self.P.losses
         if self._segments is None:
-            # load every kernel once outside capture, without touching parameters or optimizer state
+            # load every kernel once outside capture, without touching parameters, optimizer state, the gradients of an
+            # open accumulation window or the DropPath stream (the pass below accumulates into g and draws once)
+            keep_g, keep_c = self.g.clone(), self.eng._drop_counter.clone()
             self._fwd_bwd(lambda tag: None)
             scratch = torch.zeros(64, dtype=torch.float32, device=self.device)
             ops.adamw(scratch, scratch.clone(), scratch.clone(), scratch.clone(), None, 64, self.hyper, None)
             ops.grad_norm(scratch, 64, self._norm_part, self.grad_norm)
-            self.g.zero_()      # the warm-up pass above accumulated into g without an optimizer step
+            self.g.copy_(keep_g)
+            self.eng._drop_counter.copy_(keep_c)
+            del keep_g
             torch.cuda.synchronize()
             self._segments = {True: self._capture(True)}
             if self.accum_iter > 1:
