@@ -66,91 +66,142 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
     return f"gemm_kernel<{bm}, {t(a_trans)}, {t(b_trans)}, {ksub}>"
 
 
-def _pmc_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected +
-    WRITE_SIZE, collected as MI355X_MICROARCH.md prescribes); counters cannot be read from inside bench.py."""
+def kernel_source_stamp():
+    """Hash of the kernel sources + launch sequences: counter files under profiles/ carry the stamp they were measured
+    at, and a stale file is not reported (the GPU box has no .git to ask for HEAD)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "tulip_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "tulip_amd", "engine.py"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected +
+    WRITE_SIZE, collected as MI355X_MICROARCH.md prescribes: separate --pmc passes, tools/pmc_summary.py); counters cannot
+    be read from inside bench.py.  None when the file is missing or was measured on other kernel sources."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_gemm_traffic.json")) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            d = json.load(f)
+        if d.get("source_stamp") != kernel_source_stamp():
+            return None
+        return round(d["families"][family]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
 
-def gemm_roofline(trainer, reps=5):
-    """Roofline of the dominant kernel family (the bf16 MFMA GEMM: ~84 % of the step's FLOPs; the rest is in the two fused C=96 block kernels).
-    The ~170 GEMM launches of one step are recorded in an eager pass, then each is re-issued `reps`
-    times back to back between ONE HIP-event pair on the launch stream (graph nodes cannot be
-    instrumented, and eager launches would include host gaps).  achieved = sum(algorithmic FLOPs) /
-    sum(mean duration); per-instantiation mean durations are listed for comparison with rocprofv3."""
+def kernel_rooflines(trainer, reps=5):
+    """Roofline of every kernel family that matters in the step.  The launches of one step are recorded in an eager pass
+    (ops.* wrappers), then each is re-issued `reps` times back to back between ONE HIP-event pair on the launch stream
+    (graph nodes cannot be instrumented, and single eager launches would include host gaps): these are ISOLATED
+    durations -- operands of the small launches sit in the Infinity Cache and nothing runs beside them; the in-step
+    averages of the same kernels are in profiles/ (rocprofv3 --kernel-trace --stats of this command), ~10-25 % longer.
+    Per family: algorithmic FLOPs and bytes (operands read once + outputs written once, the per-launch figures of
+    DESIGN.md section 4) / summed duration; `bound` is the side of the ridge (2.5 PF / 8 TB/s = 312 FLOP/B) the
+    family's arithmetic intensity falls on."""
     from tulip_amd import ops
-    calls, groups = [], []
-    real, real_group = ops.gemm, ops.wgrad_group
+    rec = []                                  # (family, detail-name, callable, flops, bytes)
+    real = {n: getattr(ops, n) for n in ("gemm", "wgrad_group", "swin96_block_fwd", "swin96_block_bwd", "swinw_block_fwd",
+                                         "swinw_block_bwd")}
 
-    def record(A, B, M, N, K, **kw):
-        calls.append((A, B, M, N, K, kw))
-        real(A, B, M, N, K, **kw)
+    def gemm(A, B, M, N, K, **kw):
+        f = 2.0 * M * N * K
+        by = 2.0 * (M * K + N * K) + M * N * (4.0 if kw.get("epi", 0) in (3, 4, 5, 6, 7) else 2.0)
+        name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
+        rec.append(("gemm", name, lambda: real["gemm"](A, B, M, N, K, **kw), f, by))
+        real["gemm"](A, B, M, N, K, **kw)
 
-    def record_group(items, extra, ws, ws_bytes, fold=True):
-        groups.append((list(items), ws, ws_bytes))
-        real_group(items, extra, ws, ws_bytes, fold)
-
-    ops.gemm, ops.wgrad_group = record, record_group
-    try:
-        trainer._fwd_bwd(lambda tag: None)
-        torch.cuda.synchronize()
-    finally:
-        ops.gemm, ops.wgrad_group = real, real_group
-    by_inst, tot_t, tot_f, alg_bytes = {}, 0.0, 0.0, 0.0
-    # the weight gradients of a block leave as ONE grouped launch of the same tile code (gemm_group_kernel);
-    # timed without its fold launch
-    for items, ws, ws_bytes in groups:
-        real_group(items, [], ws, ws_bytes, fold=False)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            real_group(items, [], ws, ws_bytes, fold=False)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / reps
-        f, tiles, deep = 0.0, 0, True
+    def wgrad_group(items, extra, ws, ws_bytes, fold=True):
+        items = list(items)
+        f = by = 0.0
+        tiles, deep = 0, True
         for it in items:
             eff = ops.gemm_effective_splits(it.Mtok, it.splits)
             kchunk = -(-(-(-it.Mtok // eff)) // 32) * 32
             tiles += -(-it.Kw // 96) * -(-it.Nw // 64) * eff
             deep = deep and kchunk >= 256
             f += 2.0 * it.Nw * it.Kw * it.Mtok
-            alg_bytes += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw * eff
+            by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw * eff
         ksub = 4 if (tiles <= 400 and deep) else 1
-        d = by_inst.setdefault(f"gemm_group_kernel<64, true, true, {ksub}>", [0, 0.0, 0.0])
-        d[0] += 1; d[1] += t; d[2] += f
-        tot_t += t; tot_f += f
-    for A, B, M, N, K, kw in calls:
-        real(A, B, M, N, K, **kw)
+        # the weight gradients of a block leave as ONE grouped launch of the same tile code; timed without its fold
+        rec.append(("gemm", f"gemm_group_kernel<64, true, true, {ksub}>",
+                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False), f, by))
+        real["wgrad_group"](items, extra, ws, ws_bytes, fold)
+
+    def block(name, fam, bwd, C_of):
+        def f(*a, **kw):
+            C = C_of(a)
+            M = kw["B"] * kw["H"] * kw["W"]
+            # four linears (data gradients only in the backward: the weight gradients are GEMM launches) + the
+            # 16x16 attention core (fwd: QK^T, PV; bwd: S twice, dP twice, dQ, dK, dV)
+            fl = M * (24.0 * C * C + (224.0 if bwd else 64.0) * C)
+            by = (48 if bwd else 40) * C * M + 16.0 * M + 24.0 * C * C
+            rec.append((fam, name, lambda: real[name](*a, **kw), fl, by))
+            real[name](*a, **kw)
+        return f
+
+    patched = {"gemm": gemm, "wgrad_group": wgrad_group,
+               "swin96_block_fwd": block("swin96_block_fwd", "swin96_fwd", False, lambda a: 96),
+               "swin96_block_bwd": block("swin96_block_bwd", "swin96_bwd", True, lambda a: 96),
+               "swinw_block_fwd": block("swinw_block_fwd", "swinw_fwd", False, lambda a: a[0]),
+               "swinw_block_bwd": block("swinw_block_bwd", "swinw_bwd", True, lambda a: a[0])}
+    for n, fn in patched.items():
+        setattr(ops, n, fn)
+    try:
+        trainer._fwd_bwd(lambda tag: None)
+        torch.cuda.synchronize()
+    finally:
+        for n, fn in real.items():
+            setattr(ops, n, fn)
+    W = trainer.eng.params
+    rec.append(("adamw", "adamw_kernel", trainer._adamw, 0.0, 28.0 * W.total + 2.0 * W.total))
+    fams, detail = {}, {}
+    for fam, name, call, fl, by in rec:
+        call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            real(A, B, M, N, K, **kw)
+            call()
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
-        f = 2.0 * M * N * K
-        alg_bytes += 2.0 * (M * K + N * K) + M * N * (4.0 if kw.get("epi", 0) in (3, 4, 5, 6, 7) else 2.0)
-        name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
-        d = by_inst.setdefault(name, [0, 0.0, 0.0])
-        d[0] += 1; d[1] += t; d[2] += f
-        tot_t += t; tot_f += f
-    detail = {k: {"launches": n, "avg_us": round(t / n * 1e6, 2), "tflops": round(f / t / 1e12, 1)}
-              for k, (n, t, f) in sorted(by_inst.items(), key=lambda kv: -kv[1][1])}
-    return {"bound": "mfma", "kernel": "gemm_kernel / gemm_group_kernel<BM,A_T,B_T,KSUB> (one tile code: every linear / 1x1 conv fwd + dgrad outside the fused C=96 blocks, every wgrad)",
-            "achieved": round(tot_f / tot_t / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-            "frac": round(tot_f / tot_t / PEAK_BF16, 4), "traffic": _pmc_traffic(), "launches_per_step": len(calls) + len(groups),
-            # the same launches against the other roof: PMC HBM bytes per launch / mean launch time / 8 TB/s
-            "hbm_frac_of_traffic": (round(_pmc_traffic() / (tot_t / (len(calls) + len(groups))) / PEAK_HBM, 4)
-                                    if _pmc_traffic() else None),
-            "flops_per_launch": tot_f / (len(calls) + len(groups)),
-            "operand_bytes_per_launch": round(alg_bytes / (len(calls) + len(groups))),
-            "mean_launch_us": round(tot_t / (len(calls) + len(groups)) * 1e6, 2),
-            "gemm_ms_per_step": round(tot_t * 1e3, 3), "flops_per_step": tot_f, "by_kernel": detail}
+        a = fams.setdefault(fam, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += t; a[2] += fl; a[3] += by
+        d = detail.setdefault(fam, {}).setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1; d[1] += t; d[2] += fl
+    ridge = PEAK_BF16 / PEAK_HBM
+    kernels = {
+        "gemm": "gemm_kernel / gemm_group_kernel<BM,A_T,B_T,KSUB> (one tile code: every linear / 1x1 conv fwd + dgrad "
+                "outside the fused blocks, every weight gradient)",
+        "swin96_fwd": "swin96_fwd_kernel (whole C=96 Swin block, forward)", "swin96_bwd": "swin96_bwd_kernel",
+        "swinw_fwd": "swinw_fwd_kernel<C,G> (whole C=192/384 Swin block, forward)", "swinw_bwd": "swinw_bwd_kernel<C,G>",
+        "adamw": "adamw_kernel (fp32 master + moments + bf16 shadow, 30 B / parameter)"}
+    out = []
+    for fam, (n, t, fl, by) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
+        ai = fl / by
+        bound = "mfma" if ai >= ridge else "hbm"
+        tf, tb = fl / t / 1e12, by / t / 1e12
+        traffic = _pmc_traffic(fam)
+        e = {"kernel": kernels[fam], "bound": bound,
+             "achieved": round(tf if bound == "mfma" else tb * 1e3, 2), "peak": PEAK_BF16 / 1e12 if bound == "mfma" else PEAK_HBM / 1e9,
+             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+             "frac": round((tf * 1e12 / PEAK_BF16) if bound == "mfma" else (tb * 1e12 / PEAK_HBM), 4),
+             "traffic": traffic, "timing": f"isolated: mean of {reps} back-to-back launches per recorded call, HIP events",
+             "launches_per_step": n, "ms_per_step": round(t * 1e3, 3), "mean_launch_us": round(t / n * 1e6, 2),
+             "arithmetic_intensity_flop_per_byte": round(ai, 1), "algorithmic_bytes_per_launch": round(by / n),
+             "flops_per_launch": round(fl / n), "frac_mfma": round(tf * 1e12 / PEAK_BF16, 4),
+             "frac_hbm_algorithmic": round(tb * 1e12 / PEAK_HBM, 4),
+             "frac_hbm_of_traffic": round(traffic / (t / n) / PEAK_HBM, 4) if traffic else None}
+        if fam == "gemm":
+            e["by_kernel"] = {k: {"launches": c, "avg_us": round(tt / c * 1e6, 2), "tflops": round(f / tt / 1e12, 1)}
+                              for k, (c, tt, f) in sorted(detail[fam].items(), key=lambda kv: -kv[1][1])}
+        out.append(e)
+    top = dict(out[0])
+    top["others"] = out[1:]
+    return top
 
 
 def usable_cores() -> int:
@@ -184,7 +235,7 @@ def cpu_baseline(args):
     lo, hi = O.synthetic_batch(cfg, B, seed=1234)
     enc, dec = O.drop_path_rates(cfg)
     times = []
-    for it in range(1 + args.cpu_steps):
+    for it in range(args.cpu_warmup + args.cpu_steps):
         drop_u = {}
         for s in range(cfg.num_layers):
             for b in range(cfg.depths[s]):
@@ -198,7 +249,7 @@ def cpu_baseline(args):
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
+    t = sorted(times[args.cpu_warmup:])[args.cpu_steps // 2]
     cpu_name = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -209,8 +260,36 @@ def cpu_baseline(args):
     except OSError:
         pass
     return {"value": round(B / t, 3), "unit": "range-images/s", "cores": cores, "kind": "port",
-            "cpu": cpu_name, "sample": f"{args.cpu_steps} timed training steps (median) of batch {B} after 1 warm-up, "
+            "cpu": cpu_name, "sample": f"{args.cpu_steps} timed training steps (median) of batch {B} after {args.cpu_warmup} warm-up, "
             "fp32 eager PyTorch oracle, same model/config/optimizer"}
+
+
+def secondary_batch64(args, device, steps=20, warmup=5):
+    """BASELINE.json configs[4] without its fp8 leg: the same step at per-GPU batch 64, where the kernels rather than
+    the launch chain set the pace (secondary metric; bf16 operands like the headline)."""
+    import copy
+    from tulip_amd.trainer import Trainer
+    a = copy.copy(args)
+    a.batch = 64
+    model = make_model(a).to(device).train()
+    tr = Trainer(model, 64, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, device=device, use_graph=not args.no_graph)
+    lo, hi = synthetic(a, 0, device)
+    tr.load_batch(lo, hi)
+    for _ in range(warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"metric": "range-images/sec training (KITTI 16->64x1024, bs=64/GPU, bf16)", "value": round(64 * steps / dt, 2),
+           "unit": "range-images/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+           "step_mfma_frac": round(64 * steps / dt * FLOP_FWD_BWD_PER_IMG / PEAK_BF16, 5),
+           "step_hbm_frac_oplevel": round(64 * steps / dt * 3 * BYTES_FWD_OPLEVEL_PER_IMG / PEAK_HBM, 5)}
+    del tr, model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -226,7 +305,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the batch-64 line (BASELINE config 5, bf16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -255,14 +336,20 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # wall clock brackets the K steps (the contract's number); one HIP event per step boundary on the launch stream
+    # gives the per-step distribution (median and min)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         losses = trainer.step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -275,7 +362,8 @@ def main():
 
     out = {"metric": "range-images/sec training (KITTI 16->64x1024, bs=8/GPU)", "value": round(value, 2),
            "unit": "range-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "step_ms_median": round(per_step[len(per_step) // 2], 4),
+           "step_ms_min": round(per_step[0], 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"{args.model} {args.img[0]}x{args.img[1]}->{args.target[0]}x{args.target[1]} "
                                   f"training step (fwd+L1+bwd+allreduce+AdamW), per-GPU batch {args.batch}, "
@@ -288,8 +376,13 @@ def main():
            # SURVEY.md 8(d) op-level convention: 3 x 245 MB per image (forward op traffic x3 for training)
            "step_hbm_frac_oplevel": round(value * 3 * BYTES_FWD_OPLEVEL_PER_IMG / world / PEAK_HBM, 5)
            if args.model == "tulip_base" and tuple(args.img) == (16, 1024) else None}
+    out["tolerance"] = ("index ops bit-exact; loss within 1e-3 rel of the reference's fp32 forward; prediction inside the "
+                        "reference's own bf16-autocast band (max 8e-3 abs); gradients <= 1.5e-2 rel L2 per tensor "
+                        "(tests/test_model_gpu.py)")
+    if rank == 0 and world == 1 and not args.no_secondary and args.batch == 8 and args.model == "tulip_base":
+        out["secondary"] = secondary_batch64(args, device)
     if rank == 0 and world == 1 and not args.no_roofline:
-        out["roofline"] = gemm_roofline(trainer)
+        out["roofline"] = kernel_rooflines(trainer)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -357,6 +357,23 @@ typedef struct tulip_swin96_bwd_desc {
 int tulip_swin96_bwd_partial_rows(int B, int H, int W);
 int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream);
 
+/* The same two launches for the wider stages, C = 192 and C = 384 (heads of 32, window 2x8, MLP C -> 4C -> C; H even,
+ * W % 16 == 0; tulip_swinw_supported): a workgroup owns 2 or 4 neighbouring windows with one wave per head, every GEMM
+ * of the block is split along its output channels across the waves, weights stream from L2 straight into MFMA
+ * operand registers, activations pass through LDS (csrc/swinw.hip).  Descriptors, saved tensors and partial rows are
+ * those of the C = 96 entry points with 96 -> C, 288 -> 3C, 384 -> 4C, 3*256 -> (C/32)*256 and partial rows of
+ * [d(weight)[C] | d(bias)[C]].  out_bf16 (optional): bf16 copy of the block output [M][C].
+ * The BACKWARD streams rows of W^T: in its descriptor w_qkv / w_proj / w_fc1 / w_fc2 point to TRANSPOSED bf16 copies
+ * ([C][3C], [C][C], [C][4C], [4C][C]) which tulip_transpose_bf16_multi writes (dst[c][r] = src[r][c]; rows, cols
+ * multiples of 8; up to TULIP_TRANSPOSE_MAX matrices per launch). */
+#define TULIP_TRANSPOSE_MAX 32
+typedef struct tulip_transpose_item { const void* src; void* dst; int rows; int cols; } tulip_transpose_item;
+int tulip_swinw_supported(int C, int H, int W);
+int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hipStream_t stream);
+int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W);
+int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream);
+int tulip_transpose_bf16_multi(const tulip_transpose_item* items, int n, hipStream_t stream);
+
 /* library self-description */
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);

@@ -17,3 +17,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def describe_flat_diff(eng, a, b, limit=8):
+    """Where two flat parameter buffers differ: per parameter (or 'padding'), count and max |difference|."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    W = eng.params
+    covered = a.new_zeros(a.numel(), dtype=bool)
+    out = []
+    for n in W.names:
+        lo, hi = W.offset[n], W.offset[n] + W.numel[n]
+        covered[lo:hi] = True
+        d = (a[lo:hi] - b[lo:hi]).abs()
+        k = int((d > 0).sum())
+        if k:
+            out.append(f"{n}: {k}/{hi - lo} differ, max {d.max().item():.3e}")
+    d = (a - b).abs()[~covered]
+    if int((d > 0).sum()):
+        out.append(f"padding: {int((d > 0).sum())} differ, max {d.max().item():.3e}")
+    return "; ".join(out[:limit]) + (f" ... (+{len(out) - limit} more)" if len(out) > limit else "")

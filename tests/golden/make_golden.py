@@ -282,11 +282,25 @@ def golden_alternates(T):
                  bf16_ref=False)
 
 
+def golden_durlar(T):
+    """G6: BASELINE config 4 geometry -- tulip_large on DurLAR 32x2048 -> 128x2048 (bash_scripts/
+    tulip_upsampling_durlar.sh:11,26-27 runs tulip_base there; tulip_upsampling_carla.sh:10 runs tulip_large at this
+    size), B=1, eval forward incl. the bf16-autocast self-consistency band."""
+    large = O.tulip_large_config(img_size=(32, 2048), target_img_size=(128, 2048))
+    golden_model(T, "g6_durlar_large", large, batch=1, seed=0, with_grads=False, bf16_ref=True)
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     T = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "alternates":
         golden_alternates(T)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        golden_eval()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "durlar":
+        golden_durlar(T)
         return
     golden_index(T)
     golden_lr(T)
@@ -305,6 +319,7 @@ def main():
     large = O.tulip_large_config(img_size=(16, 2048), target_img_size=(64, 2048))
     golden_model(T, "g5_large_16x2048", large, batch=1, seed=0, with_grads=False, bf16_ref=False)
     golden_alternates(T)
+    golden_durlar(T)
     print("done")
 
 
@@ -586,6 +601,8 @@ def golden_eval():
         ("durlar", "durlar", (128, 256), (32, 256), True, False, True, 2),
         ("kitti_mc", "kitti", (64, 1024), (16, 1024), True, True, True, 1),
         ("durlar_mc", "durlar", (128, 256), (32, 256), True, True, False, 1),
+        # BASELINE.json configs[2] at its full size (bash_scripts/tulip_evaluate_carla.sh: 16x2048 -> 64x2048)
+        ("carla_full", "carla", (64, 2048), (16, 2048), True, False, False, 1),
     ]
     for ci, (name, ds, HW, hw, log_t, mc, keep, n_img) in enumerate(cases):
         data = [EO.synthetic_eval_case(ds, *HW, *hw, seed=500 + 10 * ci + k, log_transform=log_t) for k in range(n_img)]

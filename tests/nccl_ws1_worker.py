@@ -39,6 +39,10 @@ def main():
         res[name] = {"flat": tr.eng.params.flat.cpu(), "losses": torch.stack(losses).cpu(),
                      "segments": len(tr._segments[True]) if tr.use_graph else 0, "buckets": len(tr.bucketer.buckets),
                      "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw}
+    from tests.conftest import describe_flat_diff
+    for name in res:
+        ref = res["eager_plain"] if name.startswith("eager") else res["plain"]
+        res[name]["diff"] = describe_flat_diff(tr.eng, res[name]["flat"], ref["flat"])
     res["backend"] = dist.get_backend()
     torch.save(res, out_path)
     dist.destroy_process_group()

@@ -18,7 +18,7 @@ from tulip_amd import evaluation as EV
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-CASES = ["kitti", "carla", "carla_w", "durlar", "kitti_mc", "durlar_mc"]
+CASES = ["kitti", "carla", "carla_w", "durlar", "kitti_mc", "durlar_mc", "carla_full"]
 
 
 @pytest.fixture(scope="module")

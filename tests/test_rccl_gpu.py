@@ -36,4 +36,4 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
         # compared with an eager plain step)
         ref = got["eager_plain"] if name.startswith("eager") else plain
         assert torch.equal(g["losses"], ref["losses"]), name
-        assert torch.equal(g["flat"], ref["flat"]), name
+        assert torch.equal(g["flat"], ref["flat"]), (name, g["diff"])

@@ -114,7 +114,8 @@ def test_trainer_checkpoint_resume_in_the_reference_order():
     torch.cuda.synchronize()
     assert b.t == a.t == 6 and b.lr == 1e-3
     assert torch.equal(torch.stack(lb), torch.stack(la))
-    assert torch.equal(b.eng.params.flat, a.eng.params.flat)
+    from tests.conftest import describe_flat_diff
+    assert torch.equal(b.eng.params.flat, a.eng.params.flat), describe_flat_diff(a.eng, b.eng.params.flat, a.eng.params.flat)
     assert torch.equal(b.eng.params.shadow, a.eng.params.shadow)
     assert torch.equal(b.m, a.m) and torch.equal(b.v, a.v)
 
@@ -128,3 +129,137 @@ def test_pixel_loss_is_marked_non_differentiable():
     assert loss.requires_grad and not pix.requires_grad and not pred.requires_grad
     with pytest.raises(RuntimeError):
         pix.backward()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2..4] at their full sizes
+def _grads_vs_oracle(cfg, sd, lo, hi, B, tol=2e-2):
+    from tests.test_model_gpu import build, rel_l2
+    m = build(cfg, sd, train=False)
+    eng = m.engine()
+    eng.bind(torch.device(DEV, torch.cuda.current_device()))
+    P = eng.plan(B)
+    P.x_in.copy_(lo.to(DEV)); P.target.copy_(hi.to(DEV))
+    eng.draw_drop_scales(P, False)
+    eng.run_forward(P)
+    g1 = torch.zeros(eng.params.total, device=DEV)
+    eng.run_backward(P, g1)
+    g2 = torch.zeros(eng.params.total, device=DEV)
+    eng.run_backward(P, g2, gscale=0.5)
+    torch.cuda.synchronize()
+    _, oloss, _, og = O.tulip_loss_and_grads(sd, cfg, lo, hi)
+    assert abs(P.losses[0].item() - oloss.item()) <= 1e-3 * oloss.item()
+    W_ = eng.params
+    worst = 0.0
+    for n in W_.names:
+        g = g1[W_.offset[n]:W_.offset[n] + W_.numel[n]].view(W_.shape[n])
+        table = n.endswith("relative_position_bias_table")
+        e = rel_l2(g, og[n])
+        assert e <= (1.5e-1 if table else tol), (n, e)
+        worst = max(worst, 0.0 if table else e)
+    assert rel_l2(g2 * 2, g1) <= 4e-3              # linear in the upstream loss scale
+    return worst, eng, P
+
+
+def test_carla_large_16x2048_training_gradients_vs_oracle():
+    """BASELINE.json configs[2], train half (bash_scripts/tulip_upsampling_carla.sh:10,26-27: tulip_large, 16x2048 ->
+    64x2048; stage 4 runs the (1,16) backup window): loss and EVERY parameter gradient of the HIP path at full size against
+    the oracle's fp32 autograd (B=1, DropPath off)."""
+    cfg = O.tulip_large_config(img_size=(16, 2048), target_img_size=(64, 2048))
+    sd = O.key_seeded_state_dict(cfg, seed=13)
+    lo, hi = O.synthetic_batch(cfg, 1, seed=31)
+    worst, _, _ = _grads_vs_oracle(cfg, sd, lo, hi, 1)
+    print(f"CARLA tulip_large 16x2048: worst per-tensor relative L2 gradient error vs fp32 oracle (non-table) {worst:.3e}")
+
+
+def test_carla_large_16x2048_training_step_and_eval_full_size():
+    """configs[2] continued: a fused training step at that size stays finite and learns (B=2, 30 steps), and the
+    evaluation post-processing (expm1, gate, low-res rows restored, range image -> CARLA point cloud, voxel IoU,
+    Chamfer; engine_upsampling.py:176-271, util/evaluation.py:90-175) of one 64x2048 image equals the oracle's."""
+    from oracle import eval_oracle as EO
+    from tulip_amd import evaluation as EV
+    from tulip_amd.model.tulip import tulip_large
+    from tulip_amd.trainer import Trainer
+    torch.manual_seed(0)
+    m = tulip_large(img_size=(16, 2048), target_img_size=(64, 2048), patch_size=(1, 4), in_chans=1, window_size=[2, 8],
+                    pixel_shuffle=True, circular_padding=True, log_transform=True, patch_unmerging=True).to(DEV).train()
+    cfg = O.tulip_large_config(img_size=(16, 2048), target_img_size=(64, 2048))
+    lo, hi = O.synthetic_batch(cfg, 2, seed=5)
+    tr = Trainer(m, 2, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01)
+    tr.load_batch(lo.to(DEV), hi.to(DEV))
+    hist = torch.stack([tr.step().clone() for _ in range(30)])[:, 0].cpu()
+    assert torch.isfinite(hist).all() and hist[-3:].mean().item() < 0.8 * hist[:3].mean().item(), hist
+    m.eval()
+    with torch.no_grad():
+        pred, _, _ = m(lo.to(DEV), hi.to(DEV))
+    # evaluation of the model's own prediction for image 0 (the reference-pinned fixture for this size is the
+    # "carla_full" case of tests/test_eval_gpu.py); stage by stage against the oracle as there
+    ev = EV.RangeEvaluator("carla", (16, 2048), (64, 2048), True, 0.1, False, False, DEV)
+    res = ev(pred[:1].contiguous(), lo[:1].to(DEV), hi[:1].to(DEV)).cpu().numpy()
+    mae, mae_low, p_img, t_img = EO.postprocess(pred[:1].cpu(), hi[:1], lo[:1], "carla", True)
+    d_p, d_t = ev.pred_img.cpu().numpy(), ev.hi_img.cpu().numpy()
+    assert np.array_equal(d_p == 0, p_img == 0) and np.abs(d_p - p_img).max() <= 3e-7 and np.abs(d_t - t_img).max() <= 3e-7
+    assert abs(res[0] - mae) <= 1e-6 * mae and abs(res[1] - mae_low) <= 1e-6 * max(mae_low, 1e-9)
+    tab = EO.carla_tables(64, 2048)
+    op, ot = EO.spherical_pcd(d_p, tab, 80), EO.spherical_pcd(d_t, tab, 80)
+    assert np.array_equal(ev.pcd_pred.cpu().numpy(), op) and np.array_equal(ev.pcd_gt.cpu().numpy(), ot)
+    iou, prec, rec, f1, _ = EO.voxel_metrics(op, ot, 0.1)
+    assert (res[3], res[4], res[5], res[6]) == (iou, prec, rec, f1)
+    assert np.isfinite(res[2]) and res[2] > 0
+
+
+def test_durlar_large_32x2048_forward_vs_golden_and_backward_properties(golden_dir):
+    """BASELINE.json configs[3] geometry: tulip_large, DurLAR 32x2048 -> 128x2048.  B=1 eval forward against the
+    reference's fp32 forward (fixture g6, inside the reference's own bf16-autocast band); B=8 backward: finite, and
+    linear in the upstream loss scale."""
+    import json, os
+    from tests.test_model_gpu import _load, rel_l2
+    from tulip_amd.model import tulip as T
+    z, meta, cfg = _load(golden_dir, "g6_durlar_large")
+    sd = O.key_seeded_state_dict(cfg, seed=meta["seed"])
+    lo, hi = O.synthetic_batch(cfg, meta["batch"], seed=1234 + meta["seed"])
+    m = T.tulip_large(img_size=(32, 2048), target_img_size=(128, 2048), patch_size=(1, 4), in_chans=1,
+                      window_size=[2, 8], pixel_shuffle=True, circular_padding=True, log_transform=True,
+                      patch_unmerging=True)
+    assert sum(p.numel() for p in m.parameters()) == int(z["n_params"]) == 108_621_156
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        pred, loss, pix = m(lo.to(DEV), hi.to(DEV))
+    sub = pred.cpu().reshape(-1)[::257]
+    d = (sub - torch.from_numpy(z["pred_sub257"])).abs()
+    assert d.max().item() <= float(z["autocast_bf16_vs_fp32_maxabs"]) * 1.25, d.max().item()
+    assert d.mean().item() <= float(z["autocast_bf16_vs_fp32_meanabs"]) * 1.25, d.mean().item()
+    assert abs(loss.item() - float(z["loss"])) <= 1e-3 * float(z["loss"])
+    assert abs(pix.item() - float(z["pixel_loss"])) <= 1e-3 * float(z["pixel_loss"])
+    # ---- B = 8 (the per-GPU batch of the DDP run): backward properties at full size
+    m.train()
+    eng = m.engine()
+    P = eng.plan(8)
+    lo8, hi8 = O.synthetic_batch(cfg, 8, seed=77)
+    P.x_in.copy_(lo8.to(DEV)); P.target.copy_(hi8.to(DEV))
+    eng.draw_drop_scales(P, True)
+    eng.run_forward(P)
+    g1 = torch.zeros(eng.params.total, device=DEV)
+    eng.run_backward(P, g1)
+    g2 = torch.zeros(eng.params.total, device=DEV)
+    eng.run_backward(P, g2, gscale=0.25)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    assert rel_l2(g2 * 4, g1) <= 4e-3
+
+
+def test_kitti_batch64_training_is_stable_and_learns():
+    """BASELINE.json configs[4] without the fp8 leg: per-GPU batch 64 (bf16), 200 fused steps."""
+    from tulip_amd.model.tulip import tulip_base
+    from tulip_amd.trainer import Trainer, cosine_lr
+    torch.manual_seed(0)
+    m = tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), patch_size=(1, 4), in_chans=1, window_size=[2, 8],
+                   pixel_shuffle=True, circular_padding=True, log_transform=True, patch_unmerging=True).to(DEV).train()
+    lo, hi = O.synthetic_batch(O.tulip_base_config(), 64, seed=5)
+    tr = Trainer(m, 64, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01)
+    tr.load_batch(lo.to(DEV), hi.to(DEV))
+    hist = torch.stack([tr.step(lr=cosine_lr(it / 20, 5e-4, 1e-5, 1.0, 20.0)).clone() for it in range(200)])[:, 0].cpu()
+    assert torch.isfinite(hist).all()
+    assert hist[-10:].mean().item() < 0.7 * hist[:5].mean().item(), (hist[:5], hist[-10:])
+    assert all(torch.isfinite(p).all() for p in m.parameters())

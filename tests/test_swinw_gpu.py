@@ -1,0 +1,166 @@
+"""GPU: the one-launch Swin block for the wider stages (csrc/swinw.hip, C = 192 / 384) -- forward and backward
+  (a) against the 7-kernel sequences they replace, on every tensor either path writes, and
+  (b) DIRECTLY against the oracle's restatement of SwinTransformerBlock.forward (tulip.py:338-352) run with the same
+      rounding model, forward output and every gradient via the oracle's autograd (no unfused kernel in the loop)."""
+import pytest
+import torch
+
+from oracle import tulip_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = [(1, False, 2), (1, True, 2), (2, False, 2), (2, True, 2), (1, True, 16)]   # (stage, shifted, batch); B=16: 4 windows / workgroup
+
+
+def _model(seed):
+    from tulip_amd.model.tulip import tulip_base
+    torch.manual_seed(seed)
+    m = tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), patch_size=(1, 4), in_chans=1, window_size=[2, 8],
+                   pixel_shuffle=True, circular_padding=True, log_transform=True, patch_unmerging=True).to(DEV).train()
+    with torch.no_grad():                                     # non-trivial norms / biases / bias tables
+        for n, p in m.named_parameters():
+            if p.ndim == 1 or "relative_position_bias_table" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    eng = m.engine()
+    eng.bind(torch.device(DEV, torch.cuda.current_device()))
+    eng.params.refresh_shadow()
+    return m, eng
+
+
+def _setup(stage, shifted, B, seed):
+    m, eng = _model(seed)
+    P = eng.plan(B)
+    sp = eng.enc_blocks[stage][1 if shifted else 0]
+    assert sp.shift == shifted and sp.C == 96 << stage and eng._fusable_wide(sp)
+    M = B * sp.H * sp.W
+    x = torch.randn(M, sp.C, device=DEV) * 1.5 + 0.2
+    xin = P[f"enc{stage}.in"]
+    xin.copy_(x.view_as(xin))
+    du = 0.5 + 0.5 * torch.rand(eng.n_drop_slots, B, device=DEV)   # every other sample kept (rates <= 0.1)
+    du[:, 0] = 0.01                                           # sample 0: both branches of every block dropped
+    eng.draw_drop_scales(P, True, du)
+    return m, eng, P, sp, M, x, xin
+
+
+def _oracle_block(m, eng, P, sp, x, B, need_grad=False):
+    """SwinTransformerBlock.forward of the oracle (bf16 rounding model) on the same input, weights and DropPath draws."""
+    sd = {k: (v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu())
+          for k, v in m.state_dict().items() if k.startswith(sp.prefix + ".")}
+    if need_grad:
+        for k, v in sd.items():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+    cfg = O.tulip_base_config()
+    keep = None
+    if sp.slot >= 0:
+        keep = torch.stack([P.drop_scale[sp.slot], P.drop_scale[sp.slot + 1]]).cpu()
+    xc = x.detach().cpu().reshape(B, sp.H, sp.W, sp.C).clone().requires_grad_(need_grad)
+    out = O.swin_block(O._Prec(True), sd, sp.prefix, cfg, xc, sp.nh, sp.shift, keep)
+    return out, xc, sd
+
+
+@pytest.mark.parametrize("stage,shifted,B", CASES)
+def test_wide_block_forward(stage, shifted, B):
+    m, eng, P, sp, M, x, xin = _setup(stage, shifted, B, seed=stage)
+    C, p = sp.C, sp.prefix
+    names = ["xn1", "mean1", "rstd1", "qkv", "o", "x1", "xn2", "mean2", "rstd2", "h", "g"]
+    res = {}
+    for fused in (False, True):
+        eng.fuse_wide = fused
+        for k in names:
+            P[p + "." + k].fill_(float("nan") if P[p + "." + k].dtype == torch.float32 else 0)
+        out = torch.full((M, C), float("nan"), device=DEV)
+        ob = torch.zeros(M, C, device=DEV, dtype=torch.bfloat16)
+        eng._block_fwd(P, sp, xin, out, out_bf16=ob)
+        torch.cuda.synchronize()
+        res[fused] = {k: P[p + "." + k].float().clone() for k in names}
+        res[fused]["out"], res[fused]["out_bf16"] = out.clone(), ob.float().clone()
+    eng.fuse_wide = True
+    for k, ref in res[False].items():
+        a, b = res[True][k].reshape(-1), ref.reshape(-1)
+        assert torch.isfinite(a).all(), k
+        d = (a - b).abs()
+        tol = 1e-5 * (1 + b.abs()) if k in ("mean1", "rstd1") else 2 ** -6 * (0.05 + b.abs())
+        frac = (d > tol).float().mean().item()
+        rel = (d.norm() / (b.norm() + 1e-12)).item()
+        print(f"{k:8s} frac>{'tol'} {frac:.2e} rel {rel:.2e} max {d.max().item():.3e}")
+        assert frac <= 2e-3, (k, frac, d.max().item())
+        assert rel <= 3e-3, (k, rel)
+    if sp.slot >= 0:       # sample 0 had both branches dropped
+        assert torch.equal(res[True]["out"][: M // B], x[: M // B])
+    # ---- (b) directly against the oracle
+    oo, _, _ = _oracle_block(m, eng, P, sp, x, B)
+    a, b = res[True]["out"].cpu().reshape(-1), oo.detach().reshape(-1)
+    d = (a - b).abs()
+    rel = (d.norm() / b.norm()).item()
+    print(f"fused block vs oracle: rel L2 {rel:.3e} max {d.max().item():.3e}")
+    assert rel <= 2e-3 and d.max().item() <= 3e-2, (rel, d.max().item())
+
+
+@pytest.mark.parametrize("stage,shifted,B", CASES)
+def test_wide_block_backward(stage, shifted, B):
+    m, eng, P, sp, M, x, xin = _setup(stage, shifted, B, seed=10 + stage)
+    C, p = sp.C, sp.prefix
+    saved = eng.overlap_wgrad
+    eng.overlap_wgrad = False                                 # weight gradients and folds inline, on this stream
+    out = torch.empty(M, C, device=DEV)
+    eng.fuse_wide = False
+    eng._block_fwd(P, sp, xin, out)
+    dy = torch.randn(M, C, device=DEV)
+    cast_buf = torch.zeros(M, C, device=DEV, dtype=torch.bfloat16)
+    res = {}
+    for fused in (False, True):
+        eng.fuse_wide_bwd = fused
+        gflat = torch.zeros(eng.params.total, device=DEV)
+        G = lambda name: gflat.data_ptr() + 4 * eng.params.offset[name]
+        dx = dy.clone()
+        cast_buf.zero_()
+        eng._pending, eng._lagged_hook = [], None
+        eng._block_bwd(P, sp, xin, dx, G, have_dyb=False, next_cast=(cast_buf, None, sp.H * sp.W))
+        torch.cuda.synchronize()
+        r = {"dx": dx.clone(), "dx_bf16": cast_buf.float().clone(), "dh": P[p + ".dh"].float().clone(),
+             "dqkv": P[p + ".dqkv"].float().clone(), "dyb_a": P[p + ".dyb_a"].float().clone(),
+             "dyb_m": P[p + ".dyb_m"].float().clone()}
+        for n, q in m.named_parameters():
+            if n.startswith(p + "."):
+                o = eng.params.offset[n]
+                r["g:" + n[len(p) + 1:]] = gflat[o:o + q.numel()].clone()
+        res[fused] = r
+    eng.fuse_wide = eng.fuse_wide_bwd = True
+    eng.overlap_wgrad = saved
+    for k, ref in res[False].items():
+        a, b = res[True][k].reshape(-1), ref.reshape(-1)
+        assert torch.isfinite(a).all(), k
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        print(f"{k:44s} rel {rel:.3e}")
+        assert b.norm().item() > 0, k
+        # the unfused chain rounds d(norm input) to bf16 between its kernels, the fused one keeps it in fp32
+        assert rel <= (2e-2 if "bias_table" in k else 6e-3), (k, rel)
+    if sp.slot >= 0:       # sample 0: both branches dropped -> the block is the identity there
+        assert torch.equal(res[True]["dx"][: M // B], dy[: M // B])
+    # ---- (b) directly against the oracle's autograd of the block
+    oo, xc, sd = _oracle_block(m, eng, P, sp, x, B, need_grad=True)
+    (oo.reshape(M, C) * dy.cpu()).sum().backward()
+    ra = ((res[True]["dx"].cpu() - xc.grad.reshape(M, C)).norm() / xc.grad.norm()).item()
+    print(f"fused backward vs oracle autograd: dx rel L2 {ra:.3e}")
+    assert ra <= 1e-2, ra
+    for n, v in sd.items():
+        if not v.is_floating_point():
+            continue
+        g = res[True]["g:" + n[len(p) + 1:]].cpu().reshape(v.shape)
+        rel = ((g - v.grad).norm() / (v.grad.norm() + 1e-30)).item()
+        print(f"  {n[len(p) + 1:]:40s} vs oracle rel {rel:.3e}")
+        assert rel <= (1e-1 if "bias_table" in n else 1.5e-2), (n, rel)
+
+
+def test_transpose_multi():
+    from tulip_amd import ops
+    shapes = [(576, 192), (192, 192), (768, 192), (192, 768), (1152, 384), (40, 72)]
+    srcs = [torch.randn(r, c, device=DEV).bfloat16() for r, c in shapes]
+    dsts = [torch.zeros(c, r, device=DEV, dtype=torch.bfloat16) for r, c in shapes]
+    items, n = ops.transpose_items([(s, d, r, c) for s, d, (r, c) in zip(srcs, dsts, shapes)])
+    ops.transpose_bf16_multi(items, n)
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, s.t().contiguous())

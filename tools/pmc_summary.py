@@ -20,14 +20,25 @@ for _, k, n, fm, wm in sorted(rows, reverse=True)[:25]:
     print(f"{k:60s} {n:6d} {fm:24.2f} {wm:14.2f}")
 tot_f = sum(v[1] for v in f.values()) / 1024.0 * 2.0; tot_w = sum(v[1] for v in w.values()) / 1024.0
 print(f"TOTAL over run: fetch {tot_f:.0f} MB (x2 corrected), write {tot_w:.0f} MB")
-# GEMM-family aggregate for bench.py's roofline.traffic (optional 3rd argument: output json)
+# per-family aggregates for bench.py's roofline.traffic (optional 3rd argument: output json), stamped with the hash of
+# the kernel sources they were measured on (bench.kernel_source_stamp): a stale file is not reported
 if len(sys.argv) > 3:
-    import json
-    gf = sum(v[1] for k, v in f.items() if k.startswith(("gemm_kernel", "gemm_group_kernel"))) * 1024.0 * 2.0
-    gw = sum(v[1] for k, v in w.items() if k.startswith(("gemm_kernel", "gemm_group_kernel"))) * 1024.0
-    n = sum(v[0] for k, v in f.items() if k.startswith(("gemm_kernel", "gemm_group_kernel")))
+    import json, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_stamp
+    FAM = {"gemm": ("gemm_kernel", "gemm_group_kernel"), "swin96_fwd": ("swin96_fwd_kernel",),
+           "swin96_bwd": ("swin96_bwd_kernel",), "swinw_fwd": ("swinw_fwd_kernel",), "swinw_bwd": ("swinw_bwd_kernel",),
+           "adamw": ("adamw_kernel",)}
+    fams = {}
+    for fam, pre in FAM.items():
+        n = sum(v[0] for k, v in f.items() if k.startswith(pre))
+        if not n:
+            continue
+        gf = sum(v[1] for k, v in f.items() if k.startswith(pre)) * 1024.0 * 2.0
+        gw = sum(v[1] for k, v in w.items() if k.startswith(pre)) * 1024.0
+        fams[fam] = {"launches_counted": n, "fetch_bytes_per_launch": gf / n, "write_bytes_per_launch": gw / n,
+                     "hbm_bytes_per_launch": (gf + gw) / n}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 2; "
                          "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md HBM section); "
-                         "WRITE_SIZE uncorrected",
-               "gemm_launches_counted": n, "fetch_bytes_per_launch": gf / n, "write_bytes_per_launch": gw / n,
-               "hbm_bytes_per_launch": (gf + gw) / n}, open(sys.argv[3], "w"), indent=1)
+                         "WRITE_SIZE uncorrected; calibration of both on a known-bytes copy: profiles/pmc_calibration.txt",
+               "source_stamp": kernel_source_stamp(), "families": fams}, open(sys.argv[3], "w"), indent=1)

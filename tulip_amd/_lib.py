@@ -44,7 +44,12 @@ class WgradItem(ctypes.Structure):
                 ("splits", I)]
 
 
-REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX = 16, 4
+class TransposeItem(ctypes.Structure):
+    """tulip_transpose_item (include/tulip_hip.h)."""
+    _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I)]
+
+
+REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, TRANSPOSE_MAX = 16, 4, 32
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -52,6 +57,11 @@ SIGNATURES = {
     "tulip_swin96_block_fwd": [P, P],
     "tulip_swin96_block_bwd": [P, P],
     "tulip_swin96_bwd_partial_rows": [I, I, I],
+    "tulip_swinw_supported": [I, I, I],
+    "tulip_swinw_block_fwd": [P, I, P, P],
+    "tulip_swinw_bwd_partial_rows": [I, I, I, I],
+    "tulip_swinw_block_bwd": [P, I, P],
+    "tulip_transpose_bf16_multi": [P, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],

@@ -227,6 +227,24 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
             }
         }
     }
+    if (r.scatter && r.LL == 256) {                   // block-uniform
+        // Scatter-add through the relative-position index (several (i,j) pairs share a table entry), deterministic:
+        // a workgroup covers exactly one head here (RL = 4: 64 float4 columns = 256 dense values, set by the
+        // launcher); the dense sums go to LDS and one thread per table entry adds its pairs in index order.
+        __syncthreads();
+        if (rl == 0) red[ct] = acc;
+        __syncthreads();
+        const int h = blockIdx.x - r.first_block;
+        const float* dense = (const float*)red;
+        for (int e = threadIdx.x; e < 256; e += 256) {
+            float s = 0.f;
+            bool any = false;
+            for (int ij = 0; ij < 256; ++ij)
+                if (r.scatter[ij] == e) { s += dense[ij]; any = true; }
+            if (any) r.out[e * r.nh + h] += s;
+        }
+        return;
+    }
     if (rl == 0 && col < r.n4) {
         if (r.scatter) {
             const float v[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -509,6 +527,7 @@ extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n
         // took 50-80 us with one thread per column)
         r.rl = 1;
         while (r.rl < 16 && r.rl * 8 <= g.rows && (r.n4 * r.rl + 255) / 256 < 512) r.rl *= 2;
+        if (g.scatter_index && g.scatter_len == 256) r.rl = 4;     // one workgroup per head: deterministic scatter
         r.first_block = blocks;
         const int ct = 256 / r.rl;
         blocks += (int)((r.n4 + ct - 1) / ct);

@@ -1,0 +1,837 @@
+// One launch for a whole Swin block at the wider stages (C = 192 and 384: stages 1 and 2 of every TULIP model; 32-wide
+// heads, window 2x8, MLP C -> 4C -> C; tulip.py:338-352 with :289-323 and :194-200 inside), forward and backward.
+//
+// At these widths a block's weights (12 C^2 bf16 = 0.9 / 3.5 MB) no longer fit in LDS and one window per wave (the
+// C = 96 design of swin96.hip) is far too serial: stage 1 of a batch of 8 has 512 windows for 1024 SIMDs.  Here a
+// workgroup owns G neighbouring windows (T = 16 G tokens) and has one wave per HEAD (6 / 12 waves); every GEMM of the
+// block is split along its OUTPUT channels across the waves:
+//   * weights never touch LDS: with the MFMA issued as W . X^T the A operand of lane (t, gq) is 16 contiguous bytes of
+//     weight row n0 + t, so each wave streams exactly its own rows from L2 straight into registers (1 KiB per load
+//     instruction, a ring of loads in flight), and a fragment is reused for the G token tiles;
+//   * activations go through LDS between the GEMMs ([32-k tile][token][64 B], 16-B XOR swizzle: conflict-free
+//     ds_read_b128 fragments): LayerNorm output -> qkv (wave = head: q, k, v of its head stay in registers for the
+//     attention core) -> attention output -> proj (+ residual; LayerNorm statistics combined across the waves with the
+//     parallel-variance formula, one 8-byte exchange per token and wave) -> fc1 -> GELU -> fc2 (+ residual).
+// Everything the backward needs is written exactly as the separate kernels write it.
+//
+// The backward mirrors it: fc2' -> GELU' -> fc1' -> norm2' -> proj' -> attention' -> qkv' -> norm1' with the same
+// split.  Its data-gradient GEMMs contract over the output channels of each Linear, i.e. they stream W^T rows: the
+// caller passes bf16 TRANSPOSED copies of the four weights (tulip_transpose_bf16 refreshes them once per step).
+// Per-channel parameter partial sums (LayerNorm affine, relative-position bias) are disjoint between waves, so each
+// wave writes its slice of the workgroup's partial row directly.
+#include <type_traits>
+#include "common.h"
+#include "tulip_hip.h"
+
+namespace {
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+__device__ __forceinline__ int region(int x, int X, int wsz, int ssz) {       // create_mask slices, tulip.py:261-266
+    return (ssz == 0 || x >= X - ssz) ? 2 : (x >= X - wsz ? 1 : 0);
+}
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    return __builtin_bit_cast(bf16x4, (u32x2_t){pack_bf16x2(a, b), pack_bf16x2(c, d)});
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x4 trr(const unsigned char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p); }
+
+// activations in LDS: [k tile of 32 channels][T tokens][64 B], 16-B chunks XOR-swizzled by token
+template <int T>
+__device__ __forceinline__ void put4(unsigned char* base, int tok, int c, bf16x4 v) {
+    *(bf16x4*)(base + (c >> 5) * (T * 64) + tok * 64 + ((((c >> 3) & 3) ^ swz4(tok)) << 4) + (c & 7) * 2) = v;
+}
+template <int T>
+__device__ __forceinline__ bf16x8 frag(const unsigned char* base, int kt, int tok, int gq) {
+    return *(const bf16x8*)(base + kt * (T * 64) + tok * 64 + ((gq ^ swz4(tok)) << 4));
+}
+
+// acc[i][g] += W[rows of tile i][k] . X[token tile g][k]^T over KSTEPS 32-deep steps.  wrow[i]: this lane's weight row
+// of tile i, already offset by its 8 k-slots (8 gq); the weight stream runs PF steps ahead of the MFMAs.
+template <int NTILE, int G, int KSTEPS, int PF, int T>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[NTILE][G], const bf16_t* const (&wrow)[NTILE],
+                                          const unsigned char* act, int t, int gq) {
+    bf16x8 ring[PF][NTILE];
+    static_for<PF>([&](auto P_) {
+        constexpr int p = decltype(P_)::value;
+        if constexpr (p < KSTEPS) {
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) ring[p][i] = *(const bf16x8*)(wrow[i] + 32 * p);
+        }
+    });
+    static_for<KSTEPS>([&](auto K_) {
+        constexpr int ks = decltype(K_)::value;
+        bf16x8 a[NTILE];
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) a[i] = ring[ks % PF][i];
+        if constexpr (ks + PF < KSTEPS) {
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) ring[ks % PF][i] = *(const bf16x8*)(wrow[i] + 32 * (ks + PF));
+        }
+        bf16x8 b[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) b[g] = frag<T>(act, ks, 16 * g + t, gq);
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[g], acc[i][g], 0, 0, 0);
+    });
+}
+
+struct SwinWArgs {
+    const float* xin; float* x1; float* xout;
+    bf16_t *xn1, *qkv, *o, *xn2, *h, *g;
+    float *mean1, *rstd1, *mean2, *rstd2;
+    const bf16_t *wqkv, *wproj, *w1, *w2;
+    const float *bqkv, *bproj, *b1, *b2, *g1, *be1, *g2, *be2;
+    const float* bias_table; const int* rel_index;
+    const float *ds0, *ds1;               // DropPath multipliers per sample (attention / MLP branch) or nullptr
+    bf16_t* out_bf16;                     // optional bf16 copy of the block output (operand of a PatchUnmerging GEMM)
+    int B, H, W, sh, sw, masked;
+    float eps, scale;
+};
+
+template <int C, int G>
+struct Geo {
+    static constexpr int NH = C / 32, NWV = NH, NT = NWV * 64, T = 16 * G, KS = C / 32, HID = 4 * C;
+    static constexpr int XN_BYTES = T * C * 2;                 // LayerNorm output (norm1, then norm2)
+    static constexpr int BIG_BYTES = T * HID * 2;              // attention output | V tiles, later gelu(fc1)
+    static constexpr int OFF_XN = 0, OFF_BIG = XN_BYTES, OFF_V = OFF_BIG + XN_BYTES;
+    static constexpr int OFF_STAT = OFF_BIG + BIG_BYTES;
+    static constexpr int SMEM = OFF_STAT + NWV * T * 8;
+    static_assert(OFF_V + NWV * 1024 <= OFF_STAT, "V tiles must fit beside the attention output");
+    static_assert(SMEM <= 163840, "LDS");
+};
+
+// natural-order token of tile slot tt = 16 g + t (cyclic shift + window partition are address arithmetic, tulip.py:289-297)
+struct TokMap {
+    int b, wy, wx0, H, W, sh, sw;
+    __device__ __forceinline__ void coords(int tt, int& hs, int& ws) const {
+        const int t = tt & 15;
+        hs = wy * 2 + (t >> 3);
+        ws = (wx0 + (tt >> 4)) * 8 + (t & 7);
+    }
+    __device__ __forceinline__ size_t row(int tt) const {
+        int hs, ws;
+        coords(tt, hs, ws);
+        int hh = hs + sh; if (hh >= H) hh -= H;
+        int ww = ws + sw; if (ww >= W) ww -= W;
+        return ((size_t)b * H + hh) * W + ww;
+    }
+    __device__ __forceinline__ int label(int tt) const {
+        int hs, ws;
+        coords(tt, hs, ws);
+        return 3 * region(hs, H, 2, sh) + region(ws, W, 8, sw);
+    }
+};
+template <int G>
+__device__ __forceinline__ TokMap make_map(int B, int H, int W, int sh, int sw) {
+    const int nWx = W >> 3, nWy = H >> 1, gpr = nWx / G;
+    int blk = blockIdx.x;
+    TokMap m;
+    m.b = blk / (nWy * gpr);
+    blk -= m.b * nWy * gpr;
+    m.wy = blk / gpr;
+    m.wx0 = (blk - m.wy * gpr) * G;
+    m.H = H; m.W = W; m.sh = sh; m.sw = sw;
+    return m;
+}
+
+template <int C, int G>
+__global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWArgs a) {
+    using Z = Geo<C, G>;
+    constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
+    unsigned char* const XN = smem + Z::OFF_XN;
+    unsigned char* const XO = smem + Z::OFF_BIG;
+    unsigned char* const GB = smem + Z::OFF_BIG;
+    float2* const STAT = (float2*)(smem + Z::OFF_STAT);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
+    unsigned char* const ldsV = smem + Z::OFF_V + wid * 1024;
+    const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw);
+    const float s0 = a.ds0 ? a.ds0[tm.b] : 1.0f, s1v = a.ds1 ? a.ds1[tm.b] : 1.0f;
+
+    // ---- norm1 (tulip.py:340): 16 lanes per token, 4 tokens per wave pass
+    for (int tt = wid * 4 + gq; tt < T; tt += NWV * 4) {
+        const size_t row = tm.row(tt);
+        float4 xv[C / 64];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < C / 64; ++j) {
+            xv[j] = *(const float4*)(a.xin + row * C + 4 * t + 64 * j);
+            s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        }
+        const float mu = group_sum<16>(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < C / 64; ++j) {
+            const float d0 = xv[j].x - mu, d1 = xv[j].y - mu, d2 = xv[j].z - mu, d3 = xv[j].w - mu;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        const float rs = rsqrtf(group_sum<16>(q) * (1.0f / C) + a.eps);
+        if (t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+#pragma unroll
+        for (int j = 0; j < C / 64; ++j) {
+            const int c = 4 * t + 64 * j;
+            const float4 ga = *(const float4*)(a.g1 + c), be = *(const float4*)(a.be1 + c);
+            const bf16x4 p = pack4((xv[j].x - mu) * rs * ga.x + be.x, (xv[j].y - mu) * rs * ga.y + be.y,
+                                   (xv[j].z - mu) * rs * ga.z + be.z, (xv[j].w - mu) * rs * ga.w + be.w);
+            *(bf16x4*)(a.xn1 + row * C + c) = p;
+            put4<T>(XN, tt, c, p);
+        }
+    }
+    // this lane's tokens in the MFMA phases: token t of window g
+    size_t rows[G];
+    int lab[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { rows[g] = tm.row(16 * g + t); lab[g] = tm.label(16 * g + t); }
+    // relative-position bias of this wave's head for (query t, keys 4gq..4gq+3) (tulip.py:304-308)
+    float rpb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rpb[r] = a.bias_table[a.rel_index[t * 16 + gq * 4 + r] * NH + wid];
+    __syncthreads();
+
+    // ---- qkv Linear (tulip.py:298), wave = head: q, k, v channels 32 wid .. +31 of each section
+    bf16x4 qkvp[6][G];
+    {
+        f32x4 acc[6][G];
+        const bf16_t* wrow[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            wrow[i] = a.wqkv + (size_t)((i >> 1) * C + 32 * wid + 16 * (i & 1) + t) * C + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<6, G, KS, 2, T>(acc, wrow, XN, t, gq);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int n = (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq;
+            const float4 bq = *(const float4*)(a.bqkv + n);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                qkvp[i][g] = pack4(acc[i][g][0] + bq.x, acc[i][g][1] + bq.y, acc[i][g][2] + bq.z, acc[i][g][3] + bq.w);
+                *(bf16x4*)(a.qkv + rows[g] * (3 * C) + n) = qkvp[i][g];
+            }
+        }
+    }
+
+    // ---- attention of this head, one window at a time (tulip.py:300-317); scores as K.Q^T: lane = query t, keys 4gq + r
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const bf16x8 qf = cat8(qkvp[0][g], qkvp[1][g]);
+        const bf16x8 kf = cat8(qkvp[2][g], qkvp[3][g]);
+        *(bf16x4*)(ldsV + t * 64 + (4 * gq) * 2) = qkvp[4][g];             // V tile [token][d], d = 0..15
+        *(bf16x4*)(ldsV + t * 64 + (16 + 4 * gq) * 2) = qkvp[5][g];        // d = 16..31
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc, 0, 0, 0);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = sc[r] * a.scale + rpb[r];
+            if (a.masked) {
+                const int kl = __shfl(lab[g], gq * 4 + r, 64);
+                if (kl != lab[g]) x += -100.0f;
+            }
+            sc[r] = x;
+            mx = fmaxf(mx, x);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = __expf(sc[r] - mx); sum += sc[r]; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        const bf16x4 pb = pack4(sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv);
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) {
+            const bf16x4 vt = trr(ldsV + (gq * 4 + (t >> 2)) * 64 + dc * 32 + (t & 3) * 8);
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb, o, 0, 0, 0);   // o[r] = O[t][16dc + 4gq + r]
+            const bf16x4 op = pack4(o[0], o[1], o[2], o[3]);
+            const int c = 32 * wid + 16 * dc + 4 * gq;
+            *(bf16x4*)(a.o + rows[g] * C + c) = op;
+            put4<T>(XO, 16 * g + t, c, op);
+        }
+    }
+    __syncthreads();
+
+    // ---- proj Linear + DropPath + residual (tulip.py:318,344): this wave's 32 output channels; then norm2 (:347)
+    f32x4 x1v[2][G];
+    {
+        f32x4 acc[2][G];
+        const bf16_t* wrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wrow[i] = a.wproj + (size_t)(32 * wid + 16 * i + t) * C + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<2, G, KS, 4, T>(acc, wrow, XO, t, gq);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c0 = 32 * wid + 16 * i + 4 * gq;
+                const float4 bp = *(const float4*)(a.bproj + c0);
+                const float4 x = *(const float4*)(a.xin + rows[g] * C + c0);
+                x1v[i][g] = (f32x4){x.x + s0 * (acc[i][g][0] + bp.x), x.y + s0 * (acc[i][g][1] + bp.y),
+                                    x.z + s0 * (acc[i][g][2] + bp.z), x.w + s0 * (acc[i][g][3] + bp.w)};
+                *(float4*)(a.x1 + rows[g] * C + c0) = make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]);
+                s += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
+            }
+            // statistics of this wave's 32 channels of token t: (mean, sum of squared deviations)
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            const float mw = s * (1.0f / 32);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = x1v[i][g][r] - mw; q += d * d; }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (gq == 0) STAT[wid * T + 16 * g + t] = make_float2(mw, q);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        // combine the NWV equal-sized groups: mean of means; M2 = sum M2_w + 32 sum (mean_w - mean)^2
+        float2 st[NWV];
+        float ms = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { st[w] = STAT[w * T + 16 * g + t]; ms += st[w].x; }
+        const float mu = ms * (1.0f / NWV);
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { const float d = st[w].x - mu; m2 += st[w].y + 32.0f * d * d; }
+        const float rs = rsqrtf(m2 * (1.0f / C) + a.eps);
+        if (wid == 0 && gq == 0) { a.mean2[rows[g]] = mu; a.rstd2[rows[g]] = rs; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c0 = 32 * wid + 16 * i + 4 * gq;
+            const float4 ga = *(const float4*)(a.g2 + c0), be = *(const float4*)(a.be2 + c0);
+            const bf16x4 p = pack4((x1v[i][g][0] - mu) * rs * ga.x + be.x, (x1v[i][g][1] - mu) * rs * ga.y + be.y,
+                                   (x1v[i][g][2] - mu) * rs * ga.z + be.z, (x1v[i][g][3] - mu) * rs * ga.w + be.w);
+            *(bf16x4*)(a.xn2 + rows[g] * C + c0) = p;
+            put4<T>(XN, 16 * g + t, c0, p);
+        }
+    }
+    __syncthreads();
+
+    // ---- fc1 + exact-erf GELU (tulip.py:195-196): this wave's 128 hidden channels, 64 at a time
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        f32x4 acc[4][G];
+        const bf16_t* wrow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wrow[i] = a.w1 + (size_t)(128 * wid + 64 * ch + 16 * i + t) * C + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<4, G, KS, 2, T>(acc, wrow, XN, t, gq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
+            const float4 bb = *(const float4*)(a.b1 + n);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bf16x4 hp = pack4(acc[i][g][0] + bb.x, acc[i][g][1] + bb.y, acc[i][g][2] + bb.z, acc[i][g][3] + bb.w);
+                *(bf16x4*)(a.h + rows[g] * HID + n) = hp;
+                const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
+                const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
+                const bf16x4 gp = pack4(g01.x, g01.y, g23.x, g23.y);
+                *(bf16x4*)(a.g + rows[g] * HID + n) = gp;
+                put4<T>(GB, 16 * g + t, n, gp);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fc2 + DropPath + residual (tulip.py:198,351)
+    {
+        f32x4 acc[2][G];
+        const bf16_t* wrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wrow[i] = a.w2 + (size_t)(32 * wid + 16 * i + t) * HID + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<2, G, 4 * KS, 4, T>(acc, wrow, GB, t, gq);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c0 = 32 * wid + 16 * i + 4 * gq;
+            const float4 bb = *(const float4*)(a.b2 + c0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float o0 = x1v[i][g][0] + s1v * (acc[i][g][0] + bb.x), o1 = x1v[i][g][1] + s1v * (acc[i][g][1] + bb.y);
+                const float o2 = x1v[i][g][2] + s1v * (acc[i][g][2] + bb.z), o3 = x1v[i][g][3] + s1v * (acc[i][g][3] + bb.w);
+                *(float4*)(a.xout + rows[g] * C + c0) = make_float4(o0, o1, o2, o3);
+                if (a.out_bf16) *(bf16x4*)(a.out_bf16 + rows[g] * C + c0) = pack4(o0, o1, o2, o3);
+            }
+        }
+    }
+}
+
+template <int C, int G>
+int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
+    const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
+    hipLaunchKernelGGL((swinw_fwd_kernel<C, G>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+
+// =====================================================================================================================
+// backward
+struct SwinWBwdArgs {
+    float* dx;                                   // in: d(block output); out: d(block input)
+    const float *xin, *x1;
+    const bf16_t *qkv, *h;
+    const float *mean1, *rstd1, *mean2, *rstd2;
+    const bf16_t *wqkvt, *wprojt, *w1t, *w2t;    // TRANSPOSED bf16 weights: [C][3C], [C][C], [C][4C], [4C][C]
+    const float *g1, *g2;
+    const float* bias_table; const int* rel_index;
+    const float *ds0, *ds1;
+    bf16_t *dyb_m, *dh, *dyb_a, *dqkv;           // bf16 operands of the fc2 / fc1 / proj / qkv weight gradients
+    bf16_t* dx_bf16; const float* dx_scale;      // optional bf16(dx * per-sample scale) for the consumer of dx
+    float *lnpart1, *lnpart2, *biaspart;         // [workgroups][2C], [workgroups][2C], [workgroups][NH*256]
+    int B, H, W, sh, sw, masked;
+    float scale;
+};
+
+template <int C, int G>
+struct GeoB {
+    static constexpr int NH = C / 32, NWV = NH, NT = NWV * 64, T = 16 * G, KS = C / 32, HID = 4 * C;
+    static constexpr int DY_BYTES = T * C * 2;                 // bf16(dy s_mlp), then bf16(d(x1) s_attn)
+    static constexpr int BIG_BYTES = T * HID * 2;              // d(fc1 pre-activation), later d(qkv) (3/4 of it)
+    static constexpr int OFF_DY = 0, OFF_BIG = DY_BYTES, OFF_ATT = OFF_BIG + BIG_BYTES;   // NWV x (Q | K | dO) 1-KiB tiles
+    static constexpr int OFF_STAT = OFF_ATT + NWV * 3072;
+    static constexpr int SMEM = OFF_STAT + NWV * T * 8;
+    static_assert(SMEM <= 163840, "LDS");
+};
+
+// LayerNorm backward of this wave's 32-channel slice (2 tiles x 4 channels per lane, G token tiles).  Phase 1: the
+// affine-gradient sums of the slice (over the workgroup's T tokens) go straight to the partial row, d <- d * gamma,
+// and the per-token partial sums (sum d, sum d*xhat over the 32 channels) to STAT.  Phase 2 (after the barrier):
+// d <- rstd * (d - m1 - xhat * m2) with the sums over all NWV waves.
+template <int C, int G, int T>
+__device__ __forceinline__ void ln_bwd_part1(f32x4 (&d)[2][G], f32x4 (&xh)[2][G], const float* __restrict__ x,
+                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                             const float* __restrict__ gam, const size_t (&rows)[G], float (&rs)[G],
+                                             float* __restrict__ part, float2* STAT, int wid, int t, int gq) {
+    f32x4 pg[2], pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pg[i] = pb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float mu = mean[rows[g]];
+        rs[g] = rstd[rows[g]];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c0 = 32 * wid + 16 * i + 4 * gq;
+            const float4 xv = *(const float4*)(x + rows[g] * C + c0), ga = *(const float4*)(gam + c0);
+            const float xr[4] = {xv.x, xv.y, xv.z, xv.w}, gr[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[i][g][r] = (xr[r] - mu) * rs[g];
+                pg[i][r] += d[i][g][r] * xh[i][g][r];
+                pb[i][r] += d[i][g][r];
+                d[i][g][r] *= gr[r];
+                s1 += d[i][g][r];
+                s2 += d[i][g][r] * xh[i][g][r];
+            }
+        }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (gq == 0) STAT[wid * T + 16 * g + t] = make_float2(s1, s2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float4 sg, sb;
+        sg.x = group_sum<16>(pg[i][0]); sg.y = group_sum<16>(pg[i][1]); sg.z = group_sum<16>(pg[i][2]); sg.w = group_sum<16>(pg[i][3]);
+        sb.x = group_sum<16>(pb[i][0]); sb.y = group_sum<16>(pb[i][1]); sb.z = group_sum<16>(pb[i][2]); sb.w = group_sum<16>(pb[i][3]);
+        if (t == 0) {
+            const int c0 = 32 * wid + 16 * i + 4 * gq;
+            *(float4*)(part + c0) = sg;
+            *(float4*)(part + C + c0) = sb;
+        }
+    }
+}
+template <int C, int G, int T, int NWV>
+__device__ __forceinline__ void ln_bwd_part2(f32x4 (&d)[2][G], const f32x4 (&xh)[2][G], const float (&rs)[G],
+                                             const float2* STAT, int t) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { const float2 v = STAT[w * T + 16 * g + t]; s1 += v.x; s2 += v.y; }
+        const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[i][g][r] = rs[g] * (d[i][g][r] - m1 - xh[i][g][r] * m2);
+    }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinWBwdArgs a) {
+    using Z = GeoB<C, G>;
+    constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
+    unsigned char* const DY = smem + Z::OFF_DY;
+    unsigned char* const DH = smem + Z::OFF_BIG;
+    unsigned char* const DQ = smem + Z::OFF_BIG;
+    float2* const STAT = (float2*)(smem + Z::OFF_STAT);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
+    const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw);
+    const float s0 = a.ds0 ? a.ds0[tm.b] : 1.0f, s1v = a.ds1 ? a.ds1[tm.b] : 1.0f;
+
+    // ---- bf16(dy * s_mlp): operand of fc2's weight gradient and of the first data-gradient GEMM
+    for (int tt = wid * 4 + gq; tt < T; tt += NWV * 4) {
+        const size_t row = tm.row(tt);
+#pragma unroll
+        for (int j = 0; j < C / 64; ++j) {
+            const int c = 4 * t + 64 * j;
+            const float4 v = *(const float4*)(a.dx + row * C + c);
+            const bf16x4 p = pack4(v.x * s1v, v.y * s1v, v.z * s1v, v.w * s1v);
+            *(bf16x4*)(a.dyb_m + row * C + c) = p;
+            put4<T>(DY, tt, c, p);
+        }
+    }
+    size_t rows[G];
+    int lab[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { rows[g] = tm.row(16 * g + t); lab[g] = tm.label(16 * g + t); }
+    // relative-position bias seen from the query side (query t, key 4gq+r) and from the key side (query 4gq+r, key t)
+    float bias_q[4], bias_k[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bias_q[r] = a.bias_table[a.rel_index[t * 16 + gq * 4 + r] * NH + wid];
+        bias_k[r] = a.bias_table[a.rel_index[(gq * 4 + r) * 16 + t] * NH + wid];
+    }
+    __syncthreads();
+
+    // ---- fc2' and GELU' (tulip.py:196-198 backwards): d(h) for this wave's 128 hidden channels = (dy . W2)[hid] * gelu'(h)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        f32x4 acc[4][G];
+        const bf16_t* wrow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wrow[i] = a.w2t + (size_t)(128 * wid + 64 * ch + 16 * i + t) * C + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<4, G, KS, 2, T>(acc, wrow, DY, t, gq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bf16x4 hv = *(const bf16x4*)(a.h + rows[g] * HID + n);
+                const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[0]), bf2f((bf16_t)hv[1])});
+                const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[2]), bf2f((bf16_t)hv[3])});
+                const bf16x4 dp = pack4(acc[i][g][0] * d01.x, acc[i][g][1] * d01.y, acc[i][g][2] * d23.x, acc[i][g][3] * d23.y);
+                *(bf16x4*)(a.dh + rows[g] * HID + n) = dp;
+                put4<T>(DH, 16 * g + t, n, dp);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fc1' (tulip.py:195 backwards): d(xn2)[c] for this wave's 32 channels, then norm2' and the residual
+    f32x4 dx1[2][G];
+    {
+        f32x4 xh[2][G];
+        float rs[G];
+        const bf16_t* wrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wrow[i] = a.w1t + (size_t)(32 * wid + 16 * i + t) * HID + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) dx1[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<2, G, 4 * KS, 4, T>(dx1, wrow, DH, t, gq);
+        ln_bwd_part1<C, G, T>(dx1, xh, a.x1, a.mean2, a.rstd2, a.g2, rows, rs, a.lnpart2 + (size_t)blockIdx.x * 2 * C, STAT,
+                              wid, t, gq);
+        __syncthreads();
+        ln_bwd_part2<C, G, T, NWV>(dx1, xh, rs, STAT, t);
+        // d(x1) = dy + norm2'(d(xn2))  (residual, tulip.py:351); its bf16 copy * s_attn feeds proj' and proj's wgrad
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c0 = 32 * wid + 16 * i + 4 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float4 dy = *(const float4*)(a.dx + rows[g] * C + c0);
+                dx1[i][g] = (f32x4){dx1[i][g][0] + dy.x, dx1[i][g][1] + dy.y, dx1[i][g][2] + dy.z, dx1[i][g][3] + dy.w};
+                const bf16x4 p = pack4(dx1[i][g][0] * s0, dx1[i][g][1] * s0, dx1[i][g][2] * s0, dx1[i][g][3] * s0);
+                *(bf16x4*)(a.dyb_a + rows[g] * C + c0) = p;
+                put4<T>(DY, 16 * g + t, c0, p);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- proj' (tulip.py:318 backwards): dO of this wave's head
+    bf16x4 dop[2][G];
+    {
+        f32x4 acc[2][G];
+        const bf16_t* wrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wrow[i] = a.wprojt + (size_t)(32 * wid + 16 * i + t) * C + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<2, G, KS, 4, T>(acc, wrow, DY, t, gq);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) dop[i][g] = pack4(acc[i][g][0], acc[i][g][1], acc[i][g][2], acc[i][g][3]);
+    }
+    // ---- attention' of this head, one window at a time (tulip.py:300-317 backwards; algebra of attn_bwd_kernel)
+    {
+        unsigned char* ldsQ = smem + Z::OFF_ATT + wid * 3072;
+        unsigned char* ldsK = ldsQ + 1024;
+        unsigned char* ldsD = ldsK + 1024;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int troff = (gq * 4 + (t >> 2)) * 64 + (t & 3) * 8;
+        float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            bf16x4 qkvr[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                qkvr[i] = *(const bf16x4*)(a.qkv + rows[g] * (3 * C) + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
+            const bf16x8 qf = cat8(qkvr[0], qkvr[1]), kf = cat8(qkvr[2], qkvr[3]), vf = cat8(qkvr[4], qkvr[5]);
+            const bf16x8 df = cat8(dop[0][g], dop[1][g]);
+            const int o0 = t * 64 + (4 * gq) * 2, o1 = t * 64 + (16 + 4 * gq) * 2;
+            *(bf16x4*)(ldsQ + o0) = qkvr[0];     *(bf16x4*)(ldsQ + o1) = qkvr[1];
+            *(bf16x4*)(ldsK + o0) = qkvr[2];     *(bf16x4*)(ldsK + o1) = qkvr[3];
+            *(bf16x4*)(ldsD + o0) = dop[0][g];   *(bf16x4*)(ldsD + o1) = dop[1][g];
+            f32x4 sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);    // S[t][4gq+r]
+            f32x4 sk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);    // S[4gq+r][t]
+            f32x4 dpq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df, z, 0, 0, 0);   // dP[t][4gq+r]
+            f32x4 dpk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, z, 0, 0, 0);   // dP[4gq+r][t]
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float xq = sq[r] * a.scale + bias_q[r];
+                float xk = sk[r] * a.scale + bias_k[r];
+                if (a.masked) {
+                    const int ol = __shfl(lab[g], gq * 4 + r, 64);
+                    if (ol != lab[g]) { xq += -100.0f; xk += -100.0f; }
+                }
+                sq[r] = xq; sk[r] = xk;
+                mx = fmaxf(mx, xq);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += __expf(sq[r] - mx);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float lse = mx + __logf(sum);
+            float pq[4], pk[4], delta = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pq[r] = __expf(sq[r] - lse);
+                pk[r] = __expf(sk[r] - __shfl(lse, gq * 4 + r, 64));
+                delta += pq[r] * dpq[r];
+            }
+            delta += __shfl_xor(delta, 16, 64);
+            delta += __shfl_xor(delta, 32, 64);
+            float dsq[4], dsk[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dsq[r] = pq[r] * (dpq[r] - delta);
+                dsk[r] = pk[r] * (dpk[r] - __shfl(delta, gq * 4 + r, 64));
+                bsum[r] += dsq[r];
+            }
+            const bf16x4 dsq_b = pack4(dsq[0], dsq[1], dsq[2], dsq[3]);
+            const bf16x4 dsk_b = pack4(dsk[0], dsk[1], dsk[2], dsk[3]);
+            const bf16x4 pk_b = pack4(pk[0], pk[1], pk[2], pk[3]);
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc) {
+                const bf16x4 kt = trr(ldsK + troff + dc * 32);     // K[4gq+e][16dc+t]
+                const bf16x4 qt = trr(ldsQ + troff + dc * 32);
+                const bf16x4 dt = trr(ldsD + troff + dc * 32);
+                const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, dsq_b, z, 0, 0, 0);   // dQ[t][16dc+4gq+r] / scale
+                const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt, dsk_b, z, 0, 0, 0);
+                const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt, pk_b, z, 0, 0, 0);
+                const bf16x4 o[3] = {pack4(dq[0] * a.scale, dq[1] * a.scale, dq[2] * a.scale, dq[3] * a.scale),
+                                     pack4(dk[0] * a.scale, dk[1] * a.scale, dk[2] * a.scale, dk[3] * a.scale),
+                                     pack4(dv[0], dv[1], dv[2], dv[3])};
+#pragma unroll
+                for (int sec = 0; sec < 3; ++sec) {
+                    const int n = sec * C + 32 * wid + 16 * dc + 4 * gq;
+                    *(bf16x4*)(a.dqkv + rows[g] * (3 * C) + n) = o[sec];
+                    put4<T>(DQ, 16 * g + t, n, o[sec]);
+                }
+            }
+        }
+        // dense relative-position-bias gradient of this head, summed over the workgroup's windows: [NH][16 q][16 k]
+        *(float4*)(a.biaspart + (size_t)blockIdx.x * (NH * 256) + wid * 256 + t * 16 + gq * 4) =
+            make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+    }
+    __syncthreads();
+
+    // ---- qkv' (tulip.py:298 backwards), norm1' and the residual
+    {
+        f32x4 acc[2][G], xh[2][G];
+        float rs[G];
+        const bf16_t* wrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wrow[i] = a.wqkvt + (size_t)(32 * wid + 16 * i + t) * (3 * C) + 8 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        wave_gemm<2, G, 3 * KS, 4, T>(acc, wrow, DQ, t, gq);
+        ln_bwd_part1<C, G, T>(acc, xh, a.xin, a.mean1, a.rstd1, a.g1, rows, rs, a.lnpart1 + (size_t)blockIdx.x * 2 * C, STAT,
+                              wid, t, gq);
+        __syncthreads();
+        ln_bwd_part2<C, G, T, NWV>(acc, xh, rs, STAT, t);
+        const float cs = a.dx_scale ? a.dx_scale[tm.b] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c0 = 32 * wid + 16 * i + 4 * gq;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 o = dx1[i][g] + acc[i][g];
+                *(float4*)(a.dx + rows[g] * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (a.dx_bf16) *(bf16x4*)(a.dx_bf16 + rows[g] * C + c0) = pack4(o[0] * cs, o[1] * cs, o[2] * cs, o[3] * cs);
+            }
+        }
+    }
+}
+
+template <int C, int G>
+int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
+    const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
+    hipLaunchKernelGGL((swinw_bwd_kernel<C, G>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+__host__ __device__ inline bool wide_g4(int C, int B, int H, int W) {
+    // windows per workgroup: 4 once that still gives every CU a workgroup, else 2 (every TULIP grid has W % 16 == 0)
+    return C == 192 && (W % 32 == 0) && (B * (H / 2) * (W / 8)) / 4 >= 256;
+}
+
+// ---- dst[c][r] = src[r][c] for a list of bf16 matrices (the transposed weight copies the backward streams)
+struct TrItem { const bf16_t* src; bf16_t* dst; int rows, cols, first; };
+struct TrList { TrItem it[TULIP_TRANSPOSE_MAX]; int n; };
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const TrList L) {
+    __shared__ bf16_t tile[64][66];
+    int i = 0;
+    while (i + 1 < L.n && (int)blockIdx.x >= L.it[i + 1].first) ++i;
+    const TrItem& m = L.it[i];
+    const int tc = (m.cols + 63) / 64;
+    const int b = blockIdx.x - m.first, r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+        const int r = e >> 3, c8 = (e & 7) * 8;
+        if (r0 + r < m.rows && c0 + c8 < m.cols) {
+            const uint4 v = *(const uint4*)(m.src + (size_t)(r0 + r) * m.cols + c0 + c8);
+            const bf16_t* pv = (const bf16_t*)&v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tile[r][c8 + k] = pv[k];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+        const int c = e >> 3, r8 = (e & 7) * 8;
+        if (c0 + c < m.cols && r0 + r8 < m.rows) {
+            bf16_t o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = tile[r8 + k][c];
+            *(uint4*)(m.dst + (size_t)(c0 + c) * m.rows + r0 + r8) = *(const uint4*)o;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tulip_swinw_supported(int C, int H, int W) {
+    return (C == 192 || C == 384) && H > 0 && !(H & 1) && W > 0 && !(W & 15);
+}
+
+extern "C" int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hipStream_t stream) {
+    if (!d || d->B <= 0 || !tulip_swinw_supported(C, d->H, d->W) || d->shift_h < 0 || d->shift_h >= d->H ||
+        d->shift_w < 0 || d->shift_w >= d->W)
+        return TULIP_ERR_ARG;
+    SwinWArgs a;
+    a.xin = d->x_in; a.x1 = d->x1; a.xout = d->x_out;
+    a.xn1 = (bf16_t*)d->xn1; a.qkv = (bf16_t*)d->qkv; a.o = (bf16_t*)d->attn_out; a.xn2 = (bf16_t*)d->xn2;
+    a.h = (bf16_t*)d->fc1_pre; a.g = (bf16_t*)d->fc1_act;
+    a.mean1 = d->mean1; a.rstd1 = d->rstd1; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
+    a.wqkv = (const bf16_t*)d->w_qkv; a.wproj = (const bf16_t*)d->w_proj; a.w1 = (const bf16_t*)d->w_fc1;
+    a.w2 = (const bf16_t*)d->w_fc2;
+    a.bqkv = d->b_qkv; a.bproj = d->b_proj; a.b1 = d->b_fc1; a.b2 = d->b_fc2;
+    a.g1 = d->norm1_weight; a.be1 = d->norm1_bias; a.g2 = d->norm2_weight; a.be2 = d->norm2_bias;
+    a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
+    a.out_bf16 = (bf16_t*)out_bf16;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
+    a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
+    if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_fwd<192, 4>(a, stream) : launch_fwd<192, 2>(a, stream);
+    return launch_fwd<384, 2>(a, stream);
+}
+
+extern "C" int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W) {
+    if (B <= 0 || !tulip_swinw_supported(C, H, W)) return 0;
+    return B * (H / 2) * (W / (8 * (wide_g4(C, B, H, W) ? 4 : 2)));
+}
+
+extern "C" int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream) {
+    if (!d || d->B <= 0 || !tulip_swinw_supported(C, d->H, d->W) || d->shift_h < 0 || d->shift_h >= d->H ||
+        d->shift_w < 0 || d->shift_w >= d->W)
+        return TULIP_ERR_ARG;
+    SwinWBwdArgs a;
+    a.dx = d->dx; a.xin = d->x_in; a.x1 = d->x1;
+    a.qkv = (const bf16_t*)d->qkv; a.h = (const bf16_t*)d->fc1_pre;
+    a.mean1 = d->mean1; a.rstd1 = d->rstd1; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
+    a.wqkvt = (const bf16_t*)d->w_qkv; a.wprojt = (const bf16_t*)d->w_proj; a.w1t = (const bf16_t*)d->w_fc1;
+    a.w2t = (const bf16_t*)d->w_fc2;
+    a.g1 = d->norm1_weight; a.g2 = d->norm2_weight;
+    a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
+    a.dyb_m = (bf16_t*)d->d_out_mlp; a.dh = (bf16_t*)d->d_fc1_pre; a.dyb_a = (bf16_t*)d->d_out_attn;
+    a.dqkv = (bf16_t*)d->d_qkv;
+    a.dx_bf16 = (bf16_t*)d->dx_bf16; a.dx_scale = d->dx_bf16_scale;
+    a.lnpart1 = d->norm1_partials; a.lnpart2 = d->norm2_partials; a.biaspart = d->bias_partials;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
+    a.scale = 0.17677669529663687f;
+    if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_bwd<192, 4>(a, stream) : launch_bwd<192, 2>(a, stream);
+    return launch_bwd<384, 2>(a, stream);
+}
+
+extern "C" int tulip_transpose_bf16_multi(const tulip_transpose_item* items, int n, hipStream_t stream) {
+    if (n < 0 || n > TULIP_TRANSPOSE_MAX || (n && !items)) return TULIP_ERR_ARG;
+    TrList L;
+    L.n = 0;
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+        const tulip_transpose_item& it = items[i];
+        if (it.rows <= 0 || it.cols <= 0) continue;
+        if (!it.src || !it.dst || (it.rows & 7) || (it.cols & 7)) return TULIP_ERR_ARG;
+        L.it[L.n++] = TrItem{(const bf16_t*)it.src, (bf16_t*)it.dst, it.rows, it.cols, first};
+        first += ((it.rows + 63) / 64) * ((it.cols + 63) / 64);
+    }
+    if (L.n == 0) return TULIP_OK;
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(first), dim3(256), 0, stream, L);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}

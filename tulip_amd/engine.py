@@ -151,7 +151,28 @@ class FlatParams:
 
     def refresh_shadow(self):
         ops.cast_flat(self.flat, self.shadow, self.total)
+        self.refresh_transposes()
         self.shadow_dirty = False
+
+    def make_transposes(self, names: List[str]):
+        """bf16 TRANSPOSED copies of the given 2-D weights (the fused wide-block backward streams rows of W^T,
+        csrc/swinw.hip); refreshed from the shadow by refresh_transposes()."""
+        self.t_offset: Dict[str, int] = {}
+        off = 0
+        for n in names:
+            self.t_offset[n] = off
+            off = _ceil(off + self.numel[n], ALIGN)
+        self.shadow_t = torch.zeros(max(off, ALIGN), dtype=torch.bfloat16, device=self.device)
+        self.base16t = self.shadow_t.data_ptr()
+        pairs = [(self.p16(n), self.base16t + 2 * self.t_offset[n], self.shape[n][0], self.shape[n][1]) for n in names]
+        self._tr_items, self._tr_n = ops.transpose_items(pairs)
+
+    def p16t(self, name: str) -> int:
+        return self.base16t + 2 * self.t_offset[name]
+
+    def refresh_transposes(self):
+        if getattr(self, "_tr_n", 0):
+            ops.transpose_bf16_multi(self._tr_items, self._tr_n)
 
 
 class Plan:
@@ -335,6 +356,9 @@ class TulipEngine:
         self.plans.clear()
         self._graphs.clear()
         self.params = FlatParams(self.model, device)
+        self.params.make_transposes([sp.prefix + suffix for sp in self.blocks if self._fusable_wide(sp)
+                                     for suffix in (".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight",
+                                                    ".mlp.fc2.weight")] if self.fuse_wide_bwd else [])
         rel = self.model.layers[0].blocks[0].attn.relative_position_index
         self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
         rates = torch.ones(max(1, self.n_drop_slots), 1)
@@ -391,15 +415,29 @@ class TulipEngine:
         return (sp.C == 96 and sp.nh == 3 and self.hidden(sp.C) == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
                 and sp.H % 2 == 0)
 
+    fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
+    fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
+    wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192,384").split(",") if c)
+
+    def _fusable_wide(self, sp: BlockSpec) -> bool:
+        """csrc/swinw.hip covers C = 192 / 384: heads of 32, window 2x8, MLP C -> 4C -> C."""
+        return (sp.C in self.wide_widths and sp.C in (192, 384) and sp.nh * 32 == sp.C and self.hidden(sp.C) == 4 * sp.C
+                and tuple(sp.win) == (2, 8) and sp.W % 16 == 0 and sp.H % 2 == 0)
+
+    def _fused_bwd(self, sp: BlockSpec) -> bool:
+        return (self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp))
+
     def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout, out_bf16=None):
         """out_bf16: the block output also leaves as a bf16 [M][C] copy (operand of a PatchUnmerging GEMM)."""
         W_ = self.params
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
-        if self.fuse_block96 and self._fusable96(sp):
-            # stage 0: the whole block in one launch (csrc/swin96.hip); writes the same tensors as the sequence below
-            ops.swin96_block_fwd(
+        wide = self.fuse_wide and self._fusable_wide(sp)
+        if wide or (self.fuse_block96 and self._fusable96(sp)):
+            # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
+            launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
+            launch(
                 x_in=xin, x1=P[p + ".x1"], x_out=xout, xn1=P[p + ".xn1"], qkv=P[p + ".qkv"], attn_out=P[p + ".o"],
                 xn2=P[p + ".xn2"], fc1_pre=P[p + ".h"], fc1_act=P[p + ".g"], mean1=P[p + ".mean1"],
                 rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
@@ -412,7 +450,7 @@ class TulipEngine:
                 bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=B, H=sp.H, W=sp.W,
                 shift_h=sp.sft[0], shift_w=sp.sft[1], masked=int(sp.shift), eps=self.eps)
-            if out_bf16 is not None:
+            if out_bf16 is not None and not wide:
                 ops.cast_f32_bf16(xout, out_bf16, M, C)
             return
         ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
@@ -724,7 +762,7 @@ class TulipEngine:
 
     def _mlp_cast(self, P: Plan, sp: BlockSpec):
         """What the producer of this block's incoming gradient should emit: (dyb_m, DropPath scale, tokens)."""
-        if self.fuse_block96_bwd and self._fusable96(sp):
+        if self._fused_bwd(sp):
             return None                     # the fused block backward forms its own operand from the fp32 gradient
         return (P[sp.prefix + ".dyb_m"], self._ds(P, sp, 1), sp.H * sp.W)
 
@@ -738,20 +776,24 @@ class TulipEngine:
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
         dxn, dO, dh, dqkv = P["t.dxn"], P["t.do"], P[p + ".dh"], P[p + ".dqkv"]
         dyb = P[p + ".dyb_m"]
-        if self._fusable96(sp) and self.fuse_block96_bwd:
-            # the whole data-gradient chain of the block in one launch (csrc/swin96.hip); the weight gradients and the
-            # folds of its per-workgroup partial rows run beside the chain exactly as for the unfused sequence
+        if self._fused_bwd(sp):
+            # the whole data-gradient chain of the block in one launch (csrc/swin96.hip, csrc/swinw.hip); the weight
+            # gradients and the folds of its per-workgroup partial rows run beside the chain exactly as for the unfused
+            # sequence
+            wide = not (self.fuse_block96_bwd and self._fusable96(sp))
             cb, cs, ct = next_cast if next_cast is not None else (None, None, tok)
             if cs is not None and ct != tok:
                 raise ValueError("fused block backward: the cast scale must be per sample")
-            R = ops.swin96_bwd_partial_rows(B, sp.H, sp.W)
+            R = ops.swinw_bwd_partial_rows(C, B, sp.H, sp.W) if wide else ops.swin96_bwd_partial_rows(B, sp.H, sp.W)
             ln1, ln2 = P.scratch("lnp." + p + ".1", R * 2 * C), P.scratch("lnp." + p + ".2", R * 2 * C)
             apart = P.scratch("apart." + p, R * nh * 256)
-            ops.swin96_block_bwd(
+            launch = (lambda **kw: ops.swinw_block_bwd(C, **kw)) if wide else ops.swin96_block_bwd
+            wt = W_.p16t if wide else W_.p16          # the wide kernel streams rows of the TRANSPOSED weights
+            launch(
                 dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=P[p + ".qkv"], fc1_pre=P[p + ".h"], mean1=P[p + ".mean1"],
                 rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
-                w_qkv=W_.p16(p + ".attn.qkv.weight"), w_proj=W_.p16(p + ".attn.proj.weight"),
-                w_fc1=W_.p16(p + ".mlp.fc1.weight"), w_fc2=W_.p16(p + ".mlp.fc2.weight"),
+                w_qkv=wt(p + ".attn.qkv.weight"), w_proj=wt(p + ".attn.proj.weight"),
+                w_fc1=wt(p + ".mlp.fc1.weight"), w_fc2=wt(p + ".mlp.fc2.weight"),
                 norm1_weight=W_.p32(p + ".norm1.weight"), norm2_weight=W_.p32(p + ".norm2.weight"),
                 bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), d_out_mlp=dyb, d_fc1_pre=dh,

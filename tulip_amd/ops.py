@@ -291,6 +291,48 @@ def swin96_block_fwd(**kw):
     check(_lib.load().tulip_swin96_block_fwd(ctypes.byref(d), _stream()), "tulip_swin96_block_fwd")
 
 
+def swinw_supported(C, H, W) -> bool:
+    return bool(_lib.load().tulip_swinw_supported(C, H, W))
+
+
+def swinw_block_fwd(C, out_bf16=None, **kw):
+    """tulip_swinw_block_fwd (C = 192 / 384): keyword arguments are the fields of tulip_swin96_desc."""
+    d = _lib.Swin96Desc()
+    for name, _t in _lib.Swin96Desc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    check(_lib.load().tulip_swinw_block_fwd(ctypes.byref(d), C, _p(out_bf16), _stream()), "tulip_swinw_block_fwd")
+
+
+def swinw_bwd_partial_rows(C, B, H, W) -> int:
+    return _lib.load().tulip_swinw_bwd_partial_rows(C, B, H, W)
+
+
+def swinw_block_bwd(C, **kw):
+    """tulip_swinw_block_bwd: fields of tulip_swin96_bwd_desc; w_* are the TRANSPOSED bf16 weights."""
+    d = _lib.Swin96BwdDesc()
+    for name, _t in _lib.Swin96BwdDesc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    check(_lib.load().tulip_swinw_block_bwd(ctypes.byref(d), C, _stream()), "tulip_swinw_block_bwd")
+
+
+def transpose_items(pairs):
+    """[(src address, dst address, rows, cols)] -> ctypes array for transpose_bf16_multi (build once, launch often)."""
+    return (_lib.TransposeItem * max(len(pairs), 1))(*[_lib.TransposeItem(_p(s), _p(d), r, c) for s, d, r, c in pairs]), len(pairs)
+
+
+def transpose_bf16_multi(items, n):
+    for k in range(0, n, _lib.TRANSPOSE_MAX):
+        cnt = min(_lib.TRANSPOSE_MAX, n - k)
+        check(_lib.load().tulip_transpose_bf16_multi(ctypes.byref(items, k * ctypes.sizeof(_lib.TransposeItem)), cnt,
+                                                     _stream()), "tulip_transpose_bf16_multi")
+
+
 def swin96_bwd_partial_rows(B, H, W) -> int:
     return _lib.load().tulip_swin96_bwd_partial_rows(B, H, W)
 

@@ -138,6 +138,7 @@ class Trainer:
     def _finish_buckets(self):
         if self.bucket_adamw:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self.eng.params.refresh_transposes()
         else:
             self.bucketer.wait_all()
             self._adamw()
@@ -148,6 +149,7 @@ class Trainer:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
         ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=True)
+        W.refresh_transposes()
 
     # ------------------------------------------------------------------ checkpoint (misc.save_model / load_model keep
     # {'model', 'optimizer', 'epoch', ...}: this is the 'optimizer' entry of the fused AdamW)
