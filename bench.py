@@ -264,6 +264,39 @@ def cpu_baseline(args):
             "fp32 eager PyTorch oracle, same model/config/optimizer"}
 
 
+def comm_report(trainer, args, world, device, steps=10):
+    """N > 1, after the timed region: what the gradient exchange costs beyond the cuts it needs.  The same step
+    structure (graph segments at the bucket points) is timed again with the collectives skipped (every rank then applies
+    its own gradients: the replicas diverge, which no longer matters here); exposed = step - that.  Also the bucket plan
+    and the RCCL settings in force, for the record."""
+    def timed():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item() / steps * 1e3
+    with_coll = timed()
+    trainer.bucketer.dry = True
+    trainer.step()
+    without = timed()
+    trainer.bucketer.dry = False
+    el = 2 if trainer.grad_dtype == "bf16" else 4
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        ver = "unknown"
+    return {"buckets_MB": [round((b - a) * el / 1e6, 2) for _, a, b in trainer.bucketer.buckets],
+            "bucket_tags": [t for t, _, _ in trainer.bucketer.buckets], "grad_dtype": trainer.grad_dtype,
+            "per_bucket_adamw": trainer.bucket_adamw, "step_ms": round(with_coll, 4),
+            "step_ms_collectives_skipped": round(without, 4), "exposed_exchange_ms": round(with_coll - without, 4),
+            "rccl_version": ver,
+            "env": {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO",
+                                                   "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ}}
+
+
 def secondary_batch64(args, device, steps=20, warmup=5):
     """BASELINE.json configs[4] without its fp8 leg: the same step at per-GPU batch 64, where the kernels rather than
     the launch chain set the pace (secondary metric; bf16 operands like the headline)."""
@@ -302,6 +335,9 @@ def main():
     ap.add_argument("--img", type=int, nargs=2, default=[16, 1024])
     ap.add_argument("--target", type=int, nargs=2, default=[64, 1024])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient all-reduce (N>1): fp32 = DistributedDataParallel's exchange")
+    ap.add_argument("--bucket-mb", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -326,7 +362,7 @@ def main():
     from tulip_amd.trainer import Trainer
     model = make_model(args).to(device).train()
     trainer = Trainer(model, args.batch, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, device=device,
-                      use_graph=not args.no_graph)
+                      use_graph=not args.no_graph, grad_dtype=args.grad_dtype, bucket_mb=args.bucket_mb)
     lo, hi = synthetic(args, rank, device)
     trainer.load_batch(lo, hi)
 
@@ -379,6 +415,8 @@ def main():
     out["tolerance"] = ("index ops bit-exact; loss within 1e-3 rel of the reference's fp32 forward; prediction inside the "
                         "reference's own bf16-autocast band (max 8e-3 abs); gradients <= 1.5e-2 rel L2 per tensor "
                         "(tests/test_model_gpu.py)")
+    if world > 1:
+        out["comm"] = comm_report(trainer, args, world, device)
     if rank == 0 and world == 1 and not args.no_secondary and args.batch == 8 and args.model == "tulip_base":
         out["secondary"] = secondary_batch64(args, device)
     if rank == 0 and world == 1 and not args.no_roofline:

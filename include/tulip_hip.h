@@ -35,7 +35,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define TULIP_EPI_F32 3          /* out_f32 (+)= acc + bias                                             */
 #define TULIP_EPI_RESID_F32 4    /* out_f32 = aux_f32 + rowscale[m/rows_per_sample]*(acc+bias) (tulip.py:343-344,350-351) */
 #define TULIP_EPI_PIXSHUF2_F32 5 /* PatchUnmerging scatter: PixelShuffle(2) + BCHW->BHWC (tulip.py:120-122) */
-#define TULIP_EPI_ATOMIC_F32 6   /* out_f32 += acc (split-K weight gradients, atomics)                  */
+/* (6: retired) */
 #define TULIP_EPI_SPLIT_F32 7    /* out_f32[split][M][ldo] = acc : split-K partial slabs (deterministic) */
 #define TULIP_EPI_UNSHUF2_BF16 8 /* inverse of 5, bf16: row m = fine token (b,2h+i,2w+j), column c -> out[(b,h,w)][4c+2i+j]
                                     with psH, psW = the COARSE grid, N = fine channels (backward of PixelShuffle(2)) */
@@ -48,7 +48,7 @@ typedef struct ihipStream_t* hipStream_t;
  * Replaces nn.Linear / 1x1 nn.Conv2d forward (tulip.py:298,318,195,198,105,119,716,175) and their
  * autograd dgrad/wgrad.  Requirements: K%8==0, N%8==0, lda%8==0, ldb%8==0 (and M%8 / N%8 for the
  * transposed operands).  splits>1: the K range is cut across workgroups (for launches too small to fill 256
- * CUs).  With TULIP_EPI_SPLIT_F32 / TULIP_EPI_ATOMIC_F32 the raw partials go to `out`; with any other epilogue
+ * CUs).  With TULIP_EPI_SPLIT_F32 the raw partials go to `out`; with any other epilogue
  * the partial slabs go to `workspace` (>= effective_splits*M*N*4 bytes) and a second kernel folds them and
  * applies the epilogue.  workspace may be NULL when splits == 1.
  * Weight-gradient form (a_trans=1, epi SPLIT_F32 or F32): if out2 != NULL it additionally receives
@@ -62,7 +62,7 @@ int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb,
 /* Up to TULIP_REDUCE_REGIONS_MAX row reductions in one launch:  out[i] (+)= sum_{s<rows} partials[s*stride + i],
  * i < n (n, stride multiples of 4).  With scatter_index != NULL the region is the dense [scatter_nh][scatter_len]
  * relative-position-bias gradient and its sums are added to out[scatter_index[ij]*scatter_nh + h] instead
- * (tulip.py:304-308 backwards; replaces tulip_reduce_rows_set + tulip_bias_table_scatter). */
+ * (tulip.py:304-308 backwards; one launch, deterministic: no atomics). */
 #define TULIP_REDUCE_REGIONS_MAX 16
 typedef struct tulip_reduce_region {
     const float* partials; float* out;
@@ -97,8 +97,6 @@ int tulip_gemm_effective_splits(int K, int splits);
  * n, stride multiples of 4; a region with n<=0 is skipped. */
 int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
                        int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream);
-/* out[i] = sum over the partial rows (overwrites: no zero-fill of `out` needed) */
-int tulip_reduce_rows_set(const float* part, int64_t stride, float* out, int64_t n, int nrows, hipStream_t stream);
 /* out[i] += sum_s slabs[s*n + i]  (= tulip_reduce_rows2 with one region of stride n) */
 int tulip_reduce_splits(const float* slabs, float* out, int64_t n, int splits, hipStream_t stream);
 
@@ -152,30 +150,19 @@ int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_table, const in
                           int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream);
 /* dqkv from dout.  d(bias) leaves as R = tulip_window_attn_bwd_partial_rows(...) partial rows per head:
  * dbias_partials[(j*nh + h)*256 + i*16 + k], j < R  ==  a [R][nh*256] matrix whose column sums are the dense
- * [nh][16][16] gradient (fold with tulip_reduce_rows2, then tulip_bias_table_scatter). */
+ * [nh][16][16] gradient (fold + scatter into the table: tulip_reduce_rows_multi with scatter_index). */
 int tulip_window_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* bias_table, const int32_t* rel_index,
                           uint16_t* dqkv, float* dbias_partials, int B, int H, int W, int C, int nh, int wh, int ww,
                           int sh, int sw, int masked, hipStream_t stream);
 int tulip_window_attn_bwd_partial_rows(int B, int H, int W, int nh, int wh, int ww);
-/* dtable[rel_index[i][j]][h] += dbias_dense[h][i][j]  (tulip.py:304-308 backward) */
-int tulip_bias_table_scatter(const float* dbias_dense, const int32_t* rel_index, float* dtable, int nh, int L,
-                             hipStream_t stream);
 
 /* y_bf16 = bf16(x * rowscale[row/rows_per_sample]) ; rowscale may be NULL. x is [rows][cols]. */
 int tulip_cast_f32_bf16(const float* x, uint16_t* y, int rows, int cols, const float* rowscale, int rows_per_sample,
                         hipStream_t stream);
-/* out[r] = bf16(concat(a[r], b[r]))  -- skip connection input, tulip.py:715 */
-int tulip_concat_cast(const float* a, const float* b, uint16_t* out, int rows, int C, hipStream_t stream);
-/* inverse of the PatchUnmerging scatter: dz[(b,h,w)][4c+2i+j] = bf16(dx[b,2h+i,2w+j,c]); dx is (B,2H,2W,C2) */
-int tulip_unshuffle2_cast(const float* dx, uint16_t* dz, int B, int H, int W, int C2, hipStream_t stream);
-/* y = bf16(x*rowscale) as tulip_cast_f32_bf16 AND colsum[c] += sum_rows x[r][c]*rowscale  (bias gradient of
- * the residual-branch Linears: the cast of the stream gradient and its column sum in one pass) */
-int tulip_cast_colsum(const float* x, uint16_t* y, float* colsum, int rows, int cols, const float* rowscale,
-                      int rows_per_sample, hipStream_t stream);
-/* out[c] += sum_rows x[r][c]   (bias gradients) */
-int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream);
 /* flat fp32 -> bf16 copy (weight shadow refresh) */
 int tulip_cast_flat(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
+/* flat bf16 -> fp32 copy (gradients all-reduced in bf16 come back into the fp32 gradient buffer of the optimizer) */
+int tulip_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, hipStream_t stream);
 
 /* Fused head (tulip.py:724-731): conv1x1 E->16E (+bias), LeakyReLU(0.01), PixelShuffle(4),
  * conv1x1 E->1 (no bias); xn is norm_up's bf16 output [B*H*W][E]; pred is (B,1,4H,4W) fp32.  The
@@ -341,7 +328,7 @@ int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream);
  * [M][96], d_fc1_pre [M][384], d_out_attn = bf16(d(x1)*s_attn) [M][96], d_qkv [M][288] -- and ONE partial row per
  * workgroup (tulip_swin96_bwd_partial_rows of them) for each of: norm1 / norm2 affine gradients ([rows][192] =
  * d(weight) | d(bias), folded by tulip_reduce_rows2) and the dense relative-position-bias gradient ([rows][3*256],
- * folded by tulip_reduce_rows_set + tulip_bias_table_scatter).  dx_bf16 (optional): bf16(dx * dx_bf16_scale[sample]). */
+ * folded and scattered by tulip_reduce_rows_multi).  dx_bf16 (optional): bf16(dx * dx_bf16_scale[sample]). */
 typedef struct tulip_swin96_bwd_desc {
     float* dx; const float* x_in; const float* x1;
     const void* qkv; const void* fc1_pre;
@@ -363,16 +350,24 @@ int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream);
  * operand registers, activations pass through LDS (csrc/swinw.hip).  Descriptors, saved tensors and partial rows are
  * those of the C = 96 entry points with 96 -> C, 288 -> 3C, 384 -> 4C, 3*256 -> (C/32)*256 and partial rows of
  * [d(weight)[C] | d(bias)[C]].  out_bf16 (optional): bf16 copy of the block output [M][C].
- * The BACKWARD streams rows of W^T: in its descriptor w_qkv / w_proj / w_fc1 / w_fc2 point to TRANSPOSED bf16 copies
- * ([C][3C], [C][C], [C][4C], [4C][C]) which tulip_transpose_bf16_multi writes (dst[c][r] = src[r][c]; rows, cols
- * multiples of 8; up to TULIP_TRANSPOSE_MAX matrices per launch). */
-#define TULIP_TRANSPOSE_MAX 32
-typedef struct tulip_transpose_item { const void* src; void* dst; int rows; int cols; } tulip_transpose_item;
+ * WEIGHTS are read in fragment-major ("packed") order, written by tulip_pack_bf16_multi: the 16 x 32 block (rows 16 nt..,
+ * columns 32 ks..) of a [N][K] matrix is the 1-KiB block nt*K/32 + ks, and inside it element (n, k) sits at
+ * ((n%16) + 16*((k%32)/8))*8 + k%8 -- one MFMA A operand = one contiguous 1-KiB wave load (4x the L2 -> register rate
+ * of row-major fragments on this chip).  Forward: w_qkv / w_proj / w_fc1 / w_fc2 = packed copies of the weights as
+ * they are ([3C][C], [C][C], [4C][C], [C][4C]); backward: packed copies of their TRANSPOSES (item.transpose = 1).
+ * rows % 16 == 0 and cols % 32 == 0 of the matrix being packed (after the transpose, if any); up to TULIP_PACK_MAX
+ * matrices per launch. */
+#define TULIP_PACK_MAX 32
+typedef struct tulip_pack_item { const void* src; void* dst; int rows; int cols; int transpose; } tulip_pack_item;
 int tulip_swinw_supported(int C, int H, int W);
 int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hipStream_t stream);
+/* diagnostic twin of tulip_swinw_block_fwd: stamps[(workgroup * waves + wave) * 16 + k] = s_memtime (shader clock) at
+ * phase boundary k of every wave (waves = C/32; workgroups = tulip_swinw_bwd_partial_rows); tools/swinw_phases.py */
+int tulip_swinw_block_fwd_profiled(const tulip_swin96_desc* d, int C, void* out_bf16, uint64_t* stamps,
+                                   hipStream_t stream);
 int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W);
 int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream);
-int tulip_transpose_bf16_multi(const tulip_transpose_item* items, int n, hipStream_t stream);
+int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream);
 
 /* library self-description */
 int tulip_abi_version(void);

@@ -25,9 +25,12 @@ def main():
     cfg = O.tiny_config()                                   # DropPath on: the counter-based draws replay identically
     sd = O.key_seeded_state_dict(cfg, seed=3)
     lo, hi = O.synthetic_batch(cfg, 4, seed=77)
-    res = {}
+    res = {"init": Trainer(build(cfg, sd, train=True), 4, use_graph=False).eng.params.flat.cpu()}
     for name, kw in [("plain", dict()), ("segments", dict(force_segments=True, bucket_mb=0.05)),
                      ("segments_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, bucket_adamw=True)),
+                     ("segments_bf16", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16")),
+                     ("segments_bf16_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16",
+                                                         bucket_adamw=True)),
                      ("eager_plain", dict(use_graph=False)),
                      ("eager_segments", dict(force_segments=True, bucket_mb=0.05, use_graph=False))]:
         torch.manual_seed(11)
@@ -40,7 +43,7 @@ def main():
                      "segments": len(tr._segments[True]) if tr.use_graph else 0, "buckets": len(tr.bucketer.buckets),
                      "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw}
     from tests.conftest import describe_flat_diff
-    for name in res:
+    for name in [k for k in res if k != "init"]:
         ref = res["eager_plain"] if name.startswith("eager") else res["plain"]
         res[name]["diff"] = describe_flat_diff(tr.eng, res[name]["flat"], ref["flat"])
     res["backend"] = dist.get_backend()

@@ -25,6 +25,16 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
     assert got["backend"] == "nccl"
     plain = got["plain"]
     assert not plain["segmented"] and plain["segments"] == 1
+    # gradients exchanged in bf16 (Trainer(grad_dtype="bf16")): same structure, the update differs by the rounding of
+    # the exchanged gradients only
+    u_ref = plain["flat"] - got["init"]
+    for name in ("segments_bf16", "segments_bf16_bucket_adamw"):
+        g = got[name]
+        u = g["flat"] - got["init"]
+        rel = ((u - u_ref).norm() / u_ref.norm()).item()
+        print(f"{name}: update-vector relative L2 difference to the fp32 exchange {rel:.3e}")
+        assert g["segmented"] and 0 < rel <= 3e-2, (name, rel)
+        assert (g["losses"][-1, 0] - plain["losses"][-1, 0]).abs().item() <= 2e-2 * plain["losses"][-1, 0].item()
     for name in ("segments", "segments_bucket_adamw", "eager_segments"):
         g = got[name]
         assert g["segmented"] and g["buckets"] >= 2

@@ -23,6 +23,7 @@ def _model(seed):
             if p.ndim == 1 or "relative_position_bias_table" in n:
                 p.add_(0.2 * torch.randn_like(p))
     eng = m.engine()
+    eng.wide_widths = (192, 384)                              # both widths of the fused kernel (384 is opt-in in the engine)
     eng.bind(torch.device(DEV, torch.cuda.current_device()))
     eng.params.refresh_shadow()
     return m, eng
@@ -154,13 +155,24 @@ def test_wide_block_backward(stage, shifted, B):
         assert rel <= (1e-1 if "bias_table" in n else 1.5e-2), (n, rel)
 
 
-def test_transpose_multi():
+def test_pack_multi():
+    """tulip_pack_bf16_multi: fragment-major copies of weights and of their transposes (include/tulip_hip.h)."""
     from tulip_amd import ops
-    shapes = [(576, 192), (192, 192), (768, 192), (192, 768), (1152, 384), (40, 72)]
+
+    def packed(w):                      # [N][K] -> [N/16][K/32][gq 4][t 16][8]
+        N, K = w.shape
+        return w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+    shapes = [(576, 192), (192, 192), (768, 192), (192, 768), (1152, 384), (64, 96)]
     srcs = [torch.randn(r, c, device=DEV).bfloat16() for r, c in shapes]
-    dsts = [torch.zeros(c, r, device=DEV, dtype=torch.bfloat16) for r, c in shapes]
-    items, n = ops.transpose_items([(s, d, r, c) for s, d, (r, c) in zip(srcs, dsts, shapes)])
-    ops.transpose_bf16_multi(items, n)
+    ent, want = [], []
+    for s_, (r, c) in zip(srcs, shapes):
+        d0, d1 = (torch.zeros(r * c, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+        ent.append((s_, d0, r, c, 0)); want.append((d0, packed(s_)))
+        if r % 32 == 0 and c % 16 == 0:
+            ent.append((s_, d1, r, c, 1)); want.append((d1, packed(s_.t().contiguous())))
+    items, n = ops.pack_items(ent)
+    ops.pack_bf16_multi(items, n)
     torch.cuda.synchronize()
-    for s, d in zip(srcs, dsts):
-        assert torch.equal(d, s.t().contiguous())
+    for got, ref in want:
+        assert torch.equal(got, ref)

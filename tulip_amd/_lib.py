@@ -44,12 +44,12 @@ class WgradItem(ctypes.Structure):
                 ("splits", I)]
 
 
-class TransposeItem(ctypes.Structure):
-    """tulip_transpose_item (include/tulip_hip.h)."""
-    _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I)]
+class PackItem(ctypes.Structure):
+    """tulip_pack_item (include/tulip_hip.h)."""
+    _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I), ("transpose", I)]
 
 
-REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, TRANSPOSE_MAX = 16, 4, 32
+REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 16, 4, 32
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -59,9 +59,10 @@ SIGNATURES = {
     "tulip_swin96_bwd_partial_rows": [I, I, I],
     "tulip_swinw_supported": [I, I, I],
     "tulip_swinw_block_fwd": [P, I, P, P],
+    "tulip_swinw_block_fwd_profiled": [P, I, P, P, P],
     "tulip_swinw_bwd_partial_rows": [I, I, I, I],
     "tulip_swinw_block_bwd": [P, I, P],
-    "tulip_transpose_bf16_multi": [P, I, P],
+    "tulip_pack_bf16_multi": [P, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],
@@ -72,19 +73,14 @@ SIGNATURES = {
     "tulip_window_attn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "tulip_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "tulip_window_attn_bwd_partial_rows": [I, I, I, I, I, I],
-    "tulip_bias_table_scatter": [P, P, P, I, I, P],
     "tulip_cast_f32_bf16": [P, P, I, I, P, I, P],
-    "tulip_concat_cast": [P, P, P, I, I, P],
-    "tulip_unshuffle2_cast": [P, P, I, I, I, I, P],
-    "tulip_colsum_bf16": [P, P, I, I, P],
-    "tulip_cast_colsum": [P, P, P, I, I, P, I, P],
     "tulip_reduce_splits": [P, P, L, I, P],
     "tulip_reduce_rows2": [P, L, P, L, P, L, P, L, I, P],
-    "tulip_reduce_rows_set": [P, L, P, L, I, P],
     "tulip_reduce_rows_multi": [P, I, P],
     "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
+    "tulip_cast_bf16_f32": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],
     "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
     "tulip_expand_norm_fwd": [P, P, P, P, I, P, P, P, P, I, I, I, I, I, F, P],
@@ -107,7 +103,7 @@ SIGNATURES = {
     "tulip_build_arch": [],
 }
 
-(EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, EPI_ATOMIC_F32,
+(EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, _EPI_RETIRED_6,
  EPI_SPLIT_F32, EPI_UNSHUF2_BF16) = range(9)
 
 _lib = None

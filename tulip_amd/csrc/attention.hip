@@ -246,14 +246,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void bias_scatter_kernel(const float* __restrict__ dense, const int* __restrict__ rel_index, float* dtable,
-                                    int nh, int LL) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nh * LL) return;
-    const int h = i / LL, ij = i - h * LL;
-    atomicAdd(dtable + rel_index[ij] * nh + h, dense[i]);
-}
-
 bool make_geom(AttnGeom& g, int B, int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked) {
     if (wh * ww != 16 || nh <= 0 || C % nh) return false;
     const int P = C / nh;
@@ -321,16 +313,6 @@ extern "C" int tulip_window_attn_bwd(const uint16_t* qkv, const uint16_t* dout, 
     else
         hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(blocks), dim3(256), 0, stream, qkv, dout, bias_table, rel_index,
                            dqkv, dbias_partials, g, ngrp);
-    TULIP_CHECK_LAUNCH();
-    return TULIP_OK;
-}
-
-extern "C" int tulip_bias_table_scatter(const float* dbias_dense, const int32_t* rel_index, float* dtable, int nh, int L,
-                                        hipStream_t stream) {
-    const int n = nh * L * L;
-    if (n <= 0) return TULIP_OK;
-    hipLaunchKernelGGL(bias_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dbias_dense, rel_index, dtable,
-                       nh, L * L);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

@@ -28,112 +28,16 @@ __global__ __launch_bounds__(256) void cast_flat_kernel(const float* __restrict_
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
 }
 
-// out[r][0:C] = a[r], out[r][C:2C] = b[r]
-__global__ __launch_bounds__(256) void concat_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          bf16_t* __restrict__ out, int64_t n4, int C4) {
+__global__ __launch_bounds__(256) void cast_up_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / (2 * C4);
-        const int c = (int)(i - r * 2 * C4);
-        const float* src = c < C4 ? a + (r * C4 + c) * 4 : b + (r * C4 + (c - C4)) * 4;
-        const float4 v = *(const float4*)src;
-        *(uint2*)(out + i * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        const uint2 a = *(const uint2*)(x + i * 4);
+        *(float4*)(y + i * 4) = make_float4(bf2f((bf16_t)(a.x & 0xffff)), bf2f((bf16_t)(a.x >> 16)),
+                                            bf2f((bf16_t)(a.y & 0xffff)), bf2f((bf16_t)(a.y >> 16)));
     }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = bf2f(x[n4 * 4 + threadIdx.x]);
 }
 
-// dz[(b,h,w)][4c+2i+j] = bf16(dx[b,2h+i,2w+j,c]);  one thread per (token, c): 4 gathers, one 8-byte store
-__global__ __launch_bounds__(256) void unshuffle2_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dz, int B,
-                                                         int H, int W, int C2) {
-    const int64_t n = (int64_t)B * H * W * C2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C2);
-        const int64_t tok = i / C2;
-        const int w = (int)(tok % W);
-        const int64_t t2 = tok / W;
-        const int h = (int)(t2 % H), b = (int)(t2 / H);
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ii = r >> 1, jj = r & 1;
-            v[r] = dx[(((int64_t)b * 2 * H + 2 * h + ii) * (2 * W) + 2 * w + jj) * C2 + c];
-        }
-        *(uint2*)(dz + tok * (4 * C2) + 4 * c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-    }
-}
-
-// Column sums.  thread = one 8-column chunk (tx) x one row lane (ty); each thread keeps UNR
-// independent 16/32-byte loads in flight (the loop is latency-bound otherwise), block-level LDS
-// reduce over the row lanes, one atomicAdd per column per block.
-// F32IN: x is fp32 [rows][cols], optionally scaled per sample, and is ALSO written out as bf16 (the
-// stream-gradient cast feeding the residual-branch dgrad/wgrad GEMMs).
-template <bool F32IN>
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ xin, bf16_t* __restrict__ y, float* out,
-                                                     int rows, int cols, int tpr_log2, int rows_per_block,
-                                                     const float* __restrict__ rowscale, int rows_per_sample) {
-    constexpr int UNR = 4;
-    __shared__ float red[8][256];
-    const int TPR = 1 << tpr_log2;
-    const int tx = threadIdx.x & (TPR - 1), ty = threadIdx.x >> tpr_log2;
-    const int RL = 256 >> tpr_log2;
-    const int c = blockIdx.x * TPR + tx;
-    const int nch = cols >> 3;
-    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < nch) {
-        const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-        for (int rb = r0 + ty; rb < r1; rb += RL * UNR) {
-            if (F32IN) {
-                float4 lo[UNR], hi[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int r = rb + u * RL;
-                    if (r < r1) {
-                        const float* px = (const float*)xin + (size_t)r * cols + c * 8;
-                        lo[u] = *(const float4*)px; hi[u] = *(const float4*)(px + 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int r = rb + u * RL;
-                    if (r < r1) {
-                        const float sc = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
-                        const float v[8] = {lo[u].x * sc, lo[u].y * sc, lo[u].z * sc, lo[u].w * sc,
-                                            hi[u].x * sc, hi[u].y * sc, hi[u].z * sc, hi[u].w * sc};
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) a[i] += v[i];
-                        *(uint4*)(y + (size_t)r * cols + c * 8) =
-                            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                       pack_bf16x2(v[6], v[7]));
-                    }
-                }
-            } else {
-                uint4 v[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int r = rb + u * RL;
-                    v[u] = make_uint4(0, 0, 0, 0);
-                    if (r < r1) v[u] = *(const uint4*)((const bf16_t*)xin + (size_t)r * cols + c * 8);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    a[0] += bf2f((bf16_t)(v[u].x & 0xffff)); a[1] += bf2f((bf16_t)(v[u].x >> 16));
-                    a[2] += bf2f((bf16_t)(v[u].y & 0xffff)); a[3] += bf2f((bf16_t)(v[u].y >> 16));
-                    a[4] += bf2f((bf16_t)(v[u].z & 0xffff)); a[5] += bf2f((bf16_t)(v[u].z >> 16));
-                    a[6] += bf2f((bf16_t)(v[u].w & 0xffff)); a[7] += bf2f((bf16_t)(v[u].w >> 16));
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) red[i][threadIdx.x] = a[i];
-    __syncthreads();
-    if (ty == 0 && c < nch) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float sum = 0.f;
-            for (int k = 0; k < RL; ++k) sum += red[i][(k << tpr_log2) + tx];
-            atomicAdd(out + c * 8 + i, sum);
-        }
-    }
-}
 
 // Deterministic fold of per-workgroup partial rows (no atomics anywhere on this path: on gfx950 a chain
 // of same-address device-scope fp32 atomics costs ~0.1-0.5 us per link, which dominated the first
@@ -230,19 +134,24 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
     if (r.scatter && r.LL == 256) {                   // block-uniform
         // Scatter-add through the relative-position index (several (i,j) pairs share a table entry), deterministic:
         // a workgroup covers exactly one head here (RL = 4: 64 float4 columns = 256 dense values, set by the
-        // launcher); the dense sums go to LDS and one thread per table entry adds its pairs in index order.
+        // launcher); the dense sums and the index go to LDS and one thread per table entry adds its pairs in index
+        // order (LDS broadcast reads: ~1 us).
+        __shared__ int sidx[256];
         __syncthreads();
         if (rl == 0) red[ct] = acc;
+        sidx[threadIdx.x] = r.scatter[threadIdx.x];
         __syncthreads();
-        const int h = blockIdx.x - r.first_block;
+        const int h = blockIdx.x - r.first_block, e = threadIdx.x;
         const float* dense = (const float*)red;
-        for (int e = threadIdx.x; e < 256; e += 256) {
-            float s = 0.f;
-            bool any = false;
-            for (int ij = 0; ij < 256; ++ij)
-                if (r.scatter[ij] == e) { s += dense[ij]; any = true; }
-            if (any) r.out[e * r.nh + h] += s;
+        float s = 0.f;
+        bool any = false;
+#pragma unroll 8
+        for (int ij = 0; ij < 256; ++ij) {
+            const bool mine = sidx[ij] == e;
+            s += mine ? dense[ij] : 0.f;
+            any |= mine;
         }
+        if (any) r.out[e * r.nh + h] += s;
         return;
     }
     if (rl == 0 && col < r.n4) {
@@ -424,58 +333,9 @@ extern "C" int tulip_cast_flat(const float* x, uint16_t* y, int64_t n, hipStream
     return TULIP_OK;
 }
 
-extern "C" int tulip_concat_cast(const float* a, const float* b, uint16_t* out, int rows, int C, hipStream_t stream) {
-    if (rows <= 0 || C <= 0) return TULIP_OK;
-    if (C & 3) return TULIP_ERR_ARG;
-    const int64_t n4 = (int64_t)rows * 2 * C / 4;
-    hipLaunchKernelGGL(concat_cast_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, a, b, out, n4, C / 4);
-    TULIP_CHECK_LAUNCH();
-    return TULIP_OK;
-}
-
-extern "C" int tulip_unshuffle2_cast(const float* dx, uint16_t* dz, int B, int H, int W, int C2, hipStream_t stream) {
-    const int64_t n = (int64_t)B * H * W * C2;
+extern "C" int tulip_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, hipStream_t stream) {
     if (n <= 0) return TULIP_OK;
-    hipLaunchKernelGGL(unshuffle2_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dx, dz, B, H, W, C2);
-    TULIP_CHECK_LAUNCH();
-    return TULIP_OK;
-}
-
-static void colsum_grid(int rows, int cols, int& tpr_log2, dim3& grid, int& rows_per_block) {
-    const int nch = cols >> 3;
-    tpr_log2 = 3;
-    while ((1 << tpr_log2) < nch && tpr_log2 < 6) ++tpr_log2;
-    const int TPR = 1 << tpr_log2;
-    const int gx = (nch + TPR - 1) / TPR;
-    const int RL = 256 >> tpr_log2;
-    int gy = (rows + RL * 4 - 1) / (RL * 4);      // >= one 4-deep unrolled pass per thread
-    if (gy > 2048 / gx) gy = 2048 / gx;
-    if (gy < 1) gy = 1;
-    rows_per_block = (rows + gy - 1) / gy;
-    gy = (rows + rows_per_block - 1) / rows_per_block;
-    grid = dim3(gx, gy);
-}
-
-extern "C" int tulip_colsum_bf16(const uint16_t* x, float* out, int rows, int cols, hipStream_t stream) {
-    if (rows <= 0 || cols <= 0) return TULIP_OK;
-    if (cols & 7) return TULIP_ERR_ARG;
-    int tpr_log2, rpb; dim3 grid;
-    colsum_grid(rows, cols, tpr_log2, grid, rpb);
-    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, stream, (const void*)x, (bf16_t*)nullptr, out, rows,
-                       cols, tpr_log2, rpb, (const float*)nullptr, 1);
-    TULIP_CHECK_LAUNCH();
-    return TULIP_OK;
-}
-
-extern "C" int tulip_cast_colsum(const float* x, uint16_t* y, float* colsum, int rows, int cols, const float* rowscale,
-                                 int rows_per_sample, hipStream_t stream) {
-    if (rows <= 0 || cols <= 0) return TULIP_OK;
-    if (cols & 7) return TULIP_ERR_ARG;
-    if (rowscale && rows_per_sample <= 0) return TULIP_ERR_ARG;
-    int tpr_log2, rpb; dim3 grid;
-    colsum_grid(rows, cols, tpr_log2, grid, rpb);
-    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, stream, (const void*)x, y, colsum, rows, cols, tpr_log2,
-                       rpb, rowscale, rows_per_sample > 0 ? rows_per_sample : 1);
+    hipLaunchKernelGGL(cast_up_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, y, n);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }
@@ -501,11 +361,6 @@ static int reduce_rows_impl(const float* part0, int64_t stride0, float* out0, in
 extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* out0, int64_t n0, const float* part1,
                                   int64_t stride1, float* out1, int64_t n1, int nrows, hipStream_t stream) {
     return reduce_rows_impl(part0, stride0, out0, n0, part1, stride1, out1, n1, nrows, 0, stream);
-}
-
-extern "C" int tulip_reduce_rows_set(const float* part, int64_t stride, float* out, int64_t n, int nrows,
-                                     hipStream_t stream) {
-    return reduce_rows_impl(part, stride, out, n, nullptr, 0, nullptr, 0, nrows, 1, stream);
 }
 
 extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream) {

@@ -18,8 +18,8 @@
 // one row -> 8/16-byte epilogue loads and stores.
 //
 // Epilogues fuse: bias, exact-erf GELU (dual store), GELU backward, residual add with the
-// per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging), fp32 accumulate, and
-// split-K atomic accumulation (wgrad).
+// per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging) and its inverse, fp32 accumulate, and
+// split-K partial slabs (deterministic fold).
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
@@ -282,11 +282,6 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } break;
-        case TULIP_EPI_ATOMIC_F32: {
-            float* o = (float*)p.out + (size_t)m * p.ldo + n;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) atomicAdd(o + r, v[r]);
-        } break;
         default: break;
     }
 }
@@ -525,7 +520,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     if (a_trans && (M & 7)) return TULIP_ERR_ARG;
     if (b_trans && (N & 7)) return TULIP_ERR_ARG;
     if (splits < 1) splits = 1;
-    const bool raw_split = epi == TULIP_EPI_ATOMIC_F32 || epi == TULIP_EPI_SPLIT_F32;
+    const bool raw_split = epi == TULIP_EPI_SPLIT_F32;
     if (splits > 1 && !raw_split) {
         splits = effective_splits(K, splits);
         if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4)) return TULIP_ERR_ARG;

@@ -5,9 +5,9 @@
 // C = 96 design of swin96.hip) is far too serial: stage 1 of a batch of 8 has 512 windows for 1024 SIMDs.  Here a
 // workgroup owns G neighbouring windows (T = 16 G tokens) and has one wave per HEAD (6 / 12 waves); every GEMM of the
 // block is split along its OUTPUT channels across the waves:
-//   * weights never touch LDS: with the MFMA issued as W . X^T the A operand of lane (t, gq) is 16 contiguous bytes of
-//     weight row n0 + t, so each wave streams exactly its own rows from L2 straight into registers (1 KiB per load
-//     instruction, a ring of loads in flight), and a fragment is reused for the G token tiles;
+//   * weights never touch LDS: each wave streams exactly its own rows from L2 straight into MFMA operand registers,
+//     from a FRAGMENT-MAJOR bf16 copy of the weights in which the A operand of one MFMA (W . X^T form) is one fully
+//     contiguous 1-KiB wave load (a ring of 12 loads in flight per wave); a fragment is reused for the G token tiles;
 //   * activations go through LDS between the GEMMs ([32-k tile][token][64 B], 16-B XOR swizzle: conflict-free
 //     ds_read_b128 fragments): LayerNorm output -> qkv (wave = head: q, k, v of its head stay in registers for the
 //     attention core) -> attention output -> proj (+ residual; LayerNorm statistics combined across the waves with the
@@ -16,7 +16,8 @@
 //
 // The backward mirrors it: fc2' -> GELU' -> fc1' -> norm2' -> proj' -> attention' -> qkv' -> norm1' with the same
 // split.  Its data-gradient GEMMs contract over the output channels of each Linear, i.e. they stream W^T rows: the
-// caller passes bf16 TRANSPOSED copies of the four weights (tulip_transpose_bf16 refreshes them once per step).
+// caller passes fragment-major copies of the four TRANSPOSED weights (tulip_pack_bf16_multi writes both kinds of copy
+// once per optimizer step).
 // Per-channel parameter partial sums (LayerNorm affine, relative-position bias) are disjoint between waves, so each
 // wave writes its slice of the workgroup's partial row directly.
 #include <type_traits>
@@ -55,36 +56,88 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* base, int kt, int to
     return *(const bf16x8*)(base + kt * (T * 64) + tok * 64 + ((gq ^ swz4(tok)) << 4));
 }
 
-// acc[i][g] += W[rows of tile i][k] . X[token tile g][k]^T over KSTEPS 32-deep steps.  wrow[i]: this lane's weight row
-// of tile i, already offset by its 8 k-slots (8 gq); the weight stream runs PF steps ahead of the MFMAs.
-template <int NTILE, int G, int KSTEPS, int PF, int T>
-__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[NTILE][G], const bf16_t* const (&wrow)[NTILE],
-                                          const unsigned char* act, int t, int gq) {
+// Weights are read in FRAGMENT-MAJOR ("packed") order: the 16 x 32 block of rows 16 nt.., k 32 ks.. of a [N][K] matrix is
+// the 1-KiB block (nt * K/32 + ks) and lane (t, gq) owns its bytes [16 (t + 16 gq), +16) = W[16 nt + t][32 ks + 8 gq ..
+// +7] -- so the A operand of one MFMA is ONE fully contiguous 1-KiB wave load.  Measured on this chip (tools/
+// probe_stream.hip): a global_load_dwordx4 whose lanes walk down the rows of a row-major matrix (the natural fragment
+// order) moves 16 B/clk per CU however many are in flight, lanes along 64..512-B row pieces 20-33 B/clk, a contiguous
+// KiB 47-60 B/clk; with the row-major layout the kernels below spent 60-70 % of their time in the weight stream.
+//
+// acc[i][g] += W[tile i][k] . X[token tile g][k]^T over KSTEPS 32-deep steps.  wtile[i]: the tile's first block, already
+// offset by this lane's 8 elements; the weight stream runs PF steps ahead of the MFMAs.
+template <int NTILE, int KSTEPS, int PF>
+struct WStream {
     bf16x8 ring[PF][NTILE];
-    static_for<PF>([&](auto P_) {
-        constexpr int p = decltype(P_)::value;
-        if constexpr (p < KSTEPS) {
+    const bf16_t* wt[NTILE];
+    // the first PF steps of the stream.  Issued EARLY -- before the epilogue stores / the barrier of the phase in front:
+    // vmcnt retires in order, so a weight load issued after a batch of stores cannot be waited for without draining
+    // those stores, while one issued before them costs the wait nothing.
+    __device__ __forceinline__ void start() {
+        static_for<PF>([&](auto P_) {
+            constexpr int p = decltype(P_)::value;
+            if constexpr (p < KSTEPS) {
 #pragma unroll
-            for (int i = 0; i < NTILE; ++i) ring[p][i] = *(const bf16x8*)(wrow[i] + 32 * p);
-        }
-    });
-    static_for<KSTEPS>([&](auto K_) {
-        constexpr int ks = decltype(K_)::value;
-        bf16x8 a[NTILE];
+                for (int i = 0; i < NTILE; ++i) ring[p][i] = *(const bf16x8*)(wt[i] + 512 * p);
+            }
+        });
+    }
+    template <int G, int T>
+    __device__ __forceinline__ void run(f32x4 (&acc)[NTILE][G], const unsigned char* act, int t, int gq) {
+        static_for<KSTEPS>([&](auto K_) {
+            constexpr int ks = decltype(K_)::value;
+            bf16x8 a[NTILE];
 #pragma unroll
-        for (int i = 0; i < NTILE; ++i) a[i] = ring[ks % PF][i];
-        if constexpr (ks + PF < KSTEPS) {
+            for (int i = 0; i < NTILE; ++i) a[i] = ring[ks % PF][i];
+            if constexpr (ks + PF < KSTEPS) {
 #pragma unroll
-            for (int i = 0; i < NTILE; ++i) ring[ks % PF][i] = *(const bf16x8*)(wrow[i] + 32 * (ks + PF));
-        }
-        bf16x8 b[G];
+                for (int i = 0; i < NTILE; ++i) ring[ks % PF][i] = *(const bf16x8*)(wt[i] + 512 * (ks + PF));
+            }
+            bf16x8 b[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) b[g] = frag<T>(act, ks, 16 * g + t, gq);
+            for (int g = 0; g < G; ++g) b[g] = frag<T>(act, ks, 16 * g + t, gq);
 #pragma unroll
-        for (int i = 0; i < NTILE; ++i)
+            for (int i = 0; i < NTILE; ++i)
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[g], acc[i][g], 0, 0, 0);
-    });
+                for (int g = 0; g < G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[g], acc[i][g], 0, 0, 0);
+        });
+    }
+};
+template <int NTILE, int G, int KSTEPS, int PF, int T>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[NTILE][G], const bf16_t* const (&wtile)[NTILE],
+                                          const unsigned char* act, int t, int gq) {
+    WStream<NTILE, KSTEPS, PF> w;
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) w.wt[i] = wtile[i];
+    w.start();
+    w.template run<G, T>(acc, act, t, gq);
+}
+template <int NTILE, int G>
+__device__ __forceinline__ void zero(f32x4 (&acc)[NTILE][G]) {
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { const float4 v = *(const float4*)p; return (f32x4){v.x, v.y, v.z, v.w}; }
+// Pull `elems` bf16 of a weight array into this XCD's L2 ahead of the dependent k-step chains that stream it: inside a
+// training step the copies are cold (written at the end of the previous step, a step of other traffic ago) and each ring
+// refill of a cold stream is an HBM round trip.  The workgroups that share an XCD (workgroup b runs on XCD b % 8 --
+// observed, used for speed only) split the array in 1-KiB wave loads into a scratch register nobody reads; loads issued
+// through inline asm are invisible to the compiler's vmcnt bookkeeping, which is safe (in-order retirement: they can
+// only make a later wait longer) and costs the kernel nothing but the issue slots.
+__device__ __forceinline__ void l2_prefetch(const bf16_t* w, int elems, int waves_per_wg, int wid, int lane) {
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int rank = (blockIdx.x / nxcd) * waves_per_wg + wid, nrank = ((gridDim.x + nxcd - 1) / nxcd) * waves_per_wg;
+    const int chunks = elems >> 9;                               // 1 KiB = 512 bf16
+    for (int c = rank; c < chunks; c += nrank) {
+        const bf16_t* p = w + (size_t)c * 512 + lane * 8;
+        f32x4 sink;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+    }
+}
+// first packed block of row tile `nt` of a matrix with K columns, at this lane's 8 elements
+__device__ __forceinline__ const bf16_t* wtile_ptr(const bf16_t* w, int nt, int K, int lane) {
+    return w + ((size_t)nt * (K >> 5)) * 512 + lane * 8;
 }
 
 struct SwinWArgs {
@@ -96,9 +149,11 @@ struct SwinWArgs {
     const float* bias_table; const int* rel_index;
     const float *ds0, *ds1;               // DropPath multipliers per sample (attention / MLP branch) or nullptr
     bf16_t* out_bf16;                     // optional bf16 copy of the block output (operand of a PatchUnmerging GEMM)
+    unsigned long long* prof;             // optional: s_memtime stamps [workgroup][wave][16] at the phase boundaries
     int B, H, W, sh, sw, masked;
     float eps, scale;
 };
+#define TULIP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int C, int G>
 struct Geo {
@@ -160,33 +215,55 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw);
     const float s0 = a.ds0 ? a.ds0[tm.b] : 1.0f, s1v = a.ds1 ? a.ds1[tm.b] : 1.0f;
 
-    // ---- norm1 (tulip.py:340): 16 lanes per token, 4 tokens per wave pass
-    for (int tt = wid * 4 + gq; tt < T; tt += NWV * 4) {
-        const size_t row = tm.row(tt);
-        float4 xv[C / 64];
-        float s = 0.f;
+    // loads in flight per wave: 12 with 6 waves per CU, 6-8 with 12 waves or 4 windows (register budget 168 / 256)
+    constexpr int D = (C == 192 && G == 2) ? 2 : 1;
+    TULIP_STAMP(0);
+    // the qkv weight stream starts before anything else: it depends on nothing
+    WStream<6, KS, D> wq;
 #pragma unroll
-        for (int j = 0; j < C / 64; ++j) {
-            xv[j] = *(const float4*)(a.xin + row * C + 4 * t + 64 * j);
-            s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+    for (int i = 0; i < 6; ++i) wq.wt[i] = wtile_ptr(a.wqkv, (i >> 1) * (C / 16) + 2 * wid + (i & 1), C, lane);
+    wq.start();
+    // ---- norm1 (tulip.py:340): 16 lanes per token, 4 tokens per wave pass; every pass's loads are issued first
+    {
+        constexpr int NP = (T + NWV * 4 - 1) / (NWV * 4);
+        float4 xv[NP][C / 64];
+        size_t rowp[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int tt = wid * 4 + gq + p * NWV * 4;
+            rowp[p] = tm.row(tt < T ? tt : T - 1);
+#pragma unroll
+            for (int j = 0; j < C / 64; ++j) xv[p][j] = *(const float4*)(a.xin + rowp[p] * C + 4 * t + 64 * j);
         }
-        const float mu = group_sum<16>(s) * (1.0f / C);
-        float q = 0.f;
+        float4 ga[C / 64], be[C / 64];
 #pragma unroll
-        for (int j = 0; j < C / 64; ++j) {
-            const float d0 = xv[j].x - mu, d1 = xv[j].y - mu, d2 = xv[j].z - mu, d3 = xv[j].w - mu;
-            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-        const float rs = rsqrtf(group_sum<16>(q) * (1.0f / C) + a.eps);
-        if (t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+        for (int j = 0; j < C / 64; ++j) { ga[j] = *(const float4*)(a.g1 + 4 * t + 64 * j); be[j] = *(const float4*)(a.be1 + 4 * t + 64 * j); }
 #pragma unroll
-        for (int j = 0; j < C / 64; ++j) {
-            const int c = 4 * t + 64 * j;
-            const float4 ga = *(const float4*)(a.g1 + c), be = *(const float4*)(a.be1 + c);
-            const bf16x4 p = pack4((xv[j].x - mu) * rs * ga.x + be.x, (xv[j].y - mu) * rs * ga.y + be.y,
-                                   (xv[j].z - mu) * rs * ga.z + be.z, (xv[j].w - mu) * rs * ga.w + be.w);
-            *(bf16x4*)(a.xn1 + row * C + c) = p;
-            put4<T>(XN, tt, c, p);
+        for (int p = 0; p < NP; ++p) {
+            const int tt = wid * 4 + gq + p * NWV * 4;
+            if (tt < T) {
+                const size_t row = rowp[p];
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < C / 64; ++j) sm += (xv[p][j].x + xv[p][j].y) + (xv[p][j].z + xv[p][j].w);
+                const float mu = group_sum<16>(sm) * (1.0f / C);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < C / 64; ++j) {
+                    const float d0 = xv[p][j].x - mu, d1 = xv[p][j].y - mu, d2 = xv[p][j].z - mu, d3 = xv[p][j].w - mu;
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+                const float rs = rsqrtf(group_sum<16>(q) * (1.0f / C) + a.eps);
+                if (t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+#pragma unroll
+                for (int j = 0; j < C / 64; ++j) {
+                    const int c = 4 * t + 64 * j;
+                    const bf16x4 pk = pack4((xv[p][j].x - mu) * rs * ga[j].x + be[j].x, (xv[p][j].y - mu) * rs * ga[j].y + be[j].y,
+                                            (xv[p][j].z - mu) * rs * ga[j].z + be[j].z, (xv[p][j].w - mu) * rs * ga[j].w + be[j].w);
+                    *(bf16x4*)(a.xn1 + row * C + c) = pk;
+                    put4<T>(XN, tt, c, pk);
+                }
+            }
         }
     }
     // this lane's tokens in the MFMA phases: token t of window g
@@ -194,36 +271,52 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     int lab[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { rows[g] = tm.row(16 * g + t); lab[g] = tm.label(16 * g + t); }
-    // relative-position bias of this wave's head for (query t, keys 4gq..4gq+3) (tulip.py:304-308)
+    // relative-position bias of this wave's head for (query t, keys 4gq..4gq+3) (tulip.py:304-308), qkv biases
     float rpb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rpb[r] = a.bias_table[a.rel_index[t * 16 + gq * 4 + r] * NH + wid];
+    f32x4 bq[D == 2 ? 6 : 1];                       // hoisted only where the register budget allows (6 waves per CU)
+    if constexpr (D == 2) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bq[i] = ld4(a.bqkv + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
+    }
+    TULIP_STAMP(1);
     __syncthreads();
+    TULIP_STAMP(2);
 
     // ---- qkv Linear (tulip.py:298), wave = head: q, k, v channels 32 wid .. +31 of each section
     bf16x4 qkvp[6][G];
+    WStream<2, KS, 3 * D> wp;                       // proj weights: this wave's 32 output channels
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wp.wt[i] = wtile_ptr(a.wproj, 2 * wid + i, C, lane);
     {
         f32x4 acc[6][G];
-        const bf16_t* wrow[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            wrow[i] = a.wqkv + (size_t)((i >> 1) * C + 32 * wid + 16 * (i & 1) + t) * C + 8 * gq;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        wave_gemm<6, G, KS, 2, T>(acc, wrow, XN, t, gq);
+        zero(acc);
+        wq.template run<G, T>(acc, XN, t, gq);
+        TULIP_STAMP(3);
+        wp.start();                                 // ahead of the qkv stores
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int n = (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq;
-            const float4 bq = *(const float4*)(a.bqkv + n);
+            f32x4 bqi;
+            if constexpr (D == 2) bqi = bq[i]; else bqi = ld4(a.bqkv + n);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                qkvp[i][g] = pack4(acc[i][g][0] + bq.x, acc[i][g][1] + bq.y, acc[i][g][2] + bq.z, acc[i][g][3] + bq.w);
+                qkvp[i][g] = pack4(acc[i][g][0] + bqi[0], acc[i][g][1] + bqi[1], acc[i][g][2] + bqi[2], acc[i][g][3] + bqi[3]);
                 *(bf16x4*)(a.qkv + rows[g] * (3 * C) + n) = qkvp[i][g];
             }
         }
     }
+    // residual input and proj bias of this wave's channels: in flight during the attention core
+    f32x4 x1v[2][G], bp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        bp[i] = ld4(a.bproj + 32 * wid + 16 * i + 4 * gq);
+#pragma unroll
+        for (int g = 0; g < G; ++g) x1v[i][g] = ld4(a.xin + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
+    }
 
+    TULIP_STAMP(4);
     // ---- attention of this head, one window at a time (tulip.py:300-317); scores as K.Q^T: lane = query t, keys 4gq + r
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -264,36 +357,36 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             put4<T>(XO, 16 * g + t, c, op);
         }
     }
+    TULIP_STAMP(5);
     __syncthreads();
+    TULIP_STAMP(6);
 
     // ---- proj Linear + DropPath + residual (tulip.py:318,344): this wave's 32 output channels; then norm2 (:347)
-    f32x4 x1v[2][G];
+    WStream<4, KS, D + 1> w1a;                      // fc1, first 64 of this wave's 128 hidden channels
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1a.wt[i] = wtile_ptr(a.w1, 8 * wid + i, C, lane);
+    f32x4 ga2[2], be2[2];
     {
         f32x4 acc[2][G];
-        const bf16_t* wrow[2];
+        zero(acc);
+        wp.template run<G, T>(acc, XO, t, gq);
+        TULIP_STAMP(7);
+        w1a.start();                                // ahead of the x1 / xn2 stores
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            wrow[i] = a.wproj + (size_t)(32 * wid + 16 * i + t) * C + 8 * gq;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        wave_gemm<2, G, KS, 4, T>(acc, wrow, XO, t, gq);
+        for (int i = 0; i < 2; ++i) { ga2[i] = ld4(a.g2 + 32 * wid + 16 * i + 4 * gq); be2[i] = ld4(a.be2 + 32 * wid + 16 * i + 4 * gq); }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float s = 0.f;
+            float sm = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c0 = 32 * wid + 16 * i + 4 * gq;
-                const float4 bp = *(const float4*)(a.bproj + c0);
-                const float4 x = *(const float4*)(a.xin + rows[g] * C + c0);
-                x1v[i][g] = (f32x4){x.x + s0 * (acc[i][g][0] + bp.x), x.y + s0 * (acc[i][g][1] + bp.y),
-                                    x.z + s0 * (acc[i][g][2] + bp.z), x.w + s0 * (acc[i][g][3] + bp.w)};
+                x1v[i][g] = x1v[i][g] + s0 * (acc[i][g] + bp[i]);
                 *(float4*)(a.x1 + rows[g] * C + c0) = make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]);
-                s += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
+                sm += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
             }
             // statistics of this wave's 32 channels of token t: (mean, sum of squared deviations)
-            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            const float mw = s * (1.0f / 32);
+            sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+            const float mw = sm * (1.0f / 32);
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -303,7 +396,9 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             if (gq == 0) STAT[wid * T + 16 * g + t] = make_float2(mw, q);
         }
     }
+    TULIP_STAMP(8);
     __syncthreads();
+    TULIP_STAMP(9);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         // combine the NWV equal-sized groups: mean of means; M2 = sum M2_w + 32 sum (mean_w - mean)^2
@@ -320,34 +415,39 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c0 = 32 * wid + 16 * i + 4 * gq;
-            const float4 ga = *(const float4*)(a.g2 + c0), be = *(const float4*)(a.be2 + c0);
-            const bf16x4 p = pack4((x1v[i][g][0] - mu) * rs * ga.x + be.x, (x1v[i][g][1] - mu) * rs * ga.y + be.y,
-                                   (x1v[i][g][2] - mu) * rs * ga.z + be.z, (x1v[i][g][3] - mu) * rs * ga.w + be.w);
-            *(bf16x4*)(a.xn2 + rows[g] * C + c0) = p;
-            put4<T>(XN, 16 * g + t, c0, p);
+            const bf16x4 pk = pack4((x1v[i][g][0] - mu) * rs * ga2[i][0] + be2[i][0], (x1v[i][g][1] - mu) * rs * ga2[i][1] + be2[i][1],
+                                    (x1v[i][g][2] - mu) * rs * ga2[i][2] + be2[i][2], (x1v[i][g][3] - mu) * rs * ga2[i][3] + be2[i][3]);
+            *(bf16x4*)(a.xn2 + rows[g] * C + c0) = pk;
+            put4<T>(XN, 16 * g + t, c0, pk);
         }
     }
+    f32x4 b1v[D == 2 ? 2 : 1][4];
+    if constexpr (D == 2) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b1v[ch][i] = ld4(a.b1 + 128 * wid + 64 * ch + 16 * i + 4 * gq);
+    }
+    TULIP_STAMP(10);
     __syncthreads();
+    TULIP_STAMP(11);
 
     // ---- fc1 + exact-erf GELU (tulip.py:195-196): this wave's 128 hidden channels, 64 at a time
+    WStream<4, KS, D + 1> w1b;
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        f32x4 acc[4][G];
-        const bf16_t* wrow[4];
+    for (int i = 0; i < 4; ++i) w1b.wt[i] = wtile_ptr(a.w1, 8 * wid + 4 + i, C, lane);
+    WStream<2, 4 * KS, 3 * D> w2s;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wrow[i] = a.w1 + (size_t)(128 * wid + 64 * ch + 16 * i + t) * C + 8 * gq;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        wave_gemm<4, G, KS, 2, T>(acc, wrow, XN, t, gq);
+    for (int i = 0; i < 2; ++i) w2s.wt[i] = wtile_ptr(a.w2, 2 * wid + i, HID, lane);
+    auto fc1_out = [&](const f32x4 (&acc)[4][G], int ch) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
-            const float4 bb = *(const float4*)(a.b1 + n);
+            f32x4 bb;
+            if constexpr (D == 2) bb = b1v[ch][i]; else bb = ld4(a.b1 + n);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const bf16x4 hp = pack4(acc[i][g][0] + bb.x, acc[i][g][1] + bb.y, acc[i][g][2] + bb.z, acc[i][g][3] + bb.w);
+                const bf16x4 hp = pack4(acc[i][g][0] + bb[0], acc[i][g][1] + bb[1], acc[i][g][2] + bb[2], acc[i][g][3] + bb[3]);
                 *(bf16x4*)(a.h + rows[g] * HID + n) = hp;
                 const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
                 const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
@@ -356,33 +456,43 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                 put4<T>(GB, 16 * g + t, n, gp);
             }
         }
+    };
+    {
+        f32x4 acc[4][G];
+        zero(acc);
+        w1a.template run<G, T>(acc, XN, t, gq);
+        w1b.start();
+        fc1_out(acc, 0);
+        zero(acc);
+        w1b.template run<G, T>(acc, XN, t, gq);
+        w2s.start();
+        fc1_out(acc, 1);
     }
+    f32x4 b2v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2v[i] = ld4(a.b2 + 32 * wid + 16 * i + 4 * gq);
+    TULIP_STAMP(12);
     __syncthreads();
+    TULIP_STAMP(13);
 
     // ---- fc2 + DropPath + residual (tulip.py:198,351)
     {
         f32x4 acc[2][G];
-        const bf16_t* wrow[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            wrow[i] = a.w2 + (size_t)(32 * wid + 16 * i + t) * HID + 8 * gq;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        wave_gemm<2, G, 4 * KS, 4, T>(acc, wrow, GB, t, gq);
+        zero(acc);
+        w2s.template run<G, T>(acc, GB, t, gq);
+        TULIP_STAMP(14);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c0 = 32 * wid + 16 * i + 4 * gq;
-            const float4 bb = *(const float4*)(a.b2 + c0);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float o0 = x1v[i][g][0] + s1v * (acc[i][g][0] + bb.x), o1 = x1v[i][g][1] + s1v * (acc[i][g][1] + bb.y);
-                const float o2 = x1v[i][g][2] + s1v * (acc[i][g][2] + bb.z), o3 = x1v[i][g][3] + s1v * (acc[i][g][3] + bb.w);
-                *(float4*)(a.xout + rows[g] * C + c0) = make_float4(o0, o1, o2, o3);
-                if (a.out_bf16) *(bf16x4*)(a.out_bf16 + rows[g] * C + c0) = pack4(o0, o1, o2, o3);
+                const f32x4 o = x1v[i][g] + s1v * (acc[i][g] + b2v[i]);
+                *(float4*)(a.xout + rows[g] * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (a.out_bf16) *(bf16x4*)(a.out_bf16 + rows[g] * C + c0) = pack4(o[0], o[1], o[2], o[3]);
             }
         }
     }
+    TULIP_STAMP(15);
 }
 
 template <int C, int G>
@@ -401,7 +511,7 @@ struct SwinWBwdArgs {
     const float *xin, *x1;
     const bf16_t *qkv, *h;
     const float *mean1, *rstd1, *mean2, *rstd2;
-    const bf16_t *wqkvt, *wprojt, *w1t, *w2t;    // TRANSPOSED bf16 weights: [C][3C], [C][C], [C][4C], [4C][C]
+    const bf16_t *wqkvt, *wprojt, *w1t, *w2t;    // fragment-major TRANSPOSED weights: of [C][3C], [C][C], [C][4C], [4C][C]
     const float *g1, *g2;
     const float* bias_table; const int* rel_index;
     const float *ds0, *ds1;
@@ -423,34 +533,29 @@ struct GeoB {
     static_assert(SMEM <= 163840, "LDS");
 };
 
-// LayerNorm backward of this wave's 32-channel slice (2 tiles x 4 channels per lane, G token tiles).  Phase 1: the
+// LayerNorm backward of this wave's 32-channel slice (2 tiles x 4 channels per lane, G token tiles; x, the row
+// statistics and gamma were fetched while the GEMM in front was running).  Phase 1: the
 // affine-gradient sums of the slice (over the workgroup's T tokens) go straight to the partial row, d <- d * gamma,
 // and the per-token partial sums (sum d, sum d*xhat over the 32 channels) to STAT.  Phase 2 (after the barrier):
 // d <- rstd * (d - m1 - xhat * m2) with the sums over all NWV waves.
 template <int C, int G, int T>
-__device__ __forceinline__ void ln_bwd_part1(f32x4 (&d)[2][G], f32x4 (&xh)[2][G], const float* __restrict__ x,
-                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                             const float* __restrict__ gam, const size_t (&rows)[G], float (&rs)[G],
+__device__ __forceinline__ void ln_bwd_part1(f32x4 (&d)[2][G], f32x4 (&xh)[2][G], const f32x4 (&xv)[2][G],
+                                             const float (&mu)[G], const float (&rs)[G], const f32x4 (&gam)[2],
                                              float* __restrict__ part, float2* STAT, int wid, int t, int gq) {
     f32x4 pg[2], pb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) pg[i] = pb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const float mu = mean[rows[g]];
-        rs[g] = rstd[rows[g]];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int c0 = 32 * wid + 16 * i + 4 * gq;
-            const float4 xv = *(const float4*)(x + rows[g] * C + c0), ga = *(const float4*)(gam + c0);
-            const float xr[4] = {xv.x, xv.y, xv.z, xv.w}, gr[4] = {ga.x, ga.y, ga.z, ga.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                xh[i][g][r] = (xr[r] - mu) * rs[g];
+                xh[i][g][r] = (xv[i][g][r] - mu[g]) * rs[g];
                 pg[i][r] += d[i][g][r] * xh[i][g][r];
                 pb[i][r] += d[i][g][r];
-                d[i][g][r] *= gr[r];
+                d[i][g][r] *= gam[i][r];
                 s1 += d[i][g][r];
                 s2 += d[i][g][r] * xh[i][g][r];
             }
@@ -500,16 +605,36 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw);
     const float s0 = a.ds0 ? a.ds0[tm.b] : 1.0f, s1v = a.ds1 ? a.ds1[tm.b] : 1.0f;
 
-    // ---- bf16(dy * s_mlp): operand of fc2's weight gradient and of the first data-gradient GEMM
-    for (int tt = wid * 4 + gq; tt < T; tt += NWV * 4) {
-        const size_t row = tm.row(tt);
+    constexpr int D = (C == 192 && G == 2) ? 2 : 1;       // loads in flight per wave, as in the forward
+    // the first weight stream (fc2^T, first 64 of this wave's 128 hidden channels) starts before anything else
+    WStream<4, KS, D + 1> w2a;
 #pragma unroll
-        for (int j = 0; j < C / 64; ++j) {
-            const int c = 4 * t + 64 * j;
-            const float4 v = *(const float4*)(a.dx + row * C + c);
-            const bf16x4 p = pack4(v.x * s1v, v.y * s1v, v.z * s1v, v.w * s1v);
-            *(bf16x4*)(a.dyb_m + row * C + c) = p;
-            put4<T>(DY, tt, c, p);
+    for (int i = 0; i < 4; ++i) w2a.wt[i] = wtile_ptr(a.w2t, 8 * wid + i, C, lane);
+    w2a.start();
+    // ---- bf16(dy * s_mlp): operand of fc2's weight gradient and of the first data-gradient GEMM
+    {
+        constexpr int NP = (T + NWV * 4 - 1) / (NWV * 4);
+        float4 v[NP][C / 64];
+        size_t rowp[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int tt = wid * 4 + gq + p * NWV * 4;
+            rowp[p] = tm.row(tt < T ? tt : T - 1);
+#pragma unroll
+            for (int j = 0; j < C / 64; ++j) v[p][j] = *(const float4*)(a.dx + rowp[p] * C + 4 * t + 64 * j);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int tt = wid * 4 + gq + p * NWV * 4;
+            if (tt < T) {
+#pragma unroll
+                for (int j = 0; j < C / 64; ++j) {
+                    const int c = 4 * t + 64 * j;
+                    const bf16x4 pk = pack4(v[p][j].x * s1v, v[p][j].y * s1v, v[p][j].z * s1v, v[p][j].w * s1v);
+                    *(bf16x4*)(a.dyb_m + rowp[p] * C + c) = pk;
+                    put4<T>(DY, tt, c, pk);
+                }
+            }
         }
     }
     size_t rows[G];
@@ -526,48 +651,75 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     __syncthreads();
 
     // ---- fc2' and GELU' (tulip.py:196-198 backwards): d(h) for this wave's 128 hidden channels = (dy . W2)[hid] * gelu'(h)
+    WStream<4, KS, D + 1> w2b;
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        f32x4 acc[4][G];
-        const bf16_t* wrow[4];
+    for (int i = 0; i < 4; ++i) w2b.wt[i] = wtile_ptr(a.w2t, 8 * wid + 4 + i, C, lane);
+    WStream<2, 4 * KS, 3 * D> w1s;                  // fc1^T: this wave's 32 channels of d(xn2)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wrow[i] = a.w2t + (size_t)(128 * wid + 64 * ch + 16 * i + t) * C + 8 * gq;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        wave_gemm<4, G, KS, 2, T>(acc, wrow, DY, t, gq);
+    for (int i = 0; i < 2; ++i) w1s.wt[i] = wtile_ptr(a.w1t, 2 * wid + i, HID, lane);
+    auto dh_out = [&](const f32x4 (&acc)[4][G], const bf16x4 (&hv)[4][G], int ch) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const bf16x4 hv = *(const bf16x4*)(a.h + rows[g] * HID + n);
-                const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[0]), bf2f((bf16_t)hv[1])});
-                const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[2]), bf2f((bf16_t)hv[3])});
+                const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[i][g][0]), bf2f((bf16_t)hv[i][g][1])});
+                const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[i][g][2]), bf2f((bf16_t)hv[i][g][3])});
                 const bf16x4 dp = pack4(acc[i][g][0] * d01.x, acc[i][g][1] * d01.y, acc[i][g][2] * d23.x, acc[i][g][3] * d23.y);
                 *(bf16x4*)(a.dh + rows[g] * HID + n) = dp;
                 put4<T>(DH, 16 * g + t, n, dp);
             }
         }
+    };
+    auto load_h = [&](bf16x4 (&hv)[4][G], int ch) {          // the saved fc1 pre-activation
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) hv[i][g] = *(const bf16x4*)(a.h + rows[g] * HID + 128 * wid + 64 * ch + 16 * i + 4 * gq);
+    };
+    {
+        // (the activation loads stay BEHIND the GEMM they follow: vmcnt retires in order, so a strided HBM load issued
+        // in front of the loop would sit in front of every weight refill the loop then waits for -- measured 35 -> 50 us)
+        f32x4 acc[4][G];
+        bf16x4 hv[4][G];
+        zero(acc);
+        w2a.template run<G, T>(acc, DY, t, gq);
+        w2b.start();
+        load_h(hv, 0);
+        dh_out(acc, hv, 0);
+        zero(acc);
+        w2b.template run<G, T>(acc, DY, t, gq);
+        w1s.start();
+        load_h(hv, 1);
+        dh_out(acc, hv, 1);
     }
+    f32x4 xv[2][G], gam[2], dyv[2][G];
+    float mu[G], rs[G];
     __syncthreads();
 
     // ---- fc1' (tulip.py:195 backwards): d(xn2)[c] for this wave's 32 channels, then norm2' and the residual
+    WStream<2, KS, 3 * D> wps;                      // proj^T: dO of this wave's head
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wps.wt[i] = wtile_ptr(a.wprojt, 2 * wid + i, C, lane);
     f32x4 dx1[2][G];
     {
         f32x4 xh[2][G];
-        float rs[G];
-        const bf16_t* wrow[2];
+        zero(dx1);
+        w1s.template run<G, T>(dx1, DH, t, gq);
+        wps.start();
+        // what norm2' needs: x1 slice, row statistics, gamma; and dy for the residual
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            wrow[i] = a.w1t + (size_t)(32 * wid + 16 * i + t) * HID + 8 * gq;
+            gam[i] = ld4(a.g2 + 32 * wid + 16 * i + 4 * gq);
 #pragma unroll
-            for (int g = 0; g < G; ++g) dx1[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < G; ++g) {
+                xv[i][g] = ld4(a.x1 + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
+                dyv[i][g] = ld4(a.dx + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
+            }
         }
-        wave_gemm<2, G, 4 * KS, 4, T>(dx1, wrow, DH, t, gq);
-        ln_bwd_part1<C, G, T>(dx1, xh, a.x1, a.mean2, a.rstd2, a.g2, rows, rs, a.lnpart2 + (size_t)blockIdx.x * 2 * C, STAT,
-                              wid, t, gq);
+#pragma unroll
+        for (int g = 0; g < G; ++g) { mu[g] = a.mean2[rows[g]]; rs[g] = a.rstd2[rows[g]]; }
+        ln_bwd_part1<C, G, T>(dx1, xh, xv, mu, rs, gam, a.lnpart2 + (size_t)blockIdx.x * 2 * C, STAT, wid, t, gq);
         __syncthreads();
         ln_bwd_part2<C, G, T, NWV>(dx1, xh, rs, STAT, t);
         // d(x1) = dy + norm2'(d(xn2))  (residual, tulip.py:351); its bf16 copy * s_attn feeds proj' and proj's wgrad
@@ -576,33 +728,37 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             const int c0 = 32 * wid + 16 * i + 4 * gq;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float4 dy = *(const float4*)(a.dx + rows[g] * C + c0);
-                dx1[i][g] = (f32x4){dx1[i][g][0] + dy.x, dx1[i][g][1] + dy.y, dx1[i][g][2] + dy.z, dx1[i][g][3] + dy.w};
-                const bf16x4 p = pack4(dx1[i][g][0] * s0, dx1[i][g][1] * s0, dx1[i][g][2] * s0, dx1[i][g][3] * s0);
-                *(bf16x4*)(a.dyb_a + rows[g] * C + c0) = p;
-                put4<T>(DY, 16 * g + t, c0, p);
+                dx1[i][g] = dx1[i][g] + dyv[i][g];
+                const bf16x4 pk = pack4(dx1[i][g][0] * s0, dx1[i][g][1] * s0, dx1[i][g][2] * s0, dx1[i][g][3] * s0);
+                *(bf16x4*)(a.dyb_a + rows[g] * C + c0) = pk;
+                put4<T>(DY, 16 * g + t, c0, pk);
             }
         }
     }
     __syncthreads();
 
     // ---- proj' (tulip.py:318 backwards): dO of this wave's head
+    WStream<2, 3 * KS, 3 * D> wqs;                  // qkv^T: this wave's 32 channels of d(xn1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wqs.wt[i] = wtile_ptr(a.wqkvt, 2 * wid + i, 3 * C, lane);
     bf16x4 dop[2][G];
     {
         f32x4 acc[2][G];
-        const bf16_t* wrow[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            wrow[i] = a.wprojt + (size_t)(32 * wid + 16 * i + t) * C + 8 * gq;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        wave_gemm<2, G, KS, 4, T>(acc, wrow, DY, t, gq);
+        zero(acc);
+        wps.template run<G, T>(acc, DY, t, gq);
+        wqs.start();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < G; ++g) dop[i][g] = pack4(acc[i][g][0], acc[i][g][1], acc[i][g][2], acc[i][g][3]);
     }
+    // q, k, v of this head for the attention backward
+    bf16x4 qkvr[6][G];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            qkvr[i][g] = *(const bf16x4*)(a.qkv + rows[g] * (3 * C) + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
     // ---- attention' of this head, one window at a time (tulip.py:300-317 backwards; algebra of attn_bwd_kernel)
     {
         unsigned char* ldsQ = smem + Z::OFF_ATT + wid * 3072;
@@ -613,15 +769,11 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            bf16x4 qkvr[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                qkvr[i] = *(const bf16x4*)(a.qkv + rows[g] * (3 * C) + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
-            const bf16x8 qf = cat8(qkvr[0], qkvr[1]), kf = cat8(qkvr[2], qkvr[3]), vf = cat8(qkvr[4], qkvr[5]);
+            const bf16x8 qf = cat8(qkvr[0][g], qkvr[1][g]), kf = cat8(qkvr[2][g], qkvr[3][g]), vf = cat8(qkvr[4][g], qkvr[5][g]);
             const bf16x8 df = cat8(dop[0][g], dop[1][g]);
             const int o0 = t * 64 + (4 * gq) * 2, o1 = t * 64 + (16 + 4 * gq) * 2;
-            *(bf16x4*)(ldsQ + o0) = qkvr[0];     *(bf16x4*)(ldsQ + o1) = qkvr[1];
-            *(bf16x4*)(ldsK + o0) = qkvr[2];     *(bf16x4*)(ldsK + o1) = qkvr[3];
+            *(bf16x4*)(ldsQ + o0) = qkvr[0][g];  *(bf16x4*)(ldsQ + o1) = qkvr[1][g];
+            *(bf16x4*)(ldsK + o0) = qkvr[2][g];  *(bf16x4*)(ldsK + o1) = qkvr[3][g];
             *(bf16x4*)(ldsD + o0) = dop[0][g];   *(bf16x4*)(ldsD + o1) = dop[1][g];
             f32x4 sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);    // S[t][4gq+r]
             f32x4 sk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);    // S[4gq+r][t]
@@ -694,17 +846,17 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     // ---- qkv' (tulip.py:298 backwards), norm1' and the residual
     {
         f32x4 acc[2][G], xh[2][G];
-        float rs[G];
-        const bf16_t* wrow[2];
+        zero(acc);
+        wqs.template run<G, T>(acc, DQ, t, gq);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            wrow[i] = a.wqkvt + (size_t)(32 * wid + 16 * i + t) * (3 * C) + 8 * gq;
+            gam[i] = ld4(a.g1 + 32 * wid + 16 * i + 4 * gq);
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < G; ++g) xv[i][g] = ld4(a.xin + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
         }
-        wave_gemm<2, G, 3 * KS, 4, T>(acc, wrow, DQ, t, gq);
-        ln_bwd_part1<C, G, T>(acc, xh, a.xin, a.mean1, a.rstd1, a.g1, rows, rs, a.lnpart1 + (size_t)blockIdx.x * 2 * C, STAT,
-                              wid, t, gq);
+#pragma unroll
+        for (int g = 0; g < G; ++g) { mu[g] = a.mean1[rows[g]]; rs[g] = a.rstd1[rows[g]]; }
+        ln_bwd_part1<C, G, T>(acc, xh, xv, mu, rs, gam, a.lnpart1 + (size_t)blockIdx.x * 2 * C, STAT, wid, t, gq);
         __syncthreads();
         ln_bwd_part2<C, G, T, NWV>(acc, xh, rs, STAT, t);
         const float cs = a.dx_scale ? a.dx_scale[tm.b] : 1.0f;
@@ -734,16 +886,28 @@ __host__ __device__ inline bool wide_g4(int C, int B, int H, int W) {
     return C == 192 && (W % 32 == 0) && (B * (H / 2) * (W / 8)) / 4 >= 256;
 }
 
-// ---- dst[c][r] = src[r][c] for a list of bf16 matrices (the transposed weight copies the backward streams)
-struct TrItem { const bf16_t* src; bf16_t* dst; int rows, cols, first; };
-struct TrList { TrItem it[TULIP_TRANSPOSE_MAX]; int n; };
-__global__ __launch_bounds__(256) void transpose_multi_kernel(const TrList L) {
+// ---- fragment-major copies of a list of bf16 matrices: mode 0: dst = packed(src [rows][cols]);  mode 1: dst =
+// packed(src^T) (a [cols][rows] matrix), through an LDS tile transpose so that both sides move 16-byte pieces
+struct TrItem { const bf16_t* src; bf16_t* dst; int rows, cols, mode, first; };
+struct TrList { TrItem it[TULIP_PACK_MAX]; int n; };
+__device__ __forceinline__ size_t packed_offset(int n, int k, int K) {      // element (n, k) of a [N][K] matrix
+    return ((size_t)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + ((n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
+}
+__global__ __launch_bounds__(256) void pack_multi_kernel(const TrList L) {
     __shared__ bf16_t tile[64][66];
     int i = 0;
     while (i + 1 < L.n && (int)blockIdx.x >= L.it[i + 1].first) ++i;
     const TrItem& m = L.it[i];
     const int tc = (m.cols + 63) / 64;
     const int b = blockIdx.x - m.first, r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    if (m.mode == 0) {
+        for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+            const int r = r0 + (e >> 3), c8 = c0 + (e & 7) * 8;
+            if (r < m.rows && c8 < m.cols)
+                *(uint4*)(m.dst + packed_offset(r, c8, m.cols)) = *(const uint4*)(m.src + (size_t)r * m.cols + c8);
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < 64 * 8; e += 256) {
         const int r = e >> 3, c8 = (e & 7) * 8;
         if (r0 + r < m.rows && c0 + c8 < m.cols) {
@@ -760,17 +924,26 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const TrList L) {
             bf16_t o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = tile[r8 + k][c];
-            *(uint4*)(m.dst + (size_t)(c0 + c) * m.rows + r0 + r8) = *(const uint4*)o;
+            *(uint4*)(m.dst + packed_offset(c0 + c, r0 + r8, m.rows)) = *(const uint4*)o;    // transposed: [cols][rows]
         }
     }
 }
+
 }  // namespace
 
 extern "C" int tulip_swinw_supported(int C, int H, int W) {
     return (C == 192 || C == 384) && H > 0 && !(H & 1) && W > 0 && !(W & 15);
 }
 
+static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, unsigned long long* prof, hipStream_t stream);
 extern "C" int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hipStream_t stream) {
+    return swinw_fwd_impl(d, C, out_bf16, nullptr, stream);
+}
+extern "C" int tulip_swinw_block_fwd_profiled(const tulip_swin96_desc* d, int C, void* out_bf16, uint64_t* stamps,
+                                              hipStream_t stream) {
+    return swinw_fwd_impl(d, C, out_bf16, (unsigned long long*)stamps, stream);
+}
+static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, unsigned long long* prof, hipStream_t stream) {
     if (!d || d->B <= 0 || !tulip_swinw_supported(C, d->H, d->W) || d->shift_h < 0 || d->shift_h >= d->H ||
         d->shift_w < 0 || d->shift_w >= d->W)
         return TULIP_ERR_ARG;
@@ -785,6 +958,7 @@ extern "C" int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* ou
     a.g1 = d->norm1_weight; a.be1 = d->norm1_bias; a.g2 = d->norm2_weight; a.be2 = d->norm2_bias;
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.out_bf16 = (bf16_t*)out_bf16;
+    a.prof = prof;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
     if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_fwd<192, 4>(a, stream) : launch_fwd<192, 2>(a, stream);
@@ -818,20 +992,21 @@ extern "C" int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipS
     return launch_bwd<384, 2>(a, stream);
 }
 
-extern "C" int tulip_transpose_bf16_multi(const tulip_transpose_item* items, int n, hipStream_t stream) {
-    if (n < 0 || n > TULIP_TRANSPOSE_MAX || (n && !items)) return TULIP_ERR_ARG;
+extern "C" int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream) {
+    if (n < 0 || n > TULIP_PACK_MAX || (n && !items)) return TULIP_ERR_ARG;
     TrList L;
     L.n = 0;
     int first = 0;
     for (int i = 0; i < n; ++i) {
-        const tulip_transpose_item& it = items[i];
+        const tulip_pack_item& it = items[i];
         if (it.rows <= 0 || it.cols <= 0) continue;
-        if (!it.src || !it.dst || (it.rows & 7) || (it.cols & 7)) return TULIP_ERR_ARG;
-        L.it[L.n++] = TrItem{(const bf16_t*)it.src, (bf16_t*)it.dst, it.rows, it.cols, first};
+        const int N = it.transpose ? it.cols : it.rows, K = it.transpose ? it.rows : it.cols;
+        if (!it.src || !it.dst || (N & 15) || (K & 31)) return TULIP_ERR_ARG;
+        L.it[L.n++] = TrItem{(const bf16_t*)it.src, (bf16_t*)it.dst, it.rows, it.cols, it.transpose ? 1 : 0, first};
         first += ((it.rows + 63) / 64) * ((it.cols + 63) / 64);
     }
     if (L.n == 0) return TULIP_OK;
-    hipLaunchKernelGGL(transpose_multi_kernel, dim3(first), dim3(256), 0, stream, L);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(first), dim3(256), 0, stream, L);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

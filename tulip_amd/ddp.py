@@ -34,11 +34,19 @@ def plan_buckets(groups: Sequence[Tuple[str, int]], total: int, min_elems: int) 
     return out
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class GradBucketer:
     def __init__(self, groups: Sequence[Tuple[str, int]], total: int, bucket_mb: float = 16.0,
                  process_group: Optional[dist.ProcessGroup] = None, force: bool = False):
         """force: issue the collectives even in a one-rank group (exercises the N>1 code path -- graph segments,
-        stream-ordered work.wait(), per-bucket optimizer -- on a single GPU; needs an initialised process group)."""
+        stream-ordered work.wait(), per-bucket optimizer -- on a single GPU; needs an initialised process group).
+        `dry` (attribute): keep the step structure but skip the collectives themselves -- bench.py's measurement of
+        what the exchange costs beyond the cuts."""
+        self.dry = False
         self.buckets = plan_buckets(groups, total, int(bucket_mb * (1 << 20) / 4))
         self.by_tag = {tag: (a, b) for tag, a, b in self.buckets}
         self.pg = process_group
@@ -49,10 +57,13 @@ class GradBucketer:
     def on_group_done(self, tag: str, gflat: torch.Tensor, keep: bool = True):
         """Call after the launches producing group `tag` have been enqueued on the current stream.
         Returns (work, start, end) of the bucket's all-reduce, or None.  keep=False: the caller waits on the work
-        itself (per-bucket optimizer), wait_all() will not."""
+        itself (per-bucket optimizer), wait_all() will not.  gflat: the buffer the collective runs on -- the fp32
+        gradients, or their bf16 copy (Trainer(grad_dtype="bf16"))."""
         if not self.active or tag not in self.by_tag:
             return None
         a, b = self.by_tag[tag]
+        if self.dry:
+            return _Done(), a, b
         work = dist.all_reduce(gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         if keep:
             self.pending.append(work)

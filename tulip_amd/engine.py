@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32,
+from ._lib import (EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32,
                    EPI_UNSHUF2_BF16,
                    EPI_SPLIT_F32)
 
@@ -154,25 +154,32 @@ class FlatParams:
         self.refresh_transposes()
         self.shadow_dirty = False
 
-    def make_transposes(self, names: List[str]):
-        """bf16 TRANSPOSED copies of the given 2-D weights (the fused wide-block backward streams rows of W^T,
-        csrc/swinw.hip); refreshed from the shadow by refresh_transposes()."""
-        self.t_offset: Dict[str, int] = {}
+    def make_packed(self, names: List[str], with_transposes: bool):
+        """Fragment-major bf16 copies of the given 2-D weights, and of their transposes (what the fused wide-block kernels
+        stream, csrc/swinw.hip); refreshed from the shadow by refresh_transposes()."""
+        self.pk_offset: Dict[str, int] = {}
         off = 0
         for n in names:
-            self.t_offset[n] = off
+            self.pk_offset[n] = off
             off = _ceil(off + self.numel[n], ALIGN)
-        self.shadow_t = torch.zeros(max(off, ALIGN), dtype=torch.bfloat16, device=self.device)
-        self.base16t = self.shadow_t.data_ptr()
-        pairs = [(self.p16(n), self.base16t + 2 * self.t_offset[n], self.shape[n][0], self.shape[n][1]) for n in names]
-        self._tr_items, self._tr_n = ops.transpose_items(pairs)
+        self.packed = torch.zeros(max(off, ALIGN), dtype=torch.bfloat16, device=self.device)
+        self.packed_t = torch.zeros(max(off, ALIGN) if with_transposes else ALIGN, dtype=torch.bfloat16, device=self.device)
+        ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
+               for n in names]
+        if with_transposes:
+            ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
+                    for n in names]
+        self._pk_items, self._pk_n = ops.pack_items(ent)
+
+    def p16p(self, name: str) -> int:
+        return self.packed.data_ptr() + 2 * self.pk_offset[name]
 
     def p16t(self, name: str) -> int:
-        return self.base16t + 2 * self.t_offset[name]
+        return self.packed_t.data_ptr() + 2 * self.pk_offset[name]
 
     def refresh_transposes(self):
-        if getattr(self, "_tr_n", 0):
-            ops.transpose_bf16_multi(self._tr_items, self._tr_n)
+        if getattr(self, "_pk_n", 0):
+            ops.pack_bf16_multi(self._pk_items, self._pk_n)
 
 
 class Plan:
@@ -356,9 +363,10 @@ class TulipEngine:
         self.plans.clear()
         self._graphs.clear()
         self.params = FlatParams(self.model, device)
-        self.params.make_transposes([sp.prefix + suffix for sp in self.blocks if self._fusable_wide(sp)
-                                     for suffix in (".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight",
-                                                    ".mlp.fc2.weight")] if self.fuse_wide_bwd else [])
+        self.params.make_packed([sp.prefix + suffix for sp in self.blocks if self._fusable_wide(sp)
+                                 for suffix in (".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight",
+                                                ".mlp.fc2.weight")] if (self.fuse_wide or self.fuse_wide_bwd) else [],
+                                with_transposes=self.fuse_wide_bwd)
         rel = self.model.layers[0].blocks[0].attn.relative_position_index
         self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
         rates = torch.ones(max(1, self.n_drop_slots), 1)
@@ -417,7 +425,10 @@ class TulipEngine:
 
     fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
     fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
-    wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192,384").split(",") if c)
+    # C = 192 by default.  C = 384 (stage 2: 3.5 MB of weights per block, 2048 tokens at batch 8) is parity-tested and can be
+    # switched on, but is no faster than the 7-kernel sequences there: every workgroup streams the whole weight set through
+    # its own CU (66 + 65 us against 62 + 86 us isolated, equal inside the step); it pays from batch 16 up.
+    wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192").split(",") if c)
 
     def _fusable_wide(self, sp: BlockSpec) -> bool:
         """csrc/swinw.hip covers C = 192 / 384: heads of 32, window 2x8, MLP C -> 4C -> C."""
@@ -437,12 +448,13 @@ class TulipEngine:
         if wide or (self.fuse_block96 and self._fusable96(sp)):
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
             launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
+            wf = W_.p16p if wide else W_.p16           # the wide kernel streams fragment-major copies of the weights
             launch(
                 x_in=xin, x1=P[p + ".x1"], x_out=xout, xn1=P[p + ".xn1"], qkv=P[p + ".qkv"], attn_out=P[p + ".o"],
                 xn2=P[p + ".xn2"], fc1_pre=P[p + ".h"], fc1_act=P[p + ".g"], mean1=P[p + ".mean1"],
                 rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
-                w_qkv=W_.p16(p + ".attn.qkv.weight"), w_proj=W_.p16(p + ".attn.proj.weight"),
-                w_fc1=W_.p16(p + ".mlp.fc1.weight"), w_fc2=W_.p16(p + ".mlp.fc2.weight"),
+                w_qkv=wf(p + ".attn.qkv.weight"), w_proj=wf(p + ".attn.proj.weight"),
+                w_fc1=wf(p + ".mlp.fc1.weight"), w_fc2=wf(p + ".mlp.fc2.weight"),
                 b_qkv=W_.p32(p + ".attn.qkv.bias"), b_proj=W_.p32(p + ".attn.proj.bias"),
                 b_fc1=W_.p32(p + ".mlp.fc1.bias"), b_fc2=W_.p32(p + ".mlp.fc2.bias"),
                 norm1_weight=W_.p32(p + ".norm1.weight"), norm1_bias=W_.p32(p + ".norm1.bias"),
@@ -642,6 +654,34 @@ class TulipEngine:
         else:
             ops.reduce_rows_multi([r])
 
+    def _fold_bias_table(self, P: Plan, tag: str, part, rows: int, nh: int, gtable):
+        """Relative-position-bias gradient of one block: partial rows [rows][nh*256] (dense (head, query, key) sums per
+        workgroup) -> table gradient [45][nh] through the relative-position index (tulip.py:304-308 backwards).  Two
+        steps, both deterministic: the dense fold runs with every other fold of the block (all columns in parallel);
+        the scatter of its [nh*256] result -- one workgroup per head adding the pairs of every table entry in index
+        order -- rides in the NEXT side launch (a region of one row), so no launch is added and no workgroup has to
+        pull a whole partial matrix through one CU."""
+        dense = P.scratch("apd." + tag, nh * 256)
+        self._fold(part, nh * 256, dense, nh * 256, rows, overwrite=True)
+        r = ops.reduce_region(dense, nh * 256, gtable, nh * 256, 1, scatter_index=self._rel32, scatter_nh=nh,
+                              scatter_len=256)
+        if self.overlap_wgrad and self.n_side == 1:
+            self._pending.append(("s", r))
+        elif self.overlap_wgrad:
+            self._pending.append(("f", lambda: ops.reduce_rows_multi([r])))
+        else:
+            ops.reduce_rows_multi([r])
+
+    _carry = ()          # scatter regions waiting for the next side launch
+
+    def _flush_carry(self):
+        """Launch the scatters still waiting (end of the backward / a DDP bucket point) on the side stream."""
+        if self._carry:
+            carry, self._carry = list(self._carry), ()
+            with torch.cuda.stream(self._side_streams[0]):
+                ops.reduce_rows_multi(carry)
+            self._side_dirty = True
+
     group_wgrad = os.environ.get("TULIP_GROUP_WGRAD", "1") != "0"
 
     def _issue_pending(self, ws: int, pending=None):
@@ -649,7 +689,8 @@ class TulipEngine:
         fold in the launch that folds the slabs, other closures last."""
         pending = self._pending if pending is None else pending
         items = [a for k, a in pending if k == "w"]
-        regions = [a for k, a in pending if k == "r"]
+        regions = list(self._carry) + [a for k, a in pending if k == "r"]
+        self._carry = tuple(a for k, a in pending if k == "s")     # their dense sums are produced by THIS launch
         fns = [a for k, a in pending if k == "f"]
         ws_bytes = (self.WS_ELEMS + (1 << 20)) * 4
         if not self.group_wgrad:
@@ -717,6 +758,7 @@ class TulipEngine:
     def _wait_side(self):
         """The current stream waits for everything issued on the side streams so far (queued work stays queued)."""
         self._release_deferred()
+        self._flush_carry()
         if getattr(self, "_side_dirty", False):
             for st in self._side_streams:
                 torch.cuda.current_stream().wait_stream(st)
@@ -725,6 +767,7 @@ class TulipEngine:
     def _join_side(self):
         self._flush_wgrads()
         self._release_deferred()
+        self._flush_carry()
         if getattr(self, "_side_dirty", False):
             for st in self._side_streams:
                 torch.cuda.current_stream().wait_stream(st)
@@ -788,7 +831,7 @@ class TulipEngine:
             ln1, ln2 = P.scratch("lnp." + p + ".1", R * 2 * C), P.scratch("lnp." + p + ".2", R * 2 * C)
             apart = P.scratch("apart." + p, R * nh * 256)
             launch = (lambda **kw: ops.swinw_block_bwd(C, **kw)) if wide else ops.swin96_block_bwd
-            wt = W_.p16t if wide else W_.p16          # the wide kernel streams rows of the TRANSPOSED weights
+            wt = W_.p16t if wide else W_.p16          # the wide kernel streams fragment-major TRANSPOSED weights
             launch(
                 dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=P[p + ".qkv"], fc1_pre=P[p + ".h"], mean1=P[p + ".mean1"],
                 rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
@@ -809,8 +852,7 @@ class TulipEngine:
             self._fold(ln2 + 4 * C, 2 * C, G(p + ".norm2.bias"), C, R)
             self._fold(ln1, 2 * C, G(p + ".norm1.weight"), C, R)
             self._fold(ln1 + 4 * C, 2 * C, G(p + ".norm1.bias"), C, R)
-            self._fold(apart, nh * 256, G(p + ".attn.relative_position_bias_table"), nh * 256, R,
-                       scatter_index=self._rel32, scatter_nh=nh, scatter_len=256)
+            self._fold_bias_table(P, p, apart, R, nh, G(p + ".attn.relative_position_bias_table"))
             if self._lagged_hook is not None:
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
@@ -843,8 +885,7 @@ class TulipEngine:
         apart = P.scratch("apart." + p, R * nh * 256)
         ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
                             apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
-        self._fold(apart, nh * 256, G(p + ".attn.relative_position_bias_table"), nh * 256, R,
-                   scatter_index=self._rel32, scatter_nh=nh, scatter_len=256)
+        self._fold_bias_table(P, p, apart, R, nh, G(p + ".attn.relative_position_bias_table"))
         self._gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
                  out=dxn, ldo=C)
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
@@ -899,7 +940,7 @@ class TulipEngine:
         m, W_ = self.model, self.params
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
-        self._pending, self._lagged_hook, self._deferred = [], None, None     # nothing survives from an aborted earlier call
+        self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
         gbase = gflat.data_ptr()
         G = lambda name: gbase + 4 * W_.offset[name]
         user_hook = bucket_hook or (lambda tag: None)

@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_ATOMIC_F32, EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL,  # noqa: F401
+from ._lib import (EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL,  # noqa: F401
                    EPI_PIXSHUF2_F32, EPI_RESID_F32, EPI_SPLIT_F32, EPI_UNSHUF2_BF16, check)
 
 BF16 = torch.bfloat16
@@ -66,10 +66,6 @@ def layernorm_bwd_partial_rows(rows, C):
 def reduce_rows2(part0, stride0, out0, n0, part1, stride1, out1, n1, nrows):
     check(_lib.load().tulip_reduce_rows2(_p(part0), stride0, _p(out0), n0, _p(part1), stride1, _p(out1), n1, nrows,
                                          _stream()), "tulip_reduce_rows2")
-
-
-def reduce_rows_set(part, stride, out, n, nrows):
-    check(_lib.load().tulip_reduce_rows_set(_p(part), stride, _p(out), n, nrows, _stream()), "tulip_reduce_rows_set")
 
 
 def reduce_region(part, stride, out, n, rows, overwrite=False, scatter_index=None, scatter_nh=0, scatter_len=0):
@@ -139,27 +135,9 @@ def window_attn_bwd(qkv, dout, bias_table, rel_index, dqkv, dbias_dense, B, H, W
     check(rc, "tulip_window_attn_bwd")
 
 
-def bias_table_scatter(dbias_dense, rel_index, dtable, nh, L):
-    check(_lib.load().tulip_bias_table_scatter(_p(dbias_dense), _p(rel_index), _p(dtable), nh, L, _stream()),
-          "tulip_bias_table_scatter")
-
-
 def cast_f32_bf16(x, y, rows, cols, rowscale=None, rows_per_sample=1):
     check(_lib.load().tulip_cast_f32_bf16(_p(x), _p(y), rows, cols, _p(rowscale), rows_per_sample, _stream()),
           "tulip_cast_f32_bf16")
-
-
-def concat_cast(a, b, out, rows, C):
-    check(_lib.load().tulip_concat_cast(_p(a), _p(b), _p(out), rows, C, _stream()), "tulip_concat_cast")
-
-
-def unshuffle2_cast(dx, dz, B, H, W, C2):
-    check(_lib.load().tulip_unshuffle2_cast(_p(dx), _p(dz), B, H, W, C2, _stream()), "tulip_unshuffle2_cast")
-
-
-def cast_colsum(x, y, colsum, rows, cols, rowscale=None, rows_per_sample=1):
-    check(_lib.load().tulip_cast_colsum(_p(x), _p(y), _p(colsum), rows, cols, _p(rowscale), rows_per_sample,
-                                        _stream()), "tulip_cast_colsum")
 
 
 def reduce_splits(slabs, out, n, splits):
@@ -170,12 +148,12 @@ def gemm_effective_splits(K, splits):
     return _lib.load().tulip_gemm_effective_splits(K, splits)
 
 
-def colsum_bf16(x, out, rows, cols):
-    check(_lib.load().tulip_colsum_bf16(_p(x), _p(out), rows, cols, _stream()), "tulip_colsum_bf16")
-
-
 def cast_flat(x, y, n):
     check(_lib.load().tulip_cast_flat(_p(x), _p(y), n, _stream()), "tulip_cast_flat")
+
+
+def cast_bf16_f32(x, y, n):
+    check(_lib.load().tulip_cast_bf16_f32(_p(x), _p(y), n, _stream()), "tulip_cast_bf16_f32")
 
 
 def tail_fwd(xn, We, be, wd, pred, B, H, W, E):
@@ -295,14 +273,19 @@ def swinw_supported(C, H, W) -> bool:
     return bool(_lib.load().tulip_swinw_supported(C, H, W))
 
 
-def swinw_block_fwd(C, out_bf16=None, **kw):
-    """tulip_swinw_block_fwd (C = 192 / 384): keyword arguments are the fields of tulip_swin96_desc."""
+def swinw_block_fwd(C, out_bf16=None, stamps=None, **kw):
+    """tulip_swinw_block_fwd (C = 192 / 384): keyword arguments are the fields of tulip_swin96_desc.
+    stamps (int64 device tensor): the profiled twin, per-wave shader-clock stamps at the phase boundaries."""
     d = _lib.Swin96Desc()
     for name, _t in _lib.Swin96Desc._fields_:
         v = kw.pop(name, None)
         setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
     if kw:
         raise TypeError(f"unknown fields {sorted(kw)}")
+    if stamps is not None:
+        check(_lib.load().tulip_swinw_block_fwd_profiled(ctypes.byref(d), C, _p(out_bf16), _p(stamps), _stream()),
+              "tulip_swinw_block_fwd_profiled")
+        return
     check(_lib.load().tulip_swinw_block_fwd(ctypes.byref(d), C, _p(out_bf16), _stream()), "tulip_swinw_block_fwd")
 
 
@@ -321,16 +304,18 @@ def swinw_block_bwd(C, **kw):
     check(_lib.load().tulip_swinw_block_bwd(ctypes.byref(d), C, _stream()), "tulip_swinw_block_bwd")
 
 
-def transpose_items(pairs):
-    """[(src address, dst address, rows, cols)] -> ctypes array for transpose_bf16_multi (build once, launch often)."""
-    return (_lib.TransposeItem * max(len(pairs), 1))(*[_lib.TransposeItem(_p(s), _p(d), r, c) for s, d, r, c in pairs]), len(pairs)
+def pack_items(entries):
+    """[(src address, dst address, rows, cols, transpose)] -> ctypes array for pack_bf16_multi (build once, launch often)."""
+    return ((_lib.PackItem * max(len(entries), 1))(*[_lib.PackItem(_p(s), _p(d), r, c, int(t)) for s, d, r, c, t in entries]),
+            len(entries))
 
 
-def transpose_bf16_multi(items, n):
-    for k in range(0, n, _lib.TRANSPOSE_MAX):
-        cnt = min(_lib.TRANSPOSE_MAX, n - k)
-        check(_lib.load().tulip_transpose_bf16_multi(ctypes.byref(items, k * ctypes.sizeof(_lib.TransposeItem)), cnt,
-                                                     _stream()), "tulip_transpose_bf16_multi")
+def pack_bf16_multi(items, n):
+    """Fragment-major bf16 copies (optionally of the transpose) of a list of matrices, see include/tulip_hip.h."""
+    for k in range(0, n, _lib.PACK_MAX):
+        cnt = min(_lib.PACK_MAX, n - k)
+        check(_lib.load().tulip_pack_bf16_multi(ctypes.byref(items, k * ctypes.sizeof(_lib.PackItem)), cnt, _stream()),
+              "tulip_pack_bf16_multi")
 
 
 def swin96_bwd_partial_rows(B, H, W) -> int:

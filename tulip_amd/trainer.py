@@ -39,10 +39,13 @@ class Trainer:
     def __init__(self, model, batch_size: int, lr: float = 5e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, device=None, use_graph: bool = True, process_group=None,
                  bucket_mb: float = 16.0, accum_iter: int = 1, track_grad_norm: bool = False,
-                 force_segments: bool = False, bucket_adamw: Optional[bool] = None):
+                 force_segments: bool = False, bucket_adamw: Optional[bool] = None, grad_dtype: str = "fp32"):
         """force_segments: run the N>1 step structure (graph segments cut at the bucket points, one all-reduce per
         bucket between replays) in a one-rank process group too -- how the RCCL path is exercised on a single GPU.
-        bucket_adamw: None = environment default (TULIP_BUCKET_ADAMW, off)."""
+        bucket_adamw: None = environment default (TULIP_BUCKET_ADAMW, off).
+        grad_dtype: "fp32" (DistributedDataParallel's exchange, main_lidar_upsampling.py:277) or "bf16": every bucket is
+        cast to bf16 before its all-reduce (half the bytes on the xGMI links) and back into the fp32 gradient buffer in
+        front of AdamW, whose moments and master weights stay fp32."""
         self.model = model
         device = device or torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -70,6 +73,11 @@ class Trainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucketer = GradBucketer(W.groups, W.total, bucket_mb, process_group, force=force_segments)
         self.segmented = self.bucketer.active          # the step is cut at the bucket points
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
+        self.grad_dtype = grad_dtype
+        self.gb = (torch.zeros(W.total, dtype=torch.bfloat16, device=device)
+                   if (grad_dtype == "bf16" and self.segmented) else None)
         self.use_graph = use_graph
         # N > 1: each bucket is updated (fused AdamW on its slice) on a separate stream as soon as ITS all-reduce has
         # finished, beside the rest of the backward, instead of one update after the last bucket; nothing later in
@@ -124,15 +132,26 @@ class Trainer:
                   self.v.data_ptr() + 4 * lo, W.base16 + 2 * lo, hi - lo, self.hyper,
                   W.decay_mask.data_ptr() + lo // 64, zero_grad=True)
 
-    def _bucket_done(self, tag):
+    def _cast_bucket_down(self, tag):
+        """grad_dtype bf16: the bucket's gradients -> the bf16 exchange buffer (captured at the end of the bucket's graph
+        segment; issued right before the all-reduce in eager mode)."""
+        if self.gb is not None and tag in self.bucketer.by_tag:
+            a, b = self.bucketer.by_tag[tag]
+            ops.cast_flat(self.g.data_ptr() + 4 * a, self.gb.data_ptr() + 2 * a, b - a)
+
+    def _bucket_done(self, tag, cast: bool = False):
         """All-reduce of the bucket that `tag` completes; with bucket_adamw also its optimizer update, ordered behind
         the collective on the optimizer stream (work.wait() is a stream-level dependency for RCCL)."""
-        r = self.bucketer.on_group_done(tag, self.g, keep=not self.bucket_adamw)
+        if cast:
+            self._cast_bucket_down(tag)
+        r = self.bucketer.on_group_done(tag, self.g if self.gb is None else self.gb, keep=not self.bucket_adamw)
         if r is None or not self.bucket_adamw:
             return
         work, a, b = r
         with torch.cuda.stream(self._opt_stream):
             work.wait()
+            if self.gb is not None:
+                ops.cast_bf16_f32(self.gb.data_ptr() + 2 * a, self.g.data_ptr() + 4 * a, b - a)
             self._adamw_range(a, b)
 
     def _finish_buckets(self):
@@ -145,6 +164,8 @@ class Trainer:
 
     def _adamw(self):
         W = self.eng.params
+        if self.gb is not None:                       # the summed bf16 gradients come back into the fp32 buffer
+            ops.cast_bf16_f32(self.gb, self.g, W.total)
         if self.track_grad_norm:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
@@ -199,6 +220,7 @@ class Trainer:
             def hook(tag):
                 nonlocal cur
                 if update and self.segmented and tag in self.bucketer.by_tag:
+                    self._cast_bucket_down(tag)
                     cur.capture_end()
                     segs.append((cur, tag))
                     cur = torch.cuda.CUDAGraph()
@@ -259,7 +281,7 @@ class Trainer:
             self.eng.params.refresh_shadow()
         if not self.use_graph:
             if update:
-                self._fwd_bwd(self._bucket_done)
+                self._fwd_bwd(lambda tag: self._bucket_done(tag, cast=True))
                 if self.segmented:
                     self._finish_buckets()
                 else:
