@@ -157,7 +157,9 @@ def kernel_rooflines(trainer, reps=5):
         for n, fn in real.items():
             setattr(ops, n, fn)
     W = trainer.eng.params
-    rec.append(("adamw", "adamw_kernel", trainer._adamw, 0.0, 28.0 * W.total + 2.0 * W.total))
+    rec.append(("adamw", "adamw_kernel",
+                lambda: ops.adamw(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, W.total, trainer.hyper, W.decay_mask,
+                                  zero_grad=True), 0.0, 28.0 * W.total + 2.0 * W.total))
     fams, detail = {}, {}
     for fam, name, call, fl, by in rec:
         call()

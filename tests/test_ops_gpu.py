@@ -733,3 +733,43 @@ def test_patch_embed_bf16_copy(ops):
                         out_bf16=cat.data_ptr() + 2 * E, ld_bf16=2 * E)
     torch.cuda.synchronize()
     assert torch.equal(cat[:, E:], out.bfloat16()) and not cat[:, :E].any()
+
+
+@pytest.mark.parametrize("shapes", [
+    [(8192, 576, 192, 8), (8192, 192, 192, 4), (8192, 768, 192, 8), (8192, 192, 768, 1)],        # a C = 192 block
+    [(2048, 1152, 384, 2), (2048, 384, 384, 2), (2048, 1536, 384, 2), (2048, 384, 1536, 2)],      # a C = 384 block
+    [(1000, 256, 384, 3), (520, 136, 200, 2)],                                                    # ragged sizes
+    [(512, 2304, 768, 1), (512, 768, 3072, 1)]])                                                  # C = 768, no split
+def test_wgrad_group_wide_stage_shapes(ops, shapes):
+    """tulip_wgrad_group on the problem groups of the wider stages (C = 192 / 384 / 768 blocks, ragged sizes): dW += dY^T . X
+    and db += column sums of dY, split-K slabs folded deterministically (bit-identical from run to run)."""
+    torch.manual_seed(5)
+    items, refs = [], []
+    for Mtok, Nw, Kw, sp in shapes:
+        dY = (torch.randn(Mtok, Nw, device=DEV) * 0.5).bfloat16()
+        X = torch.randn(Mtok, Kw, device=DEV).bfloat16()
+        dW0, db0 = torch.randn(Nw, Kw, device=DEV), torch.randn(Nw, device=DEV)
+        dW, db = dW0.clone(), db0.clone()
+        items.append((ops.wgrad_item(dY, Nw, X, Kw, Nw, Kw, Mtok, dW, db, sp), dY, X, dW, db))
+        refs.append((dW0 + dY.float().t() @ X.float(), db0 + dY.float().sum(0)))
+    ws = torch.empty(16 << 20, device=DEV)
+    ops.wgrad_group([it[0] for it in items], [], ws, ws.numel() * 4)
+    torch.cuda.synchronize()
+    for (it, dY, X, dW, db), (rW, rb) in zip(items, refs):
+        assert torch.isfinite(dW).all()
+        assert ((dW - rW).norm() / rW.norm()).item() < 1e-5
+        assert ((db - rb).norm() / rb.norm()).item() < 1e-5
+    # deterministic: a second run gives the same bits
+    again = []
+    for (it, dY, X, dW, db), (Mtok, Nw, Kw, sp) in zip(items, shapes):
+        d2, b2 = torch.zeros(Nw, Kw, device=DEV), torch.zeros(Nw, device=DEV)
+        again.append((ops.wgrad_item(dY, Nw, X, Kw, Nw, Kw, Mtok, d2, b2, sp), d2, b2))
+    for rep in range(2):
+        for _, d2, b2 in again:
+            d2.zero_(); b2.zero_()
+        ops.wgrad_group([a[0] for a in again], [], ws, ws.numel() * 4)
+        torch.cuda.synchronize()
+        if rep == 0:
+            first = [(d2.clone(), b2.clone()) for _, d2, b2 in again]
+    for (f0, f1), (_, d2, b2) in zip(first, again):
+        assert torch.equal(f0, d2) and torch.equal(f1, b2)
