@@ -23,7 +23,7 @@ def _model(seed):
             if p.ndim == 1 or "relative_position_bias_table" in n:
                 p.add_(0.2 * torch.randn_like(p))
     eng = m.engine()
-    eng.wide_widths = (192, 384)                              # both widths of the fused kernel (384 is opt-in in the engine)
+    eng.wide_min_windows = 0                                  # C = 384 fused at any batch size (the engine waits for 256 windows)
     eng.bind(torch.device(DEV, torch.cuda.current_device()))
     eng.params.refresh_shadow()
     return m, eng

@@ -154,22 +154,27 @@ class FlatParams:
         self.refresh_transposes()
         self.shadow_dirty = False
 
-    def make_packed(self, names: List[str], with_transposes: bool):
+    def make_packed(self, names_by_width: Dict[int, List[str]], with_transposes: bool):
         """Fragment-major bf16 copies of the given 2-D weights, and of their transposes (what the fused wide-block kernels
-        stream, csrc/swinw.hip); refreshed from the shadow by refresh_transposes()."""
+        stream, csrc/swinw.hip), grouped by block width; refresh_transposes() rewrites the copies of the widths some plan
+        actually runs fused (`pk_active`) from the shadow."""
         self.pk_offset: Dict[str, int] = {}
         off = 0
-        for n in names:
-            self.pk_offset[n] = off
-            off = _ceil(off + self.numel[n], ALIGN)
+        for names in names_by_width.values():
+            for n in names:
+                self.pk_offset[n] = off
+                off = _ceil(off + self.numel[n], ALIGN)
         self.packed = torch.zeros(max(off, ALIGN), dtype=torch.bfloat16, device=self.device)
         self.packed_t = torch.zeros(max(off, ALIGN) if with_transposes else ALIGN, dtype=torch.bfloat16, device=self.device)
-        ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
-               for n in names]
-        if with_transposes:
-            ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
-                    for n in names]
-        self._pk_items, self._pk_n = ops.pack_items(ent)
+        self._pk_lists = {}
+        for width, names in names_by_width.items():
+            ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
+                   for n in names]
+            if with_transposes:
+                ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
+                        for n in names]
+            self._pk_lists[width] = ops.pack_items(ent)
+        self.pk_active = set()
 
     def p16p(self, name: str) -> int:
         return self.packed.data_ptr() + 2 * self.pk_offset[name]
@@ -178,8 +183,10 @@ class FlatParams:
         return self.packed_t.data_ptr() + 2 * self.pk_offset[name]
 
     def refresh_transposes(self):
-        if getattr(self, "_pk_n", 0):
-            ops.pack_bf16_multi(self._pk_items, self._pk_n)
+        for width in sorted(getattr(self, "pk_active", ())):
+            items, n = self._pk_lists[width]
+            if n:
+                ops.pack_bf16_multi(items, n)
 
 
 class Plan:
@@ -363,10 +370,13 @@ class TulipEngine:
         self.plans.clear()
         self._graphs.clear()
         self.params = FlatParams(self.model, device)
-        self.params.make_packed([sp.prefix + suffix for sp in self.blocks if self._fusable_wide(sp)
-                                 for suffix in (".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight",
-                                                ".mlp.fc2.weight")] if (self.fuse_wide or self.fuse_wide_bwd) else [],
-                                with_transposes=self.fuse_wide_bwd)
+        by_width: Dict[int, List[str]] = {}
+        if self.fuse_wide or self.fuse_wide_bwd:
+            for sp in self.blocks:
+                if self._fusable_wide(sp):
+                    by_width.setdefault(sp.C, []).extend(sp.prefix + suffix for suffix in (
+                        ".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"))
+        self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd)
         rel = self.model.layers[0].blocks[0].attn.relative_position_index
         self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
         rates = torch.ones(max(1, self.n_drop_slots), 1)
@@ -383,6 +393,12 @@ class TulipEngine:
     def plan(self, B: int) -> Plan:
         if B not in self.plans:
             self.plans[B] = Plan(self, B)
+            # block widths this batch size runs fused: their weight copies are maintained from now on
+            widths = {sp.C for sp in self.blocks if (self.fuse_wide or self.fuse_wide_bwd) and self._fusable_wide(sp, B)}
+            if not widths <= self.params.pk_active:
+                self.params.pk_active |= widths
+                if not self.params.shadow_dirty:
+                    self.params.refresh_transposes()
         if getattr(self, "_ws", None) is None or self._ws.device != self.device:
             self._ws = torch.empty(self.WS_ELEMS + (1 << 20), dtype=torch.float32, device=self.device)
             self._ws_ptr = self._ws.data_ptr()
@@ -425,18 +441,24 @@ class TulipEngine:
 
     fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
     fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
-    # C = 192 by default.  C = 384 (stage 2: 3.5 MB of weights per block, 2048 tokens at batch 8) is parity-tested and can be
-    # switched on, but is no faster than the 7-kernel sequences there: every workgroup streams the whole weight set through
-    # its own CU (66 + 65 us against 62 + 86 us isolated, equal inside the step); it pays from batch 16 up.
-    wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192").split(",") if c)
+    # C = 192 always; C = 384 (stage 2: 3.5 MB of weights per block) from 256 windows per launch up (batch 16 at the KITTI
+    # size).  Every workgroup streams the block's whole weight set through its own CU, so with the 128 windows = 64
+    # workgroups of batch 8 the fused form only ties the 7-kernel sequences (66 + 65 us against 62 + 86 us isolated, 2.896 vs
+    # 2.862 ms in the step); at batch 16 / 32 / 64 it wins 3 / 5 / 4.5 % of the step.  TULIP_FUSE_WIDE_MIN_WINDOWS overrides.
+    wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192,384").split(",") if c)
+    wide_min_windows = int(os.environ.get("TULIP_FUSE_WIDE_MIN_WINDOWS", "256"))
 
-    def _fusable_wide(self, sp: BlockSpec) -> bool:
-        """csrc/swinw.hip covers C = 192 / 384: heads of 32, window 2x8, MLP C -> 4C -> C."""
-        return (sp.C in self.wide_widths and sp.C in (192, 384) and sp.nh * 32 == sp.C and self.hidden(sp.C) == 4 * sp.C
-                and tuple(sp.win) == (2, 8) and sp.W % 16 == 0 and sp.H % 2 == 0)
+    def _fusable_wide(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
+        """csrc/swinw.hip covers C = 192 / 384: heads of 32, window 2x8, MLP C -> 4C -> C.  B = None: could the block ever
+        be fused (weight copies are kept for it); with a batch size: is it fused in that plan."""
+        ok = (sp.C in self.wide_widths and sp.C in (192, 384) and sp.nh * 32 == sp.C and self.hidden(sp.C) == 4 * sp.C
+              and tuple(sp.win) == (2, 8) and sp.W % 16 == 0 and sp.H % 2 == 0)
+        if ok and B is not None and sp.C == 384:
+            ok = B * (sp.H // 2) * (sp.W // 8) >= self.wide_min_windows
+        return ok
 
-    def _fused_bwd(self, sp: BlockSpec) -> bool:
-        return (self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp))
+    def _fused_bwd(self, sp: BlockSpec, B: int) -> bool:
+        return (self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
 
     def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout, out_bf16=None):
         """out_bf16: the block output also leaves as a bf16 [M][C] copy (operand of a PatchUnmerging GEMM)."""
@@ -444,7 +466,7 @@ class TulipEngine:
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
-        wide = self.fuse_wide and self._fusable_wide(sp)
+        wide = self.fuse_wide and self._fusable_wide(sp, B)
         if wide or (self.fuse_block96 and self._fusable96(sp)):
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
             launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
@@ -805,7 +827,7 @@ class TulipEngine:
 
     def _mlp_cast(self, P: Plan, sp: BlockSpec):
         """What the producer of this block's incoming gradient should emit: (dyb_m, DropPath scale, tokens)."""
-        if self._fused_bwd(sp):
+        if self._fused_bwd(sp, P.B):
             return None                     # the fused block backward forms its own operand from the fp32 gradient
         return (P[sp.prefix + ".dyb_m"], self._ds(P, sp, 1), sp.H * sp.W)
 
@@ -819,7 +841,7 @@ class TulipEngine:
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
         dxn, dO, dh, dqkv = P["t.dxn"], P["t.do"], P[p + ".dh"], P[p + ".dqkv"]
         dyb = P[p + ".dyb_m"]
-        if self._fused_bwd(sp):
+        if self._fused_bwd(sp, B):
             # the whole data-gradient chain of the block in one launch (csrc/swin96.hip, csrc/swinw.hip); the weight
             # gradients and the folds of its per-workgroup partial rows run beside the chain exactly as for the unfused
             # sequence
