@@ -739,6 +739,7 @@ def test_patch_embed_bf16_copy(ops):
     [(8192, 576, 192, 8), (8192, 192, 192, 4), (8192, 768, 192, 8), (8192, 192, 768, 1)],        # a C = 192 block
     [(2048, 1152, 384, 2), (2048, 384, 384, 2), (2048, 1536, 384, 2), (2048, 384, 1536, 2)],      # a C = 384 block
     [(1000, 256, 384, 3), (520, 136, 200, 2)],                                                    # ragged sizes
+    [(1000, 192, 384, 3), (520, 576, 192, 2), (72, 384, 96, 1), (4104, 96, 288, 5)],              # ragged token counts, large tiles
     [(512, 2304, 768, 1), (512, 768, 3072, 1)]])                                                  # C = 768, no split
 def test_wgrad_group_wide_stage_shapes(ops, shapes):
     """tulip_wgrad_group on the problem groups of the wider stages (C = 192 / 384 / 768 blocks, ragged sizes): dW += dY^T . X

@@ -457,6 +457,204 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
     gemm_tile<BM, A_T, B_T, KSUB>(p, bx, b % G.gy[i], b / G.gy[i]);
 }
 
+// ---- weight gradients, large tiles ------------------------------------------------------------------------------
+// dW[N,K] = dY^T . X over a chunk of tokens, both operands token-major (the A_T, B_T form).  The 64 x 96 tile of gemm_tile
+// re-reads every operand element N/64 resp. K/96 times through the texture path and issues 10 transpose reads for 6 MFMAs
+// per wave and k-step; here a workgroup owns (GM*96) x (GN*96) outputs, one 96 x 96 tile per wave: 36 accumulator
+// fragments in registers (one wave per SIMD), 24 transpose reads for 36 MFMAs, and a third of the operand traffic.
+// GM x GN = 2 x 2 (192 x 192: every linear of stages 1-3), 4 x 1 (384 x 96) and 1 x 4 (96 x 384) for the C = 96 stage.
+// Each k-step's operands are [32 tokens][96 columns] sub-tiles in the k-slow LDS layout of Stage<96, true> (pitch 288 B).
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+constexpr int WG_SUB = 32 * T_PITCH;          // bytes of one sub-tile
+constexpr int WG_STG_PITCH = 96 * 4 + 16;     // fp32 write-out staging row
+constexpr int WG_LDS_BYTES = 2 * 5 * WG_SUB;  // double-buffered 4 x 1 stage (the 2 x 2 stage is 4 sub-tiles)
+
+template <int GM, int GN, int RING>
+__device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, const int by, const int bz,
+                                           unsigned char* __restrict__ smem) {
+    static_assert(GM * GN == 4, "four waves");
+    constexpr int SUBS = GM + GN;
+    constexpr int STAGE = SUBS * WG_SUB;
+    constexpr bool A_FIRST = GM >= GN;                 // the wider operand first: its chunk count is a multiple of 256
+    constexpr int G1 = A_FIRST ? GM : GN, G2 = A_FIRST ? GN : GM;
+    constexpr int NCH = SUBS * 384;                    // 16-B chunks of one k-step
+    constexpr int PT = (NCH + 255) / 256;
+    constexpr int I1 = G1 * 384 / 256;                 // chunk slots (per thread) of the first operand
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / GN, wn = wid % GN;
+    const int m0 = by * (GM * 96), n0 = bx * (GN * 96);
+    const int kbeg = bz * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nt = (kend - kbeg + 31) >> 5;
+
+    // per-thread chunk slots: global address of k-step 0, LDS offset, token row inside the k-step
+    const bf16_t* gp[PT];
+    int loff[PT], krow[PT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const bool first = i < I1;
+        const bool isA = first == A_FIRST;
+        const int G = first ? G1 : G2;
+        const int cc = tid + i * 256 - (first ? 0 : G1 * 384);
+        const int k = cc / (12 * G), mc = cc - k * (12 * G);
+        const int sub = mc / 12, mcs = mc - sub * 12;
+        const int col = (isA ? m0 : n0) + mc * 8;
+        const bool ok = (first || cc < G2 * 384) && col < (isA ? p.M : p.N);
+        okmask |= (ok ? 1u : 0u) << i;
+        gp[i] = (isA ? p.A : p.B) + (size_t)(kbeg + (ok ? k : 0)) * (isA ? p.lda : p.ldb) + (ok ? col : 0);
+        krow[i] = k;
+        loff[i] = ((isA ? sub : GM + sub) * WG_SUB) + k * T_PITCH + ((((mcs >> 1) ^ (((k >> 3) & 1) << 2))) << 5) +
+                  ((mcs & 1) << 4);
+    }
+    const size_t stepA = (size_t)32 * p.lda, stepB = (size_t)32 * p.ldb;
+
+    uint4 ring[RING][PT];
+    auto issue = [&](auto R, int t) {
+        constexpr int r = decltype(R)::value;
+        const int rows = kend - (kbeg + t * 32);       // valid token rows of this k-step
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const bool isA = (i < I1) == A_FIRST;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (((okmask >> i) & 1) && krow[i] < rows) v = *(const uint4*)(gp[i] + (size_t)t * (isA ? stepA : stepB));
+            ring[r][i] = v;
+        }
+    };
+    auto stash = [&](auto R, unsigned char* dst) {
+        constexpr int r = decltype(R)::value;
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+            if (NCH % 256 == 0 || i < PT - 1 || tid + i * 256 < NCH) *(uint4*)(dst + loff[i]) = ring[r][i];
+    };
+
+    f32x4 acc[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 rsum[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    static_for<RING - 1>([&](auto R) { if (nt > decltype(R)::value) issue(R, decltype(R)::value); });
+    if (nt > 0) stash(std::integral_constant<int, 0>{}, smem);
+    __syncthreads();
+
+    const int g = lane >> 4, li = lane & 15;
+    const int fbase = (g * 8 + (li >> 2)) * T_PITCH + ((li & 3) << 3);
+    const int fsw = (g & 1) << 7;                      // the 32-B chunk swizzle of the odd 8-row groups
+    const bool active = m0 + wm * 96 < p.M && n0 + wn * 96 < p.N;      // wave-uniform
+    const bool do_rowsum = active && p.out2 != nullptr && bx == 0 && wn == 0;
+    const short one = (short)0x3F80;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+    auto step = [&](auto R, int t) {
+        constexpr int r = decltype(R)::value;
+        const int cur = t & 1;
+        if (t + RING - 1 < nt) issue(std::integral_constant<int, (r + RING - 1) % RING>{}, t + RING - 1);
+        if (active) {
+            const unsigned char* la = smem + cur * STAGE + wm * WG_SUB + fbase;
+            const unsigned char* lb = smem + cur * STAGE + (GM + wn) * WG_SUB + fbase;
+            bf16x8 af[6], bfr[6];
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                const int o = (f << 5) ^ fsw;
+                const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o));
+                const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o + 4 * T_PITCH));
+                const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o));
+                const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o + 4 * T_PITCH));
+                af[f] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                bfr[f] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], rsum[i], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) stash(std::integral_constant<int, (r + 1) % RING>{}, smem + (cur ^ 1) * STAGE);
+        __syncthreads();
+    };
+    for (int t = 0; t < nt; t += RING)
+        static_for<RING>([&](auto R) { if (t + decltype(R)::value < nt) step(R, t + decltype(R)::value); });
+
+    // write-out: each wave stages 32 rows of its own tile at a time and stores them as full 384-B rows
+    if (!active) return;
+    unsigned char* wst = smem + wid * (32 * WG_STG_PITCH);
+    const bool split = p.epi == TULIP_EPI_SPLIT_F32;
+    float* obase = (float*)p.out + (split ? (size_t)bz * p.M * p.ldo : 0);
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                *(f32x4*)(wst + (ii * 16 + li) * WG_STG_PITCH + (j * 16 + g * 4) * 4) = acc[ps * 2 + ii][j];
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int c = lane + it * 64;
+            const int rl = c / 24, c4 = c - rl * 24;
+            const int m = m0 + wm * 96 + ps * 32 + rl, n = n0 + wn * 96 + c4 * 4;
+            if (m < p.M && n < p.N) {
+                float4 v = *(const float4*)(wst + rl * WG_STG_PITCH + c4 * 16);
+                float* o = obase + (size_t)m * p.ldo + n;
+                if (!split && p.accumulate) {
+                    const float4 q = *(const float4*)o;
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                *(float4*)o = v;
+            }
+        }
+    }
+    if (do_rowsum && g == 0) {
+        float* rs = (float*)p.out2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int m = m0 + wm * 96 + i * 16 + li;
+            if (m >= p.M) continue;
+            if (split) rs[(size_t)bz * p.M + m] = rsum[i][0];
+            else if (p.accumulate) rs[m] += rsum[i][0];
+            else rs[m] = rsum[i][0];
+        }
+    }
+}
+
+struct WgradGroup {
+    GemmArgs g[GROUP_MAX];
+    int first[GROUP_MAX + 1];
+    int gx[GROUP_MAX], gy[GROUP_MAX], shape[GROUP_MAX];
+    int n;
+};
+#ifndef TULIP_WGRAD_BIG_RING
+#define TULIP_WGRAD_BIG_RING 4
+#endif
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS_BYTES];
+    // workgroup b runs on XCD b % 8: neighbours in the (token chunk, tile) order -- tiles of one chunk share its
+    // operand rows -- are given to the same XCD's L2, 8 launch slots apart
+    int b = blockIdx.x;
+    const int nb8 = (int)gridDim.x & ~7;
+    if (b < nb8) b = (b & 7) * (nb8 >> 3) + (b >> 3);
+    int i = 0;
+    while (i + 1 < G.n && b >= G.first[i + 1]) ++i;
+    b -= G.first[i];
+    const int tiles = G.gx[i] * G.gy[i];
+    const int bz = b / tiles;
+    b -= bz * tiles;
+    const int by = b / G.gx[i], bx = b - by * G.gx[i];
+    const GemmArgs p = G.g[i];
+    switch (G.shape[i]) {
+        case 0: wgrad_tile<2, 2, TULIP_WGRAD_BIG_RING>(p, bx, by, bz, smem); break;
+        case 1: wgrad_tile<4, 1, TULIP_WGRAD_BIG_RING>(p, bx, by, bz, smem); break;
+        default: wgrad_tile<1, 4, TULIP_WGRAD_BIG_RING>(p, bx, by, bz, smem); break;
+    }
+}
+
 // split-K for the ordinary epilogues: the GEMM wrote raw fp32 partial slabs [splits][M][N]; fold them
 // and apply the fused epilogue (bias / GELU / residual / ...) once.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, const float* __restrict__ slabs,
@@ -557,12 +755,38 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
 
 extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream);
 
+// tile shape of the large-tile weight-gradient kernel for a [Nw][Kw] gradient: 0 = 192 x 192, 1 = 384 x 96, 2 = 96 x 384,
+// -1 = none (the 64 x 96 tile of gemm_group_kernel)
+static int g_wgrad_mode = 1;
+static int wgrad_shape(int Nw, int Kw) {
+    if (!g_wgrad_mode) return -1;
+    if (Nw % 192 == 0 && Kw % 192 == 0) return 0;
+    if (Kw == 96 && Nw % 96 == 0) return 1;
+    if (Nw == 96 && Kw % 96 == 0) return 2;
+    return -1;
+}
+static void wgrad_tile_grid(int shape, int Nw, int Kw, int* gx, int* gy) {
+    const int tm = shape == 0 ? 192 : shape == 1 ? 384 : shape == 2 ? 96 : 64;
+    const int tn = shape == 0 ? 192 : shape == 1 ? 96 : shape == 2 ? 384 : BN;
+    *gx = (Kw + tn - 1) / tn;
+    *gy = (Nw + tm - 1) / tm;
+}
+extern "C" void tulip_wgrad_set_mode(int mode) { g_wgrad_mode = mode; }
+extern "C" int tulip_wgrad_tiles(int Nw, int Kw) {
+    int gx, gy;
+    wgrad_tile_grid(wgrad_shape(Nw, Kw), Nw, Kw, &gx, &gy);
+    return gx * gy;
+}
+
 extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
                                  void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream) {
     if (n < 0 || n > GROUP_MAX || n_extra < 0 || n + n + n_extra > TULIP_REDUCE_REGIONS_MAX || (n && !items) ||
         (n_extra && !extra))
         return TULIP_ERR_ARG;
-    GemmGroup G;
+    bool big = true;
+    for (int i = 0; i < n; ++i)
+        if (items[i].Nw > 0 && items[i].Kw > 0 && items[i].Mtok > 0 && wgrad_shape(items[i].Nw, items[i].Kw) < 0) big = false;
+    WgradGroup G;
     tulip_reduce_region folds[TULIP_REDUCE_REGIONS_MAX];
     int nf = 0;
     int64_t ws_used = 0;                       // floats
@@ -595,18 +819,26 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
         } else {
             p.epi = TULIP_EPI_F32; p.accumulate = 1; p.out = it.dW; p.out2 = it.db;
         }
-        G.gx[G.n] = (it.Kw + BN - 1) / BN;
-        G.gy[G.n] = (it.Nw + 63) / 64;
+        G.shape[G.n] = big ? wgrad_shape(it.Nw, it.Kw) : -1;
+        wgrad_tile_grid(G.shape[G.n], it.Nw, it.Kw, &G.gx[G.n], &G.gy[G.n]);
         G.first[G.n + 1] = G.first[G.n] + G.gx[G.n] * G.gy[G.n] * splits;
         deep = deep && kchunk >= 256;
         ++G.n;
     }
     if (G.n > 0) {
         const int blocks = G.first[G.n];
-        if (blocks <= TULIP_GEMM_KSUB_GRID && deep)
-            hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 4>), dim3(blocks), dim3(256), 0, stream, G);
-        else
-            hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 1>), dim3(blocks), dim3(256), 0, stream, G);
+        if (big) {
+            hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(256), 0, stream, G);
+        } else {
+            GemmGroup S;
+            S.n = G.n;
+            for (int i = 0; i < G.n; ++i) { S.g[i] = G.g[i]; S.gx[i] = G.gx[i]; S.gy[i] = G.gy[i]; }
+            for (int i = 0; i <= G.n; ++i) S.first[i] = G.first[i];
+            if (blocks <= TULIP_GEMM_KSUB_GRID && deep)
+                hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 4>), dim3(blocks), dim3(256), 0, stream, S);
+            else
+                hipLaunchKernelGGL((gemm_group_kernel<64, true, true, 1>), dim3(blocks), dim3(256), 0, stream, S);
+        }
         TULIP_CHECK_LAUNCH();
     }
     if (!fold) return TULIP_OK;

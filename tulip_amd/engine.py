@@ -302,6 +302,7 @@ class TulipEngine:
     def __init__(self, model):
         self.model = model
         self.device = None
+        ops.wgrad_set_mode(int(os.environ.get("TULIP_WGRAD_TILES", "1")))
         self.params: Optional[FlatParams] = None
         self.plans: Dict[int, Plan] = {}
         m = model
@@ -605,11 +606,16 @@ class TulipEngine:
     # quarter of what "fill the chip" splitting (256 tokens) produced: step 4.07 -> 3.96 ms.
     WGRAD_CTAS = int(os.environ.get("TULIP_WGRAD_CTAS", "512"))
     WGRAD_MINK = int(os.environ.get("TULIP_WGRAD_MINK", "1024"))
+    WGRAD_BIG_CTAS = int(os.environ.get("TULIP_WGRAD_BIG_CTAS", "256"))
+    WGRAD_BIG_MINK = int(os.environ.get("TULIP_WGRAD_BIG_MINK", "512"))
 
     @classmethod
-    def _splits(cls, Mout: int, Nout: int, K: int) -> int:
-        tiles = ((Mout + 127) // 128) * ((Nout + 95) // 96)
-        s = max(1, min(cls.WGRAD_CTAS // max(tiles, 1), K // cls.WGRAD_MINK, cls.WS_ELEMS // (Mout * Nout)))
+    def _splits(cls, Mout: int, Nout: int, K: int, group_tiles: int = 0) -> int:
+        if group_tiles:  # large tiles (192 x 192 / 384 x 96 / 96 x 384), `group_tiles` of them per split in this launch
+            s = max(1, min(cls.WGRAD_BIG_CTAS // group_tiles, K // cls.WGRAD_BIG_MINK, cls.WS_ELEMS // (Mout * Nout)))
+        else:
+            tiles = ((Mout + 127) // 128) * ((Nout + 95) // 96)
+            s = max(1, min(cls.WGRAD_CTAS // max(tiles, 1), K // cls.WGRAD_MINK, cls.WS_ELEMS // (Mout * Nout)))
         while True:  # the kernel cuts K in multiples of 32: iterate to the split count it really launches
             e = ops.gemm_effective_splits(K, s)
             if e == s:
@@ -722,9 +728,14 @@ class TulipEngine:
         from . import _lib
         while items:
             grp, used = [], 0
+            cand = items[:_lib.WGRAD_GROUP_MAX]
+            big = all(ops.wgrad_tiles(a[4], a[5]) != ((a[4] + 63) // 64) * ((a[5] + 95) // 96) for a in cand)
+            # large tiles run one workgroup per CU: the token splits of a launch are sized so that the whole group is
+            # about one round of the chip
+            group_tiles = sum(ops.wgrad_tiles(a[4], a[5]) for a in cand) if big else 0
             while items and len(grp) < _lib.WGRAD_GROUP_MAX:
                 dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias = items[0]
-                sp = self._splits(Nw, Kw, Mtok)
+                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles)
                 need = (Nw * Kw + Nw) * sp * 4 if sp > 1 else 0
                 if grp and used + need > ws_bytes:
                     break

@@ -85,6 +85,16 @@ def reduce_rows_multi(regions):
     check(_lib.load().tulip_reduce_rows_multi(arr, len(regions), _stream()), "tulip_reduce_rows_multi")
 
 
+def wgrad_tiles(Nw, Kw):
+    """Workgroup tiles per token split of a [Nw][Kw] weight gradient in the grouped launch (tulip_wgrad_tiles)."""
+    return _lib.load().tulip_wgrad_tiles(Nw, Kw)
+
+
+def wgrad_set_mode(mode):
+    """1 (default): large weight-gradient tiles where the shape allows; 0: the 64 x 96 tile everywhere."""
+    _lib.load().tulip_wgrad_set_mode(int(mode))
+
+
 def wgrad_group(items, extra, workspace, workspace_bytes, fold=True):
     """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions."""
     ia = (_lib.WgradItem * max(len(items), 1))(*items)
