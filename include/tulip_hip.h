@@ -90,7 +90,7 @@ int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_r
  * both dimensions are multiples of 192, 384 x 96 / 96 x 384 for the 96-wide stage, else 64 x 96): what a caller sizes
  * `splits` with.  tulip_wgrad_set_mode(0) forces the 64 x 96 tile everywhere (A/B measurements); default 1. */
 int tulip_wgrad_tiles(int Nw, int Kw);
-void tulip_wgrad_set_mode(int mode);
+int tulip_wgrad_set_mode(int mode);
 
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);

@@ -771,7 +771,7 @@ static void wgrad_tile_grid(int shape, int Nw, int Kw, int* gx, int* gy) {
     *gx = (Kw + tn - 1) / tn;
     *gy = (Nw + tm - 1) / tm;
 }
-extern "C" void tulip_wgrad_set_mode(int mode) { g_wgrad_mode = mode; }
+extern "C" int tulip_wgrad_set_mode(int mode) { g_wgrad_mode = mode; return TULIP_OK; }
 extern "C" int tulip_wgrad_tiles(int Nw, int Kw) {
     int gx, gy;
     wgrad_tile_grid(wgrad_shape(Nw, Kw), Nw, Kw, &gx, &gy);
