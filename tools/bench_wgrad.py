@@ -9,6 +9,7 @@ from tulip_amd.engine import TulipEngine as Engine
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, nargs="+", default=[8, 64])
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--modes", type=lambda x: int(x, 0), nargs="+", default=[0, 1])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ws = torch.empty((Engine.WS_ELEMS + (1 << 20)), device=dev)
@@ -36,10 +37,10 @@ for B in a.batch:
             bufs.append((dY, X, torch.zeros(Nw, Kw, device=dev), torch.zeros(Nw, device=dev)))
         fl = sum(2.0 * tok * Nw * Kw for Nw, Kw in shapes)
         line = f"B={B:3d} C={C:3d} tok={tok:6d}"
-        for mode in (0, 1):
+        for mode in a.modes:
             ops.wgrad_set_mode(mode)
             items, nwg, slab = [], 0, 0
-            gt = sum(ops.wgrad_tiles(Nw, Kw) for Nw, Kw in shapes) if mode else 0
+            gt = sum(ops.wgrad_tiles(Nw, Kw) for Nw, Kw in shapes) if mode & 1 else 0
             sps = [Engine._splits(Nw, Kw, tok, group_tiles=gt) for Nw, Kw in shapes]
             while sum((Nw * Kw + Nw) * sp * 4 for (Nw, Kw), sp in zip(shapes, sps) if sp > 1) > ws.numel() * 4:
                 sps = [max(1, sp // 2) for sp in sps]       # (the engine starts a second launch instead)
@@ -49,6 +50,6 @@ for B in a.batch:
                 items.append(ops.wgrad_item(dY, Nw, X, Kw, Nw, Kw, tok, dW, db, sp))
             t0 = timeit(items, False, a.reps)
             t1 = timeit(items, True, a.reps)
-            line += f" | mode {mode}: {nwg:5d} wg, slabs {slab / 1e6:6.1f} MB, gemm {t0:7.1f} us ({fl / t0 / 1e6:6.1f} TF/s), +fold {t1:7.1f} us"
+            line += f" | mode {mode:#x}: {nwg:5d} wg, slabs {slab / 1e6:6.1f} MB, gemm {t0:7.1f} us ({fl / t0 / 1e6:6.1f} TF/s), +fold {t1:7.1f} us"
         print(line, flush=True)
 ops.wgrad_set_mode(1)

@@ -486,11 +486,15 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg + 31) >> 5;
+    if (nt <= 0) return;                               // (uniform; the launcher never creates an empty chunk)
 
-    // per-thread chunk slots: global address of k-step 0, LDS offset, token row inside the k-step
-    const bf16_t* gp[PT];
-    int loff[PT], krow[PT];
-    unsigned okmask = 0;
+    // per-thread chunk slots: byte offset inside a k-step's operand rows (32-bit, added to a wave-uniform base that
+    // advances by 32 token rows per k-step) and the LDS offset.  Everything in the k-loop is unconditional: the token
+    // count is a multiple of 32 (the launcher's condition for this kernel); sub-tiles beyond M / N are never read (M, N
+    // are multiples of 96, only inactive waves own them), so their slots load the k-step's first chunk; the slots past
+    // the end of the chunk list (4 x 1 / 1 x 4: 7.5 per thread) write into the unused last 32 B of a sub-tile row.
+    unsigned goff[PT];
+    int loff[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const bool first = i < I1;
@@ -500,32 +504,31 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
         const int k = cc / (12 * G), mc = cc - k * (12 * G);
         const int sub = mc / 12, mcs = mc - sub * 12;
         const int col = (isA ? m0 : n0) + mc * 8;
-        const bool ok = (first || cc < G2 * 384) && col < (isA ? p.M : p.N);
-        okmask |= (ok ? 1u : 0u) << i;
-        gp[i] = (isA ? p.A : p.B) + (size_t)(kbeg + (ok ? k : 0)) * (isA ? p.lda : p.ldb) + (ok ? col : 0);
-        krow[i] = k;
-        loff[i] = ((isA ? sub : GM + sub) * WG_SUB) + k * T_PITCH + ((((mcs >> 1) ^ (((k >> 3) & 1) << 2))) << 5) +
-                  ((mcs & 1) << 4);
+        const bool real = first || cc < G2 * 384;
+        const bool ok = real && col < (isA ? p.M : p.N);
+        goff[i] = ok ? (unsigned)(k * (isA ? p.lda : p.ldb) + col) * 2u : 0u;
+        loff[i] = real ? ((isA ? sub : GM + sub) * WG_SUB) + k * T_PITCH + ((((mcs >> 1) ^ (((k >> 3) & 1) << 2))) << 5) +
+                             ((mcs & 1) << 4)
+                       : (tid & 31) * T_PITCH + 256 + ((tid >> 5) & 1) * 16;
     }
-    const size_t stepA = (size_t)32 * p.lda, stepB = (size_t)32 * p.ldb;
+    const unsigned char* baseA = (const unsigned char*)(p.A + (size_t)kbeg * p.lda);
+    const unsigned char* baseB = (const unsigned char*)(p.B + (size_t)kbeg * p.ldb);
 
-    uint4 ring[RING][PT];
+    // (a native vector type: a struct uint4 assigned straight from memory becomes a memcpy into the array, which keeps
+    // the whole ring in scratch)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t ring[RING][PT];
     auto issue = [&](auto R, int t) {
         constexpr int r = decltype(R)::value;
-        const int rows = kend - (kbeg + t * 32);       // valid token rows of this k-step
+        const unsigned char* a = baseA + (size_t)t * 64 * p.lda;
+        const unsigned char* b = baseB + (size_t)t * 64 * p.ldb;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const bool isA = (i < I1) == A_FIRST;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (((okmask >> i) & 1) && krow[i] < rows) v = *(const uint4*)(gp[i] + (size_t)t * (isA ? stepA : stepB));
-            ring[r][i] = v;
-        }
+        for (int i = 0; i < PT; ++i) ring[r][i] = *(const u32x4_t*)(((i < I1) == A_FIRST ? a : b) + goff[i]);
     };
     auto stash = [&](auto R, unsigned char* dst) {
         constexpr int r = decltype(R)::value;
 #pragma unroll
-        for (int i = 0; i < PT; ++i)
-            if (NCH % 256 == 0 || i < PT - 1 || tid + i * 256 < NCH) *(uint4*)(dst + loff[i]) = ring[r][i];
+        for (int i = 0; i < PT; ++i) *(u32x4_t*)(dst + loff[i]) = ring[r][i];
     };
 
     f32x4 acc[6][6];
@@ -533,13 +536,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 rsum[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    static_for<RING - 1>([&](auto R) { if (nt > decltype(R)::value) issue(R, decltype(R)::value); });
-    if (nt > 0) stash(std::integral_constant<int, 0>{}, smem);
-    __syncthreads();
+    f32x4 rsum = (f32x4){0.f, 0.f, 0.f, 0.f};          // bias gradient: row sums of the six A fragments, one per MFMA column
 
     const int g = lane >> 4, li = lane & 15;
     const int fbase = (g * 8 + (li >> 2)) * T_PITCH + ((li & 3) << 3);
@@ -547,37 +544,56 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     const bool active = m0 + wm * 96 < p.M && n0 + wn * 96 < p.N;      // wave-uniform
     const bool do_rowsum = active && p.out2 != nullptr && bx == 0 && wn == 0;
     const short one = (short)0x3F80;
-    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+    const bf16x8 ones = {one, one, one, one, one, one, one, one}, zeros = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // One wave per SIMD: nothing hides a wave's own LDS latency, so the k-loop is software-pipelined.  In step t the
+    // wave issues, in this order, the global loads of k-step t+RING, the LDS writes of k-step t+2 (into the buffer whose
+    // fragments were read a step ago), the transpose reads of k-step t+1 into the second fragment set -- and then the 36
+    // MFMAs of k-step t, which run while all of that is in flight.  One barrier per step.
+    static_assert(RING % 2 == 0, "fragment sets alternate with the ring slot");
+    bf16x8 fa[2][6], fb[2][6];
+    auto readfr = [&](auto S, const unsigned char* stage) {
+        constexpr int sidx = decltype(S)::value;
+        const unsigned char* la = stage + wm * WG_SUB + fbase;
+        const unsigned char* lb = stage + (GM + wn) * WG_SUB + fbase;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int o = (f << 5) ^ fsw;
+            const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o));
+            const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o + 4 * T_PITCH));
+            const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o));
+            const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o + 4 * T_PITCH));
+            fa[sidx][f] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+            fb[sidx][f] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    // (the global loads are issued unconditionally -- past the end of the chunk they re-read its last k-step into a slot
+    // nobody stashes: a branch around them makes the compiler's counted vmcnt waits collapse to vmcnt(0) at the join)
+    static_for<RING>([&](auto R) { issue(R, min((int)decltype(R)::value, nt - 1)); });
+    stash(std::integral_constant<int, 0>{}, smem);
+    __syncthreads();
+    if (active) readfr(std::integral_constant<int, 0>{}, smem);
+    if (nt > 1) stash(std::integral_constant<int, 1>{}, smem + STAGE);
+    __syncthreads();
 
     auto step = [&](auto R, int t) {
         constexpr int r = decltype(R)::value;
         const int cur = t & 1;
-        if (t + RING - 1 < nt) issue(std::integral_constant<int, (r + RING - 1) % RING>{}, t + RING - 1);
+        issue(R, min(t + RING, nt - 1));                            // slot r held k-step t, stashed two steps ago
+        if (t + 2 < nt) stash(std::integral_constant<int, (r + 2) % RING>{}, smem + cur * STAGE);
         if (active) {
-            const unsigned char* la = smem + cur * STAGE + wm * WG_SUB + fbase;
-            const unsigned char* lb = smem + cur * STAGE + (GM + wn) * WG_SUB + fbase;
-            bf16x8 af[6], bfr[6];
-#pragma unroll
-            for (int f = 0; f < 6; ++f) {
-                const int o = (f << 5) ^ fsw;
-                const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o));
-                const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o + 4 * T_PITCH));
-                const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o));
-                const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o + 4 * T_PITCH));
-                af[f] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-                bfr[f] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+            if (t + 1 < nt) readfr(std::integral_constant<int, (r + 1) & 1>{}, smem + (cur ^ 1) * STAGE);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            if (do_rowsum) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[r & 1][j], fa[r & 1][i], acc[i][j], 0, 0, 0);
+            if (do_rowsum) {        // out[n][m] += sel_i[n][k] a_i[m][k], sel_i = 1 on row n == i: column i collects fragment i
 #pragma unroll
-                for (int i = 0; i < 6; ++i) rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], rsum[i], 0, 0, 0);
+                for (int i = 0; i < 6; ++i)
+                    rsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[r & 1][i], li == i ? ones : zeros, rsum, 0, 0, 0);
             }
         }
-        if (t + 1 < nt) stash(std::integral_constant<int, (r + 1) % RING>{}, smem + (cur ^ 1) * STAGE);
         __syncthreads();
     };
     for (int t = 0; t < nt; t += RING)
@@ -611,15 +627,16 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
             }
         }
     }
-    if (do_rowsum && g == 0) {
+    if (do_rowsum && li < 6) {
+        // rsum lane (g, li), element e = sum over k of fragment li's row 4 g + e
         float* rs = (float*)p.out2;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int m = m0 + wm * 96 + i * 16 + li;
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 96 + li * 16 + g * 4 + e;
             if (m >= p.M) continue;
-            if (split) rs[(size_t)bz * p.M + m] = rsum[i][0];
-            else if (p.accumulate) rs[m] += rsum[i][0];
-            else rs[m] = rsum[i][0];
+            if (split) rs[(size_t)bz * p.M + m] = rsum[e];
+            else if (p.accumulate) rs[m] += rsum[e];
+            else rs[m] = rsum[e];
         }
     }
 }
@@ -630,9 +647,6 @@ struct WgradGroup {
     int gx[GROUP_MAX], gy[GROUP_MAX], shape[GROUP_MAX];
     int n;
 };
-#ifndef TULIP_WGRAD_BIG_RING
-#define TULIP_WGRAD_BIG_RING 4
-#endif
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS_BYTES];
     // workgroup b runs on XCD b % 8: neighbours in the (token chunk, tile) order -- tiles of one chunk share its
@@ -649,9 +663,9 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
     const int by = b / G.gx[i], bx = b - by * G.gx[i];
     const GemmArgs p = G.g[i];
     switch (G.shape[i]) {
-        case 0: wgrad_tile<2, 2, TULIP_WGRAD_BIG_RING>(p, bx, by, bz, smem); break;
-        case 1: wgrad_tile<4, 1, TULIP_WGRAD_BIG_RING>(p, bx, by, bz, smem); break;
-        default: wgrad_tile<1, 4, TULIP_WGRAD_BIG_RING>(p, bx, by, bz, smem); break;
+        case 0: wgrad_tile<2, 2, 4>(p, bx, by, bz, smem); break;
+        case 1: wgrad_tile<4, 1, 4>(p, bx, by, bz, smem); break;
+        default: wgrad_tile<1, 4, 4>(p, bx, by, bz, smem); break;
     }
 }
 
@@ -759,7 +773,7 @@ extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n
 // -1 = none (the 64 x 96 tile of gemm_group_kernel)
 static int g_wgrad_mode = 1;
 static int wgrad_shape(int Nw, int Kw) {
-    if (!g_wgrad_mode) return -1;
+    if (!(g_wgrad_mode & 1)) return -1;
     if (Nw % 192 == 0 && Kw % 192 == 0) return 0;
     if (Kw == 96 && Nw % 96 == 0) return 1;
     if (Nw == 96 && Kw % 96 == 0) return 2;
@@ -785,7 +799,9 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
         return TULIP_ERR_ARG;
     bool big = true;
     for (int i = 0; i < n; ++i)
-        if (items[i].Nw > 0 && items[i].Kw > 0 && items[i].Mtok > 0 && wgrad_shape(items[i].Nw, items[i].Kw) < 0) big = false;
+        if (items[i].Nw > 0 && items[i].Kw > 0 && items[i].Mtok > 0 &&
+            (wgrad_shape(items[i].Nw, items[i].Kw) < 0 || (items[i].Mtok & 31)))
+            big = false;
     WgradGroup G;
     tulip_reduce_region folds[TULIP_REDUCE_REGIONS_MAX];
     int nf = 0;

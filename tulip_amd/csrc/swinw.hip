@@ -119,22 +119,6 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[NTILE][G]) {
         for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { const float4 v = *(const float4*)p; return (f32x4){v.x, v.y, v.z, v.w}; }
-// Pull `elems` bf16 of a weight array into this XCD's L2 ahead of the dependent k-step chains that stream it: inside a
-// training step the copies are cold (written at the end of the previous step, a step of other traffic ago) and each ring
-// refill of a cold stream is an HBM round trip.  The workgroups that share an XCD (workgroup b runs on XCD b % 8 --
-// observed, used for speed only) split the array in 1-KiB wave loads into a scratch register nobody reads; loads issued
-// through inline asm are invisible to the compiler's vmcnt bookkeeping, which is safe (in-order retirement: they can
-// only make a later wait longer) and costs the kernel nothing but the issue slots.
-__device__ __forceinline__ void l2_prefetch(const bf16_t* w, int elems, int waves_per_wg, int wid, int lane) {
-    const int nxcd = gridDim.x >= 8 ? 8 : 1;
-    const int rank = (blockIdx.x / nxcd) * waves_per_wg + wid, nrank = ((gridDim.x + nxcd - 1) / nxcd) * waves_per_wg;
-    const int chunks = elems >> 9;                               // 1 KiB = 512 bf16
-    for (int c = rank; c < chunks; c += nrank) {
-        const bf16_t* p = w + (size_t)c * 512 + lane * 8;
-        f32x4 sink;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
-    }
-}
 // first packed block of row tile `nt` of a matrix with K columns, at this lane's 8 elements
 __device__ __forceinline__ const bf16_t* wtile_ptr(const bf16_t* w, int nt, int K, int lane) {
     return w + ((size_t)nt * (K >> 5)) * 512 + lane * 8;
