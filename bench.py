@@ -126,8 +126,10 @@ def kernel_rooflines(trainer, reps=5):
             f += 2.0 * it.Nw * it.Kw * it.Mtok
             by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw * eff
         ksub = 4 if (tiles <= 400 and deep) else 1
-        # the weight gradients of a block leave as ONE grouped launch of the same tile code; timed without its fold
-        rec.append(("gemm", f"gemm_group_kernel<64, true, true, {ksub}>",
+        big = all(ops.wgrad_tiles(it.Nw, it.Kw) != -(-it.Nw // 64) * -(-it.Kw // 96) and it.Mtok % 32 == 0 for it in items)
+        # the weight gradients of a block leave as ONE grouped launch; timed without its fold
+        rec.append(("gemm", "wgrad_group_kernel (192x192 / 384x96 / 96x384 tiles)" if big
+                    else f"gemm_group_kernel<64, true, true, {ksub}>",
                     lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False), f, by))
         real["wgrad_group"](items, extra, ws, ws_bytes, fold)
 
@@ -176,8 +178,8 @@ def kernel_rooflines(trainer, reps=5):
         d[0] += 1; d[1] += t; d[2] += fl
     ridge = PEAK_BF16 / PEAK_HBM
     kernels = {
-        "gemm": "gemm_kernel / gemm_group_kernel<BM,A_T,B_T,KSUB> (one tile code: every linear / 1x1 conv fwd + dgrad "
-                "outside the fused blocks, every weight gradient)",
+        "gemm": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv fwd + dgrad outside the fused blocks) + "
+                "wgrad_group_kernel / gemm_group_kernel (every weight gradient)",
         "swin96_fwd": "swin96_fwd_kernel (whole C=96 Swin block, forward)", "swin96_bwd": "swin96_bwd_kernel",
         "swinw_fwd": "swinw_fwd_kernel<C,G> (whole C=192/384 Swin block, forward)", "swinw_bwd": "swinw_bwd_kernel<C,G>",
         "adamw": "adamw_kernel (fp32 master + moments + bf16 shadow, 30 B / parameter)"}

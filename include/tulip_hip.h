@@ -91,6 +91,9 @@ int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_r
  * `splits` with.  tulip_wgrad_set_mode(0) forces the 64 x 96 tile everywhere (A/B measurements); default 1. */
 int tulip_wgrad_tiles(int Nw, int Kw);
 int tulip_wgrad_set_mode(int mode);
+/* Profiling: a device buffer of 4 x uint64 per workgroup of the next large-tile launches (shader-clock stamps: start, end
+ * of the pipeline prologue, end of the k-loop, end of the write-out), or NULL to stop. */
+int tulip_wgrad_set_profile(void* stamps);
 
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
     "tulip_wgrad_tiles": [I, I],
     "tulip_wgrad_set_mode": [I],
+    "tulip_wgrad_set_profile": [P],
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_cast_bf16_f32": [P, P, L, P],

@@ -486,6 +486,10 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg + 31) >> 5;
+    // p.aux (unused by this form): optional profile buffer, 4 shader-clock stamps per workgroup (tools/wgrad_phases.py)
+    unsigned long long* prof = (unsigned long long*)p.aux;
+#define TULIP_WG_STAMP(k) do { if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    TULIP_WG_STAMP(0);
     if (nt <= 0) return;                               // (uniform; the launcher never creates an empty chunk)
 
     // per-thread chunk slots: byte offset inside a k-step's operand rows (32-bit, added to a wave-uniform base that
@@ -575,6 +579,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     if (active) readfr(std::integral_constant<int, 0>{}, smem);
     if (nt > 1) stash(std::integral_constant<int, 1>{}, smem + STAGE);
     __syncthreads();
+    TULIP_WG_STAMP(1);
 
     auto step = [&](auto R, int t) {
         constexpr int r = decltype(R)::value;
@@ -599,6 +604,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     for (int t = 0; t < nt; t += RING)
         static_for<RING>([&](auto R) { if (t + decltype(R)::value < nt) step(R, t + decltype(R)::value); });
 
+    TULIP_WG_STAMP(2);
     // write-out: each wave stages 32 rows of its own tile at a time and stores them as full 384-B rows
     if (!active) return;
     unsigned char* wst = smem + wid * (32 * WG_STG_PITCH);
@@ -627,6 +633,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
             }
         }
     }
+    TULIP_WG_STAMP(3);
     if (do_rowsum && li < 6) {
         // rsum lane (g, li), element e = sum over k of fragment li's row 4 g + e
         float* rs = (float*)p.out2;
@@ -786,6 +793,8 @@ static void wgrad_tile_grid(int shape, int Nw, int Kw, int* gx, int* gy) {
     *gy = (Nw + tm - 1) / tm;
 }
 extern "C" int tulip_wgrad_set_mode(int mode) { g_wgrad_mode = mode; return TULIP_OK; }
+static void* g_wgrad_prof = nullptr;
+extern "C" int tulip_wgrad_set_profile(void* stamps) { g_wgrad_prof = stamps; return TULIP_OK; }
 extern "C" int tulip_wgrad_tiles(int Nw, int Kw) {
     int gx, gy;
     wgrad_tile_grid(wgrad_shape(Nw, Kw), Nw, Kw, &gx, &gy);
@@ -844,6 +853,7 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
     if (G.n > 0) {
         const int blocks = G.first[G.n];
         if (big) {
+            for (int i = 0; i < G.n; ++i) G.g[i].aux = g_wgrad_prof;
             hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(256), 0, stream, G);
         } else {
             GemmGroup S;

@@ -95,6 +95,11 @@ def wgrad_set_mode(mode):
     _lib.load().tulip_wgrad_set_mode(int(mode))
 
 
+def wgrad_set_profile(stamps):
+    """int64 device tensor [workgroups, 4] receiving the large-tile kernel's phase stamps, or None."""
+    _lib.load().tulip_wgrad_set_profile(_p(stamps))
+
+
 def wgrad_group(items, extra, workspace, workspace_bytes, fold=True):
     """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions."""
     ia = (_lib.WgradItem * max(len(items), 1))(*items)
