@@ -133,51 +133,20 @@ __device__ __forceinline__ bf16x8 frag_n(const unsigned char* lds, int row, int 
 }
 
 // k-slow fragments through the LDS transpose read.  NF fragments (16 rows each, starting at 32-B
-// chunk c32_0 + f), one asm statement: 2*NF reads then a single lgkmcnt(0).
+// chunk c32_0 + f); the builtin leaves the wait placement to the compiler.
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 template <int NF>
 __device__ __forceinline__ void frag_t(const unsigned char* lds, int c32_0, int lane, bf16x8* out) {
     const int g = lane >> 4, i = lane & 15;
     const int k = g * 8 + (i >> 2);
     const int sw = (g & 1) << 2;
-    unsigned a[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
-        a[f] = (unsigned)(uintptr_t)(lds + k * T_PITCH + (((c32_0 + f) ^ sw) << 5) + ((i & 3) << 3));
-    bf16x4 lo[NF], hi[NF];
-    if constexpr (NF == 2) {
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:1152\n\t"
-            "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:1152\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1])
-            : "v"(a[0]), "v"(a[1])
-            : "memory");
-    } else if constexpr (NF == 3) {
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:1152\n\t"
-            "ds_read_b64_tr_b16 %2, %7\n\tds_read_b64_tr_b16 %3, %7 offset:1152\n\t"
-            "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:1152\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2])
-            : "v"(a[0]), "v"(a[1]), "v"(a[2])
-            : "memory");
-    } else {
-        static_assert(NF == 4, "NF");
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1152\n\t"
-            "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1152\n\t"
-            "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1152\n\t"
-            "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1152\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]),
-              "=&v"(hi[3])
-            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
-            : "memory");
+    for (int f = 0; f < NF; ++f) {
+        const unsigned char* a = lds + k * T_PITCH + (((c32_0 + f) ^ sw) << 5) + ((i & 3) << 3);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(a + 4 * T_PITCH));
+        out[f] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-        out[f] = __builtin_shufflevector(lo[f], hi[f], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // ---- epilogue: 8 consecutive columns n..n+7 of row m (16-B bf16 / 32-B fp32 accesses) -----------
@@ -464,7 +433,6 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
 // fragments in registers (one wave per SIMD), 24 transpose reads for 36 MFMAs, and a third of the operand traffic.
 // GM x GN = 2 x 2 (192 x 192: every linear of stages 1-3), 4 x 1 (384 x 96) and 1 x 4 (96 x 384) for the C = 96 stage.
 // Each k-step's operands are [32 tokens][96 columns] sub-tiles in the k-slow LDS layout of Stage<96, true> (pitch 288 B).
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 constexpr int WG_SUB = 32 * T_PITCH;          // bytes of one sub-tile
 constexpr int WG_STG_PITCH = 96 * 4 + 16;     // fp32 write-out staging row
 constexpr int WG_LDS_BYTES = 2 * 5 * WG_SUB;  // double-buffered 4 x 1 stage (the 2 x 2 stage is 4 sub-tiles)
