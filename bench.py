@@ -301,7 +301,7 @@ def comm_report(trainer, args, world, device, steps=10):
                                                    "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ}}
 
 
-def secondary_batch64(args, device, steps=20, warmup=5):
+def secondary_batch64(args, device, steps=30, warmup=15):
     """BASELINE.json configs[4] without its fp8 leg: the same step at per-GPU batch 64, where the kernels rather than
     the launch chain set the pace (secondary metric; bf16 operands like the headline)."""
     import copy
