@@ -440,7 +440,7 @@ constexpr int WG_LDS_BYTES = 2 * 5 * WG_SUB;  // double-buffered 4 x 1 stage (th
 template <int GM, int GN, int RING>
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, const int by, const int bz,
                                            unsigned char* __restrict__ smem) {
-    static_assert(GM * GN == 4, "four waves");
+    static_assert(GM * GN == 4, "four compute waves");
     constexpr int SUBS = GM + GN;
     constexpr int STAGE = SUBS * WG_SUB;
     constexpr bool A_FIRST = GM >= GN;                 // the wider operand first: its chunk count is a multiple of 256
@@ -448,7 +448,14 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     constexpr int NCH = SUBS * 384;                    // 16-B chunks of one k-step
     constexpr int PT = (NCH + 255) / 256;
     constexpr int I1 = G1 * 384 / 256;                 // chunk slots (per thread) of the first operand
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // eight waves, two per SIMD: waves 0-3 own the 96 x 96 tiles (LDS fragment reads + MFMAs), waves 4-7 move the
+    // operands (global -> registers -> LDS).  A wave issues in order, and a global load waits at issue while the CU's
+    // address unit works through the ~24 KB a k-step fetches (~850 cycles per step measured with the MFMAs removed,
+    // more than the 36 MFMAs take): in one wave the two add up (1500 cycles per step); in two waves of one SIMD the
+    // matrix pipe runs while the loader is held.
+    const int wid8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool loader = wid8 >= 4;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = wid8 & 3;
     const int wm = wid / GN, wn = wid % GN;
     const int m0 = by * (GM * 96), n0 = bx * (GN * 96);
     const int kbeg = bz * p.kchunk;
@@ -460,48 +467,68 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     TULIP_WG_STAMP(0);
     if (nt <= 0) return;                               // (uniform; the launcher never creates an empty chunk)
 
-    // per-thread chunk slots: byte offset inside a k-step's operand rows (32-bit, added to a wave-uniform base that
-    // advances by 32 token rows per k-step) and the LDS offset.  Everything in the k-loop is unconditional: the token
-    // count is a multiple of 32 (the launcher's condition for this kernel); sub-tiles beyond M / N are never read (M, N
-    // are multiples of 96, only inactive waves own them), so their slots load the k-step's first chunk; the slots past
-    // the end of the chunk list (4 x 1 / 1 x 4: 7.5 per thread) write into the unused last 32 B of a sub-tile row.
-    unsigned goff[PT];
-    int loff[PT];
+    constexpr int NSTEP_UNROLL = RING;
+    if (loader) {
+        // per-thread chunk slots: byte offset inside a k-step's operand rows (32-bit, added to a wave-uniform base that
+        // advances by 32 token rows per k-step) and the LDS offset.  Everything in the k-loop is unconditional: the token
+        // count is a multiple of 32 (the launcher's condition for this kernel); sub-tiles beyond M / N are never read (M,
+        // N are multiples of 96, only inactive waves own them), so their slots load the k-step's first chunk; the slots
+        // past the end of the chunk list (4 x 1 / 1 x 4: 7.5 per thread) write into the unused last 32 B of a sub-tile row.
+        unsigned goff[PT];
+        int loff[PT];
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        const bool first = i < I1;
-        const bool isA = first == A_FIRST;
-        const int G = first ? G1 : G2;
-        const int cc = tid + i * 256 - (first ? 0 : G1 * 384);
-        const int k = cc / (12 * G), mc = cc - k * (12 * G);
-        const int sub = mc / 12, mcs = mc - sub * 12;
-        const int col = (isA ? m0 : n0) + mc * 8;
-        const bool real = first || cc < G2 * 384;
-        const bool ok = real && col < (isA ? p.M : p.N);
-        goff[i] = ok ? (unsigned)(k * (isA ? p.lda : p.ldb) + col) * 2u : 0u;
-        loff[i] = real ? ((isA ? sub : GM + sub) * WG_SUB) + k * T_PITCH + ((((mcs >> 1) ^ (((k >> 3) & 1) << 2))) << 5) +
-                             ((mcs & 1) << 4)
-                       : (tid & 31) * T_PITCH + 256 + ((tid >> 5) & 1) * 16;
+        for (int i = 0; i < PT; ++i) {
+            const bool first = i < I1;
+            const bool isA = first == A_FIRST;
+            const int G = first ? G1 : G2;
+            const int cc = tid + i * 256 - (first ? 0 : G1 * 384);
+            const int k = cc / (12 * G), mc = cc - k * (12 * G);
+            const int sub = mc / 12, mcs = mc - sub * 12;
+            const int col = (isA ? m0 : n0) + mc * 8;
+            const bool real = first || cc < G2 * 384;
+            const bool ok = real && col < (isA ? p.M : p.N);
+            goff[i] = ok ? (unsigned)(k * (isA ? p.lda : p.ldb) + col) * 2u : 0u;
+            loff[i] = real ? ((isA ? sub : GM + sub) * WG_SUB) + k * T_PITCH + ((((mcs >> 1) ^ (((k >> 3) & 1) << 2))) << 5) +
+                                 ((mcs & 1) << 4)
+                           : (tid & 31) * T_PITCH + 256 + ((tid >> 5) & 1) * 16;
+        }
+        const unsigned char* baseA = (const unsigned char*)(p.A + (size_t)kbeg * p.lda);
+        const unsigned char* baseB = (const unsigned char*)(p.B + (size_t)kbeg * p.ldb);
+        // (a native vector type: a struct uint4 assigned straight from memory becomes a memcpy into the array, which
+        // keeps the whole ring in scratch)
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t ring[RING][PT];
+        auto issue = [&](auto R, int t) {
+            constexpr int r = decltype(R)::value;
+            const unsigned char* a = baseA + (size_t)t * 64 * p.lda;
+            const unsigned char* b = baseB + (size_t)t * 64 * p.ldb;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) ring[r][i] = *(const u32x4_t*)(((i < I1) == A_FIRST ? a : b) + goff[i]);
+        };
+        auto stash = [&](auto R, unsigned char* dst) {
+            constexpr int r = decltype(R)::value;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) *(u32x4_t*)(dst + loff[i]) = ring[r][i];
+        };
+        // (the global loads are issued unconditionally -- past the end of the chunk they re-read its last k-step into a
+        // slot nobody stashes: a branch around them makes the compiler's counted vmcnt waits collapse to vmcnt(0))
+        static_for<RING>([&](auto R) { issue(R, min((int)decltype(R)::value, nt - 1)); });
+        stash(std::integral_constant<int, 0>{}, smem);
+        __syncthreads();
+        if (nt > 1) stash(std::integral_constant<int, 1>{}, smem + STAGE);
+        __syncthreads();
+        // step t: load k-step t+RING into the slot whose k-step t went to LDS two steps ago; k-step t+2 goes into the
+        // buffer whose fragments the compute waves read during step t-1
+        auto step = [&](auto R, int t) {
+            constexpr int r = decltype(R)::value;
+            issue(R, min(t + RING, nt - 1));
+            if (t + 2 < nt) stash(std::integral_constant<int, (r + 2) % RING>{}, smem + (t & 1) * STAGE);
+            __syncthreads();
+        };
+        for (int t = 0; t < nt; t += NSTEP_UNROLL)
+            static_for<NSTEP_UNROLL>([&](auto R) { if (t + decltype(R)::value < nt) step(R, t + decltype(R)::value); });
+        return;
     }
-    const unsigned char* baseA = (const unsigned char*)(p.A + (size_t)kbeg * p.lda);
-    const unsigned char* baseB = (const unsigned char*)(p.B + (size_t)kbeg * p.ldb);
-
-    // (a native vector type: a struct uint4 assigned straight from memory becomes a memcpy into the array, which keeps
-    // the whole ring in scratch)
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t ring[RING][PT];
-    auto issue = [&](auto R, int t) {
-        constexpr int r = decltype(R)::value;
-        const unsigned char* a = baseA + (size_t)t * 64 * p.lda;
-        const unsigned char* b = baseB + (size_t)t * 64 * p.ldb;
-#pragma unroll
-        for (int i = 0; i < PT; ++i) ring[r][i] = *(const u32x4_t*)(((i < I1) == A_FIRST ? a : b) + goff[i]);
-    };
-    auto stash = [&](auto R, unsigned char* dst) {
-        constexpr int r = decltype(R)::value;
-#pragma unroll
-        for (int i = 0; i < PT; ++i) *(u32x4_t*)(dst + loff[i]) = ring[r][i];
-    };
 
     f32x4 acc[6][6];
 #pragma unroll
@@ -518,49 +545,47 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     const short one = (short)0x3F80;
     const bf16x8 ones = {one, one, one, one, one, one, one, one}, zeros = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // One wave per SIMD: nothing hides a wave's own LDS latency, so the k-loop is software-pipelined.  In step t the
-    // wave issues, in this order, the global loads of k-step t+RING, the LDS writes of k-step t+2 (into the buffer whose
-    // fragments were read a step ago), the transpose reads of k-step t+1 into the second fragment set -- and then the 36
-    // MFMAs of k-step t, which run while all of that is in flight.  One barrier per step.
-    static_assert(RING % 2 == 0, "fragment sets alternate with the ring slot");
-    bf16x8 fa[2][6], fb[2][6];
-    auto readfr = [&](auto S, const unsigned char* stage) {
-        constexpr int sidx = decltype(S)::value;
-        const unsigned char* la = stage + wm * WG_SUB + fbase;
-        const unsigned char* lb = stage + (GM + wn) * WG_SUB + fbase;
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
-            const int o = (f << 5) ^ fsw;
-            const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o));
-            const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(la + o + 4 * T_PITCH));
-            const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o));
-            const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(lb + o + 4 * T_PITCH));
-            fa[sidx][f] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-            fb[sidx][f] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+    // compute waves, step t: issue the transpose reads of k-step t+1's A fragments into the second set, then the 36
+    // MFMAs of k-step t, which run while the reads are in flight; each B fragment of k-step t+1 is read right behind the
+    // last MFMA that uses its predecessor (two full fragment sets + 36 accumulators do not fit 256 registers, the
+    // budget of a wave when two share a SIMD).  One barrier per step, shared with the loaders.
+    bf16x8 fa[2][6], fb[6];
+    auto tr2 = [&](const unsigned char* a) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(a + 4 * T_PITCH));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    // (the global loads are issued unconditionally -- past the end of the chunk they re-read its last k-step into a slot
-    // nobody stashes: a branch around them makes the compiler's counted vmcnt waits collapse to vmcnt(0) at the join)
-    static_for<RING>([&](auto R) { issue(R, min((int)decltype(R)::value, nt - 1)); });
-    stash(std::integral_constant<int, 0>{}, smem);
+    auto readA = [&](auto S, const unsigned char* stage) {
+        const unsigned char* la = stage + wm * WG_SUB + fbase;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) fa[decltype(S)::value][f] = tr2(la + ((f << 5) ^ fsw));
+    };
     __syncthreads();
-    if (active) readfr(std::integral_constant<int, 0>{}, smem);
-    if (nt > 1) stash(std::integral_constant<int, 1>{}, smem + STAGE);
+    if (active) {
+        readA(std::integral_constant<int, 0>{}, smem);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) fb[f] = tr2(smem + (GM + wn) * WG_SUB + fbase + ((f << 5) ^ fsw));
+    }
     __syncthreads();
     TULIP_WG_STAMP(1);
 
     auto step = [&](auto R, int t) {
         constexpr int r = decltype(R)::value;
-        const int cur = t & 1;
-        issue(R, min(t + RING, nt - 1));                            // slot r held k-step t, stashed two steps ago
-        if (t + 2 < nt) stash(std::integral_constant<int, (r + 2) % RING>{}, smem + cur * STAGE);
+        const unsigned char* nxt = smem + ((t & 1) ^ 1) * STAGE;
         if (active) {
-            if (t + 1 < nt) readfr(std::integral_constant<int, (r + 1) & 1>{}, smem + (cur ^ 1) * STAGE);
+            const bool more = t + 1 < nt;
+            if (more) readA(std::integral_constant<int, (r + 1) & 1>{}, nxt);
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[r & 1][j], fa[r & 1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][i], acc[i][j], 0, 0, 0);
+            const unsigned char* lb = nxt + (GM + wn) * WG_SUB + fbase;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                acc[5][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][5], acc[5][j], 0, 0, 0);
+                if (more) fb[j] = tr2(lb + ((j << 5) ^ fsw));
+            }
             if (do_rowsum) {        // out[n][m] += sel_i[n][k] a_i[m][k], sel_i = 1 on row n == i: column i collects fragment i
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
@@ -569,8 +594,8 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
         }
         __syncthreads();
     };
-    for (int t = 0; t < nt; t += RING)
-        static_for<RING>([&](auto R) { if (t + decltype(R)::value < nt) step(R, t + decltype(R)::value); });
+    for (int t = 0; t < nt; t += 2)
+        static_for<2>([&](auto R) { if (t + decltype(R)::value < nt) step(R, t + decltype(R)::value); });
 
     TULIP_WG_STAMP(2);
     // write-out: each wave stages 32 rows of its own tile at a time and stores them as full 384-B rows
@@ -622,7 +647,7 @@ struct WgradGroup {
     int gx[GROUP_MAX], gy[GROUP_MAX], shape[GROUP_MAX];
     int n;
 };
-__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradGroup G) {
+__global__ __launch_bounds__(512) void wgrad_group_kernel(const WgradGroup G) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS_BYTES];
     // workgroup b runs on XCD b % 8: neighbours in the (token chunk, tile) order -- tiles of one chunk share its
     // operand rows -- are given to the same XCD's L2, 8 launch slots apart
@@ -822,7 +847,7 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
         const int blocks = G.first[G.n];
         if (big) {
             for (int i = 0; i < G.n; ++i) G.g[i].aux = g_wgrad_prof;
-            hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(256), 0, stream, G);
+            hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(512), 0, stream, G);
         } else {
             GemmGroup S;
             S.n = G.n;
