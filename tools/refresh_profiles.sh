@@ -1,18 +1,27 @@
 #!/bin/bash
 # Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): regenerates everything profiles/ cites.
+# The PMC passes run first and their per-family summary is put where bench.py looks for it, so that the bench line of the
+# same run carries `traffic` (bench.py only accepts a summary whose source stamp matches the code it runs).
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $O/pmc_w.log 2>&1
+python tools/pmc_summary.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_hbm_traffic.txt
+cp $O/pmc_traffic.json profiles/pmc_traffic.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_f -- python tools/pmc_calib.py > $O/pmc_calibration.txt 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_w -- python tools/pmc_calib.py > /dev/null 2>&1
+python tools/pmc_summary.py $(find $O/cal_f -name "*counter_collection.csv" | head -1) $(find $O/cal_w -name "*counter_collection.csv" | head -1) >> $O/pmc_calibration.txt
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-secondary > $O/kt.log 2>&1
 python tools/kstats.py $(find $O/kt -name "*.db" | head -1) 26 > $O/kernel_stats.txt
 python tools/timeline.py $(find $O/kt -name "*.db" | head -1) > $O/timeline_summary.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $O/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > $O/pmc_w.log 2>&1
-python tools/pmc_summary.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_hbm_traffic.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_f -- python tools/pmc_calib.py > $O/pmc_calibration.txt 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_w -- python tools/pmc_calib.py > /dev/null 2>&1
-python tools/pmc_summary.py $(find $O/cal_f -name "*counter_collection.csv" | head -1) $(find $O/cal_w -name "*counter_collection.csv" | head -1) >> $O/pmc_calibration.txt
+rocprofv3 --kernel-trace --stats -d $O/kt64 -- python bench.py --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary > $O/kt64.log 2>&1
+python tools/kstats.py $(find $O/kt64 -name "*.db" | head -1) 20 > $O/kernel_stats_b64.txt
 python tools/bench_eval.py > $O/eval_bench.json 2>/dev/null
-rm -rf $O/kt $O/pmc_f $O/pmc_w $O/cal_f $O/cal_w
+python tools/exp_chain.py > $O/exp_chain.txt 2>/dev/null
+python tools/wgrad_phases.py > $O/wgrad_phases.txt 2>/dev/null
+python tools/bench_wgrad.py > $O/wgrad_isolated.txt 2>/dev/null
+python tools/chain_gemms.py > $O/chain_gemms.txt 2>/dev/null
+rm -rf $O/kt $O/kt64 $O/pmc_f $O/pmc_w $O/cal_f $O/cal_w
 ls -la $O
