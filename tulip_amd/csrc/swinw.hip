@@ -869,6 +869,16 @@ __host__ __device__ inline bool wide_g4(int C, int B, int H, int W) {
     // windows per workgroup: 4 once that still gives every CU a workgroup, else 2 (every TULIP grid has W % 16 == 0)
     return C == 192 && (W % 32 == 0) && (B * (H / 2) * (W / 8)) / 4 >= 256;
 }
+#ifndef TULIP_SWINW_G1_BELOW
+#define TULIP_SWINW_G1_BELOW 128
+#endif
+__host__ __device__ inline int wide_g(int C, int B, int H, int W) {
+    if (wide_g4(C, B, H, W)) return 4;
+    // C = 384 with few windows (batch 8: 128): one window per workgroup, twice the workgroups streaming the weights
+    // (forward 66 -> 50 us, backward 65 -> 51 us at batch 8)
+    if (C == 384 && (B * (H / 2) * (W / 8)) / 2 < TULIP_SWINW_G1_BELOW) return 1;
+    return 2;
+}
 
 // ---- fragment-major copies of a list of bf16 matrices: mode 0: dst = packed(src [rows][cols]);  mode 1: dst =
 // packed(src^T) (a [cols][rows] matrix), through an LDS tile transpose so that both sides move 16-byte pieces
@@ -946,12 +956,12 @@ static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, uns
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
     if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_fwd<192, 4>(a, stream) : launch_fwd<192, 2>(a, stream);
-    return launch_fwd<384, 2>(a, stream);
+    return wide_g(C, d->B, d->H, d->W) == 1 ? launch_fwd<384, 1>(a, stream) : launch_fwd<384, 2>(a, stream);
 }
 
 extern "C" int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W) {
     if (B <= 0 || !tulip_swinw_supported(C, H, W)) return 0;
-    return B * (H / 2) * (W / (8 * (wide_g4(C, B, H, W) ? 4 : 2)));
+    return B * (H / 2) * (W / (8 * wide_g(C, B, H, W)));
 }
 
 extern "C" int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream) {
@@ -973,7 +983,7 @@ extern "C" int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipS
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.scale = 0.17677669529663687f;
     if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_bwd<192, 4>(a, stream) : launch_bwd<192, 2>(a, stream);
-    return launch_bwd<384, 2>(a, stream);
+    return wide_g(C, d->B, d->H, d->W) == 1 ? launch_bwd<384, 1>(a, stream) : launch_bwd<384, 2>(a, stream);
 }
 
 extern "C" int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream) {

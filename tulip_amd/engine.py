@@ -442,12 +442,13 @@ class TulipEngine:
 
     fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
     fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
-    # C = 192 always; C = 384 (stage 2: 3.5 MB of weights per block) from 256 windows per launch up (batch 16 at the KITTI
-    # size).  Every workgroup streams the block's whole weight set through its own CU, so with the 128 windows = 64
-    # workgroups of batch 8 the fused form only ties the 7-kernel sequences (66 + 65 us against 62 + 86 us isolated, 2.896 vs
-    # 2.862 ms in the step); at batch 16 / 32 / 64 it wins 3 / 5 / 4.5 % of the step.  TULIP_FUSE_WIDE_MIN_WINDOWS overrides.
+    # C = 192 always; C = 384 (stage 2: 3.5 MB of weights per block) from 128 windows per launch up (batch 8 at the KITTI
+    # size).  Every workgroup streams the block's whole weight set through its own CU: with two windows per workgroup the
+    # 128 windows of batch 8 were 64 workgroups and the fused form only tied the 7-kernel sequences (66 + 65 us against
+    # 63 + 91 us isolated); with ONE window per workgroup below 256 windows (csrc/swinw.hip wide_g) it is 50 + 51 us and
+    # 1.7 % of the step; at batch 16 / 32 / 64 it wins 3 / 5 / 4.5 %.  TULIP_FUSE_WIDE_MIN_WINDOWS overrides.
     wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192,384").split(",") if c)
-    wide_min_windows = int(os.environ.get("TULIP_FUSE_WIDE_MIN_WINDOWS", "256"))
+    wide_min_windows = int(os.environ.get("TULIP_FUSE_WIDE_MIN_WINDOWS", "128"))
 
     def _fusable_wide(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
         """csrc/swinw.hip covers C = 192 / 384: heads of 32, window 2x8, MLP C -> 4C -> C.  B = None: could the block ever
