@@ -38,11 +38,10 @@ __device__ __forceinline__ void slot_info(const AttnGeom& g, int b, int wy, int 
     label = 3 * region(hs, g.H, g.wh, g.sh) + region(ws, g.W, g.ww, g.sw);
 }
 
+// ds_read_b64_tr_b16 through the builtin: the compiler batches the waits of consecutive reads
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
-    bf16x4 v;
-    const unsigned a = (unsigned)(uintptr_t)p;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
-    return v;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)p);
 }
 
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {

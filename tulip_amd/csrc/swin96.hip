@@ -51,11 +51,10 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
 __device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// ds_read_b64_tr_b16 through the builtin: the compiler batches the waits of consecutive reads
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
-    bf16x4 v;
-    const unsigned a = (unsigned)(uintptr_t)p;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
-    return v;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)p);
 }
 // weight fragment in the chained-operand k order: k slots 0..3 <- columns c0..c0+3, slots 4..7 <- c0+16..c0+19
 __device__ __forceinline__ bf16x8 wfrag(const unsigned char* rowp, int c0) {
