@@ -296,7 +296,7 @@ def comm_report(trainer, args, world, device, steps=10):
             "bucket_tags": [t for t, _, _ in trainer.bucketer.buckets], "grad_dtype": trainer.grad_dtype,
             "per_bucket_adamw": trainer.bucket_adamw, "step_ms": round(with_coll, 4),
             "step_ms_collectives_skipped": round(without, 4), "exposed_exchange_ms": round(with_coll - without, 4),
-            "rccl_version": ver,
+            "rccl_version": ver, "wgrad_workgroups_per_launch": trainer.eng.wgrad_ctas or trainer.eng.WGRAD_BIG_CTAS,
             "env": {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO",
                                                    "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ}}
 

@@ -609,11 +609,18 @@ class TulipEngine:
     WGRAD_MINK = int(os.environ.get("TULIP_WGRAD_MINK", "1024"))
     WGRAD_BIG_CTAS = int(os.environ.get("TULIP_WGRAD_BIG_CTAS", "256"))
     WGRAD_BIG_MINK = int(os.environ.get("TULIP_WGRAD_BIG_MINK", "512"))
+    # A large-tile workgroup takes a whole CU (8 waves x 256 registers, 92 KB of LDS): a group is sized to one round of
+    # the CUs that are FREE.  With a gradient all-reduce running beside the backward RCCL's channel workgroups hold wave
+    # slots on up to ~32 CUs for the length of a collective, and a 256-workgroup launch would need a second round for
+    # the workgroups those CUs cannot take; the Trainer sets this to WGRAD_DDP_CTAS when world_size > 1 (not measured on
+    # a multi-GPU node; TULIP_WGRAD_DDP_CTAS overrides).
+    wgrad_ctas = 0                                   # 0: WGRAD_BIG_CTAS
+    WGRAD_DDP_CTAS = int(os.environ.get("TULIP_WGRAD_DDP_CTAS", "224"))
 
     @classmethod
-    def _splits(cls, Mout: int, Nout: int, K: int, group_tiles: int = 0) -> int:
+    def _splits(cls, Mout: int, Nout: int, K: int, group_tiles: int = 0, ctas: int = 0) -> int:
         if group_tiles:  # large tiles (192 x 192 / 384 x 96 / 96 x 384), `group_tiles` of them per split in this launch
-            s = max(1, min(cls.WGRAD_BIG_CTAS // group_tiles, K // cls.WGRAD_BIG_MINK, cls.WS_ELEMS // (Mout * Nout)))
+            s = max(1, min((ctas or cls.WGRAD_BIG_CTAS) // group_tiles, K // cls.WGRAD_BIG_MINK, cls.WS_ELEMS // (Mout * Nout)))
         else:
             tiles = ((Mout + 127) // 128) * ((Nout + 95) // 96)
             s = max(1, min(cls.WGRAD_CTAS // max(tiles, 1), K // cls.WGRAD_MINK, cls.WS_ELEMS // (Mout * Nout)))
@@ -736,7 +743,7 @@ class TulipEngine:
             group_tiles = sum(ops.wgrad_tiles(a[4], a[5]) for a in cand) if big else 0
             while items and len(grp) < _lib.WGRAD_GROUP_MAX:
                 dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias = items[0]
-                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles)
+                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles, ctas=self.wgrad_ctas)
                 need = (Nw * Kw + Nw) * sp * 4 if sp > 1 else 0
                 if grp and used + need > ws_bytes:
                     break

@@ -99,6 +99,7 @@ class Trainer:
             # apply identical averaged gradients to different weights.
             src = 0 if process_group is None else dist.get_global_rank(process_group, 0)
             dist.broadcast(W.flat, src=src, group=process_group)
+            self.eng.wgrad_ctas = self.eng.WGRAD_DDP_CTAS      # leave the CUs RCCL's channels sit on out of a round
         W.refresh_shadow()
 
     # ------------------------------------------------------------------ pieces
