@@ -355,11 +355,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # rehearsal of the N > 1 path on a one-GPU box (dev only): TULIP_BENCH_BACKEND=gloo lets the ranks share cuda:0
+    backend = os.environ.get("TULIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
 
