@@ -1,27 +1,45 @@
-"""dev experiment: step time when the step graph is cut into segments at the DDP bucket points (as with
-world_size > 1) but without any collective: isolates the cost of segmentation + side-stream joins."""
-import sys, os, argparse, time
+"""What the N > 1 step STRUCTURE costs on one GPU: the step graph cut into segments at the DDP bucket points, side-stream
+joins there, AdamW as its own segment behind the last bucket -- with a one-rank nccl group (Trainer(force_segments=True)),
+once with the (identity) all-reduces issued and once with them skipped (GradBucketer.dry)."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, bench
+import argparse
+import torch
+import torch.distributed as dist
+import bench
 from tulip_amd.trainer import Trainer
-args = argparse.Namespace(model=os.environ.get("MODEL", "tulip_base"), img=[int(v) for v in os.environ.get("IMG", "16,1024").split(",")],
-                          target=[int(v) for v in os.environ.get("TARGET", "64,1024").split(",")], batch=8)
-dev = torch.device("cuda", 0)
-for fake in (1, 2):
-    model = bench.make_model(args).to(dev).train()
-    tr = Trainer(model, 8, device=dev)
-    tr.world = fake
-    class _Done:
-        def wait(self): pass
-    tr.bucketer.on_group_done = (lambda tag, g, keep=True, b=tr.bucketer:
-                                 (_Done(), *b.by_tag[tag]) if (fake > 1 and tag in b.by_tag) else None)
-    tr.bucketer.wait_all = lambda: None
-    if fake > 1 and os.environ.get("TULIP_BUCKET_ADAMW", "1") != "0":
-        tr.bucket_adamw, tr._opt_stream = True, torch.cuda.Stream()
 
-    lo, hi = bench.synthetic(args, 0, dev); tr.load_batch(lo, hi)
-    for _ in range(10): tr.step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(100): tr.step()
-    torch.cuda.synchronize()
-    print(f"fake world {fake}: segments {len(tr._segments[True])} step {(time.perf_counter() - t0) * 10:.3f} ms")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+args = argparse.Namespace(model="tulip_base", img=[16, 1024], target=[64, 1024], batch=int(os.environ.get("B", "8")))
+
+
+def run(tag, **kw):
+    model = bench.make_model(args).to(dev).train()
+    tr = Trainer(model, args.batch, device=dev, **kw)
+    for k, v in kw.pop("_attrs", {}).items():
+        setattr(tr.eng, k, v)
+    lo, hi = bench.synthetic(args, 0, dev)
+    tr.load_batch(lo, hi)
+    out = []
+    for dry in (False, True):
+        tr.bucketer.dry = dry
+        for _ in range(10):
+            tr.step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50):
+            tr.step()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) * 20)
+    segs = len(tr._segments[True]) if tr._segments else 1
+    print(f"{tag:46s} segments {segs}  step {out[0]:.3f} ms   collectives skipped {out[1]:.3f} ms", flush=True)
+
+
+run("one graph (world 1)")
+for mb in (16.0, 24.0, 64.0, 1000.0):
+    run(f"segmented, fp32 buckets >= {mb:g} MB", force_segments=True, bucket_mb=mb)
+run("segmented, bf16 buckets", force_segments=True, grad_dtype="bf16")
+run("segmented, per-bucket AdamW", force_segments=True, bucket_adamw=True)
+dist.destroy_process_group()
