@@ -612,10 +612,11 @@ class TulipEngine:
     # A large-tile workgroup takes a whole CU (8 waves x 256 registers, 92 KB of LDS): a group is sized to one round of
     # the CUs that are FREE.  With a gradient all-reduce running beside the backward RCCL's channel workgroups hold wave
     # slots on up to ~32 CUs for the length of a collective, and a 256-workgroup launch would need a second round for
-    # the workgroups those CUs cannot take; the Trainer sets this to WGRAD_DDP_CTAS when world_size > 1 (not measured on
-    # a multi-GPU node; TULIP_WGRAD_DDP_CTAS overrides).
+    # the workgroups those CUs cannot take; the Trainer sets this to WGRAD_DDP_CTAS when world_size > 1: 192 leaves room
+    # for up to 64 channels and costs 0.2 % of the one-GPU step (2.749 vs 2.743 ms).  Not measured on a multi-GPU node;
+    # TULIP_WGRAD_DDP_CTAS overrides.
     wgrad_ctas = 0                                   # 0: WGRAD_BIG_CTAS
-    WGRAD_DDP_CTAS = int(os.environ.get("TULIP_WGRAD_DDP_CTAS", "224"))
+    WGRAD_DDP_CTAS = int(os.environ.get("TULIP_WGRAD_DDP_CTAS", "192"))
 
     @classmethod
     def _splits(cls, Mout: int, Nout: int, K: int, group_tiles: int = 0, ctas: int = 0) -> int:
