@@ -65,7 +65,7 @@ __device__ __forceinline__ WaveMap wave_map(int nh, int ngrp) {
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
                                                        const float* __restrict__ bias_table,
                                                        const int* __restrict__ rel_index, bf16_t* __restrict__ out,
                                                        AttnGeom g, int ngrp) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                        const float* __restrict__ bias_table,
                                                        const int* __restrict__ rel_index, bf16_t* __restrict__ dqkv,
                                                        float* dbias_part, AttnGeom g, int ngrp) {

@@ -402,7 +402,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 }
 
 template <int BM, bool A_T, bool B_T, int KSUB>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     gemm_tile<BM, A_T, B_T, KSUB>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -416,7 +416,7 @@ struct GemmGroup {
     int n;
 };
 template <int BM, bool A_T, bool B_T, int KSUB>
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroup G) {
     int i = 0;
     while (i + 1 < G.n && (int)blockIdx.x >= G.first[i + 1]) ++i;
     int b = blockIdx.x - G.first[i];
@@ -576,14 +576,18 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
             const bool more = t + 1 < nt;
             if (more) readA(std::integral_constant<int, (r + 1) & 1>{}, nxt);
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][i], acc[i][j], 0, 0, 0);
+            // second half column by column: B fragment j is dead after its three MFMAs and is re-read for the next k-step
+            // while the remaining columns still compute
             const unsigned char* lb = nxt + (GM + wn) * WG_SUB + fbase;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                acc[5][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][5], acc[5][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 3; i < 6; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][i], acc[i][j], 0, 0, 0);
                 if (more) fb[j] = tr2(lb + ((j << 5) ^ fsw));
             }
             if (do_rowsum) {        // out[n][m] += sel_i[n][k] a_i[m][k], sel_i = 1 on row n == i: column i collects fragment i

@@ -59,7 +59,7 @@ __device__ __forceinline__ size_t pred_off(const TailGeom& g, int tok, int i) {
 // (the first version gave each wave 32 tokens and all E channels: 1 wave per SIMD and a 96-deep chain of
 // dependent L2 loads -- latency-bound at 85 / 111 us).  Forward: the four partial pixel sums meet in LDS.
 template <int KS>
-__global__ __launch_bounds__(256) void tail_fwd_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
+__global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
                                                        const float* __restrict__ be, const float* __restrict__ wd,
                                                        float* __restrict__ pred, TailGeom g) {
     __shared__ __attribute__((aligned(16))) float red[4][32][16];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const bf16_t* __restrict_
 }
 
 template <int KS>
-__global__ __launch_bounds__(256) void tail_bwd_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
+__global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
                                                        const float* __restrict__ be, const float* __restrict__ wd,
                                                        const float* __restrict__ dpred, bf16_t* __restrict__ dz,
                                                        float* dwd, TailGeom g, const float* __restrict__ target,
