@@ -93,6 +93,19 @@ def _pmc_traffic(family):
         return None
 
 
+def _instep(family):
+    """In-step mean duration of a kernel family from the committed kernel trace (profiles/instep_durations.json,
+    tools/instep_summary.py), under the same stamp rule as the PMC traffic."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "instep_durations.json")
+    try:
+        d = json.load(open(path))
+        if d.get("source_stamp") != kernel_source_stamp():
+            return None
+        return d["families"][family]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def kernel_rooflines(trainer, reps=5):
     """Roofline of every kernel family that matters in the step.  The launches of one step are recorded in an eager pass
     (ops.* wrappers), then each is re-issued `reps` times back to back between ONE HIP-event pair on the launch stream
@@ -199,6 +212,12 @@ def kernel_rooflines(trainer, reps=5):
              "flops_per_launch": round(fl / n), "frac_mfma": round(tf * 1e12 / PEAK_BF16, 4),
              "frac_hbm_algorithmic": round(tb * 1e12 / PEAK_HBM, 4),
              "frac_hbm_of_traffic": round(traffic / (t / n) / PEAK_HBM, 4) if traffic else None}
+        ins = _instep(fam)
+        if ins:     # the same family inside the traced step (other kernels running beside it): the honest, lower figure
+            ti = ins["mean_launch_us"] * 1e-6
+            e["in_step"] = {"mean_launch_us": round(ins["mean_launch_us"], 2), "launches_per_step": round(ins["launches_per_step"], 1),
+                            "frac_hbm_algorithmic": round(by / n / ti / PEAK_HBM, 4), "frac_mfma": round(fl / n / ti / PEAK_BF16, 4),
+                            "source": "profiles/instep_durations.json (rocprofv3 --kernel-trace of this command)"}
         if fam == "gemm":
             e["by_kernel"] = {k: {"launches": c, "avg_us": round(tt / c * 1e6, 2), "tflops": round(f / tt / 1e12, 1)}
                               for k, (c, tt, f) in sorted(detail[fam].items(), key=lambda kv: -kv[1][1])}

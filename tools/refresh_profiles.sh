@@ -12,10 +12,12 @@ cp $O/pmc_traffic.json profiles/pmc_traffic.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_f -- python tools/pmc_calib.py > $O/pmc_calibration.txt 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_w -- python tools/pmc_calib.py > /dev/null 2>&1
 python tools/pmc_summary.py $(find $O/cal_f -name "*counter_collection.csv" | head -1) $(find $O/cal_w -name "*counter_collection.csv" | head -1) >> $O/pmc_calibration.txt
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-secondary > $O/kt.log 2>&1
 python tools/kstats.py $(find $O/kt -name "*.db" | head -1) 26 > $O/kernel_stats.txt
 python tools/timeline.py $(find $O/kt -name "*.db" | head -1) > $O/timeline_summary.txt
+python tools/instep_summary.py $(find $O/kt -name "*.db" | head -1) $O/instep_durations.json > /dev/null
+cp $O/instep_durations.json profiles/instep_durations.json
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 rocprofv3 --kernel-trace --stats -d $O/kt64 -- python bench.py --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary > $O/kt64.log 2>&1
 python tools/kstats.py $(find $O/kt64 -name "*.db" | head -1) 20 > $O/kernel_stats_b64.txt
 python tools/bench_eval.py > $O/eval_bench.json 2>/dev/null
