@@ -154,7 +154,13 @@ int tulip_patch_embed_bwd_blocks(int ntok);
  * as address arithmetic on natural-order tokens.  qkv is [B*H*W][3C] with channel order (T,Nh,P)
  * (tulip.py:298); out is [B*H*W][C] with channel order (Nh,P).  L = wh*ww must be 16; head dim P
  * in {16,32}.  rel_index is the module's (L,L) relative_position_index buffer as int32.
- * masked!=0 for shifted blocks. */
+ * `masked` (here and in the block descriptors below) is a bit set: bit 0 (TULIP_ATTN_MASKED) = shifted block, apply the
+ * region mask; bit 1 (TULIP_ATTN_FP8) = BASELINE configs[4] "fp8 MFMA attention": the scores Q.K^T are computed by
+ * v_mfma_f32_16x16x32_fp8_fp8 from q, k rounded bf16 -> OCP e4m3 (round to nearest even); softmax, P.V and all
+ * stored tensors stay as they are, and the backward multiplies dS with the same rounded q, k (it differentiates the
+ * function the forward ran).  Default 0/1: the reference's bf16 / fp16 scores. */
+#define TULIP_ATTN_MASKED 1
+#define TULIP_ATTN_FP8 2
 int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_table, const int32_t* rel_index, uint16_t* out, int B,
                           int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream);
 /* dqkv from dout.  d(bias) leaves as R = tulip_window_attn_bwd_partial_rows(...) partial rows per head:

@@ -338,8 +338,9 @@ class _Prec:
     LayerNorm statistics, softmax and loss stay fp32 (same contract as CUDA autocast,
     SURVEY.md Appendix A, except that the residual stream is fp32 in every stage)."""
 
-    def __init__(self, lowp: bool):
+    def __init__(self, lowp: bool, attn_fp8: bool = False):
         self.lowp = lowp
+        self.attn_fp8 = attn_fp8          # BASELINE configs[4]: attention scores from e4m3 q, k (engine.attn_fp8)
 
     def r(self, t: Tensor) -> Tensor:
         if not self.lowp:
@@ -354,6 +355,19 @@ class _BF16Round(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t):
         return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _FP8Round(torch.autograd.Function):
+    """OCP e4m3 round-to-nearest-even (torch.float8_e4m3fn = the gfx950 fp8 format) with a straight-through
+    gradient: the HIP backward multiplies dS with the ROUNDED q, k, i.e. differentiates the function the forward ran."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.float8_e4m3fn).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
@@ -395,6 +409,8 @@ def window_attention(pr: _Prec, sd, prefix: str, cfg: TulipConfig, x: Tensor, nh
     qkv = pr.r(linear(pr, tok, sd[f"{prefix}.attn.qkv.weight"], sd[f"{prefix}.attn.qkv.bias"]))
     qkv = qkv.reshape(B * nW, L, 3, nh, P).permute(2, 0, 3, 1, 4)        # (T, Bn, Nh, L, P)
     q, k, v = qkv[0], qkv[1], qkv[2]
+    if pr.attn_fp8:
+        q, k = _FP8Round.apply(q), _FP8Round.apply(k)
     attn = (q @ k.transpose(-2, -1)) * (P ** -0.5)
     rpi = sd[f"{prefix}.attn.relative_position_index"].reshape(-1)
     bias = sd[f"{prefix}.attn.relative_position_bias_table"][rpi].reshape(L, L, nh).permute(2, 0, 1)
@@ -508,7 +524,7 @@ def drop_path_keep(rate: float, u: Tensor) -> Optional[Tensor]:
 
 def tulip_forward(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Optional[Tensor],
                   lowp: bool = False, drop_u: Optional[Dict[str, Tensor]] = None,
-                  taps: Optional[Dict[str, Tensor]] = None):
+                  taps: Optional[Dict[str, Tensor]] = None, attn_fp8: bool = False):
     """TULIP.forward (tulip.py:702-737), every flag combination of pixel_shuffle / patch_unmerging /
     circular_padding.
 
@@ -516,7 +532,7 @@ def tulip_forward(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Op
     randomness (None = eval / identity).  ``taps`` collects per-stage activations.
     Returns (pred, loss, pixel_loss), or pred alone when target is None (mc_drop path).
     """
-    pr = _Prec(lowp)
+    pr = _Prec(lowp, attn_fp8)
     up = (lambda prefix, t: patch_unmerging(pr, sd, prefix, t)) if cfg.patch_unmerging else \
         (lambda prefix, t: patch_expanding(pr, sd, prefix, cfg, t))
     enc_rates, dec_rates = drop_path_rates(cfg)
@@ -562,12 +578,12 @@ def tulip_forward(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Op
 
 
 def tulip_loss_and_grads(sd: Dict[str, Tensor], cfg: TulipConfig, x: Tensor, target: Tensor,
-                         lowp: bool = False, drop_u=None):
+                         lowp: bool = False, drop_u=None, attn_fp8: bool = False):
     """Autograd of the oracle: (pred, loss, pixel_loss, {key: grad})."""
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
     full = dict(sd)
     full.update(leaves)
-    pred, loss, pixel = tulip_forward(full, cfg, x, target, lowp=lowp, drop_u=drop_u)
+    pred, loss, pixel = tulip_forward(full, cfg, x, target, lowp=lowp, drop_u=drop_u, attn_fp8=attn_fp8)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return pred.detach(), loss.detach(), pixel.detach(), grads

@@ -271,14 +271,17 @@ def test_patch_embed(ops, circular, E, Hin, Win):
 
 
 # ------------------------------------------------------------------ window attention
-def attn_reference(qkv, table, rel_index, B, H, W, C, nh, shift):
-    """tulip.py:289-323 minus the Linears, on natural-order tokens, fp32 (P rounded to bf16)."""
+def attn_reference(qkv, table, rel_index, B, H, W, C, nh, shift, fp8=False):
+    """tulip.py:289-323 minus the Linears, on natural-order tokens, fp32 (P rounded to bf16).  fp8: the scores from
+    e4m3-rounded q, k (BASELINE configs[4]; straight-through gradient)."""
     win, sft = O.effective_window(H, (2, 8), shift)
     L, P = 16, C // nh
     idx = torch.from_numpy(O.window_token_index(H, W, win, sft)).to(qkv.device)
     nW = idx.shape[0]
     t = qkv.reshape(B, H * W, 3 * C)[:, idx.reshape(-1)].reshape(B * nW, L, 3, nh, P).permute(2, 0, 3, 1, 4)
     q, k, v = t[0], t[1], t[2]
+    if fp8:
+        q, k = O._FP8Round.apply(q), O._FP8Round.apply(k)
     attn = (q @ k.transpose(-2, -1)) * P ** -0.5
     bias = table[rel_index.reshape(-1).long()].reshape(L, L, nh).permute(2, 0, 1)
     attn = attn + bias[None]
@@ -296,6 +299,19 @@ def attn_reference(qkv, table, rel_index, B, H, W, C, nh, shift):
                                         (1, 1, 32, 1536, 48), (3, 4, 64, 384, 12)])
 @pytest.mark.parametrize("shift", [False, True])
 def test_window_attention_fwd_bwd(ops, B, H, W, C, nh, shift):
+    _window_attention_fwd_bwd(ops, B, H, W, C, nh, shift, False)
+
+
+@pytest.mark.parametrize("B,H,W,C,nh", [(2, 8, 64, 48, 3), (2, 2, 32, 768, 24), (3, 4, 64, 384, 12)])
+@pytest.mark.parametrize("shift", [False, True])
+def test_window_attention_fp8_scores(ops, B, H, W, C, nh, shift):
+    """`masked` bit 1: Q.K^T from e4m3 operands (v_mfma_f32_16x16x32_fp8_fp8), against the same reference with q, k rounded
+    through torch.float8_e4m3fn -- the bf16 tolerances hold because both sides round identically."""
+    _window_attention_fwd_bwd(ops, B, H, W, C, nh, shift, True)
+
+
+def _window_attention_fwd_bwd(ops, B, H, W, C, nh, shift, fp8):
+    shift_arg = int(shift) | (2 if fp8 else 0)
     M = B * H * W
     qkv = bf(rnd(M, 3 * C, scale=1.5))
     table = rnd(45, nh, scale=0.5, seed=1)
@@ -303,17 +319,17 @@ def test_window_attention_fwd_bwd(ops, B, H, W, C, nh, shift):
     rel32 = rel.to(torch.int32).contiguous()
     win, sft = O.effective_window(H, (2, 8), shift)
     out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
-    ops.window_attn_fwd(qkv, table, rel32, out, B, H, W, C, nh, win, sft, shift)
+    ops.window_attn_fwd(qkv, table, rel32, out, B, H, W, C, nh, win, sft, shift_arg)
     qr = qkv.float().requires_grad_(True)
     tr = table.clone().requires_grad_(True)
-    ref = attn_reference(qr, tr, rel, B, H, W, C, nh, shift)
+    ref = attn_reference(qr, tr, rel, B, H, W, C, nh, shift, fp8)
     close(out, ref, 2 ** -7, 3e-3, "attn fwd")
     dout = bf(rnd(M, C, seed=3))
     ref.backward(dout.float())
     dqkv = torch.empty_like(qkv)
     R = ops.window_attn_bwd_partial_rows(B, H, W, nh, win)
     part = torch.full((R * nh, 256), float("nan"), device=DEV)
-    ops.window_attn_bwd(qkv, dout, table, rel32, dqkv, part, B, H, W, C, nh, win, sft, shift)
+    ops.window_attn_bwd(qkv, dout, table, rel32, dqkv, part, B, H, W, C, nh, win, sft, shift_arg)
     close(dqkv, qr.grad, 2 ** -5, 6e-3, "attn dqkv")
     assert torch.isfinite(part).all()
     dense = torch.zeros(nh, 16, 16, device=DEV)
@@ -506,8 +522,8 @@ def test_drop_path_scales_kernel(ops):
     assert c < 0.02
 
 
-@pytest.mark.parametrize("shifted", [False, True])
-def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted):
+@pytest.mark.parametrize("shifted,fp8", [(False, False), (True, False), (True, True)])
+def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted, fp8):
     """tulip_swin96_block_fwd (one launch for a whole stage-0 Swin block) against the 7-kernel sequence it replaces, on
     every tensor either path writes: identical up to fp32 summation order (LayerNorm statistics, K-split of the MFMAs),
     i.e. equal except for isolated bf16 rounding flips."""
@@ -524,6 +540,7 @@ def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted):
     eng.bind(torch.device(DEV, torch.cuda.current_device()))
     eng.params.refresh_shadow()                                # bf16 weights the kernels read
     assert eng.params.shadow.float().abs().sum().item() > 0
+    eng.attn_fp8 = fp8                                         # both paths then take their scores from e4m3 q, k
     saved, eng.fuse_block96 = getattr(eng, "fuse_block96", False), False
     P = eng.plan(2)
     sp = eng.enc_blocks[0][1 if shifted else 0]
@@ -568,8 +585,8 @@ def test_swin96_fused_block_forward_matches_separate_kernels(ops, shifted):
         assert torch.equal(buf["out"][: M // 2], x[: M // 2])
 
 
-@pytest.mark.parametrize("shifted", [False, True])
-def test_swin96_fused_block_backward_matches_separate_kernels(ops, shifted):
+@pytest.mark.parametrize("shifted,fp8", [(False, False), (True, False), (True, True)])
+def test_swin96_fused_block_backward_matches_separate_kernels(ops, shifted, fp8):
     """tulip_swin96_block_bwd (one launch for the data-gradient chain of a stage-0 Swin block) against the 7-kernel chain
     it replaces: the input gradient, the four weight-gradient operands it hands to the side streams, and every
     parameter gradient of the block after the folds."""
@@ -584,6 +601,7 @@ def test_swin96_fused_block_backward_matches_separate_kernels(ops, shifted):
     eng = m.engine()
     eng.bind(torch.device(DEV, torch.cuda.current_device()))
     eng.params.refresh_shadow()
+    eng.attn_fp8 = fp8
     saved = (eng.fuse_block96, eng.fuse_block96_bwd, eng.overlap_wgrad)
     eng.overlap_wgrad = False                                 # weight gradients and folds inline, on this stream
     B = 2

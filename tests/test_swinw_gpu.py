@@ -30,8 +30,9 @@ def _model(seed):
     return m, eng
 
 
-def _setup(stage, shifted, B, seed):
+def _setup(stage, shifted, B, seed, fp8=False):
     m, eng = _model(seed)
+    eng.attn_fp8 = fp8                                        # BASELINE configs[4]: attention scores from e4m3 q, k
     P = eng.plan(B)
     sp = eng.enc_blocks[stage][1 if shifted else 0]
     assert sp.shift == shifted and sp.C == 96 << stage and eng._fusable_wide(sp)
@@ -58,13 +59,23 @@ def _oracle_block(m, eng, P, sp, x, B, need_grad=False):
     if sp.slot >= 0:
         keep = torch.stack([P.drop_scale[sp.slot], P.drop_scale[sp.slot + 1]]).cpu()
     xc = x.detach().cpu().reshape(B, sp.H, sp.W, sp.C).clone().requires_grad_(need_grad)
-    out = O.swin_block(O._Prec(True), sd, sp.prefix, cfg, xc, sp.nh, sp.shift, keep)
+    out = O.swin_block(O._Prec(True, attn_fp8=eng.attn_fp8), sd, sp.prefix, cfg, xc, sp.nh, sp.shift, keep)
     return out, xc, sd
 
 
 @pytest.mark.parametrize("stage,shifted,B", CASES)
 def test_wide_block_forward(stage, shifted, B):
-    m, eng, P, sp, M, x, xin = _setup(stage, shifted, B, seed=stage)
+    _forward(stage, shifted, B, False)
+
+
+@pytest.mark.parametrize("stage,shifted,B", [(1, True, 2), (2, False, 2), (2, True, 16)])
+def test_wide_block_forward_fp8_scores(stage, shifted, B):
+    """engine.attn_fp8: fused == unfused kernel sequence and == the oracle with e4m3-rounded q, k, to the bf16 bounds."""
+    _forward(stage, shifted, B, True)
+
+
+def _forward(stage, shifted, B, fp8):
+    m, eng, P, sp, M, x, xin = _setup(stage, shifted, B, seed=stage, fp8=fp8)
     C, p = sp.C, sp.prefix
     names = ["xn1", "mean1", "rstd1", "qkv", "o", "x1", "xn2", "mean2", "rstd2", "h", "g"]
     res = {}
@@ -102,7 +113,17 @@ def test_wide_block_forward(stage, shifted, B):
 
 @pytest.mark.parametrize("stage,shifted,B", CASES)
 def test_wide_block_backward(stage, shifted, B):
-    m, eng, P, sp, M, x, xin = _setup(stage, shifted, B, seed=10 + stage)
+    _backward(stage, shifted, B, False)
+
+
+@pytest.mark.parametrize("stage,shifted,B", [(1, True, 2), (2, False, 2), (2, True, 16)])
+def test_wide_block_backward_fp8_scores(stage, shifted, B):
+    """engine.attn_fp8: the backward differentiates the function the forward ran (dS times the e4m3-rounded q, k)."""
+    _backward(stage, shifted, B, True)
+
+
+def _backward(stage, shifted, B, fp8):
+    m, eng, P, sp, M, x, xin = _setup(stage, shifted, B, seed=10 + stage, fp8=fp8)
     C, p = sp.C, sp.prefix
     saved = eng.overlap_wgrad
     eng.overlap_wgrad = False                                 # weight gradients and folds inline, on this stream

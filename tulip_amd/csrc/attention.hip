@@ -18,7 +18,7 @@ namespace {
 
 struct AttnGeom {
     int B, H, W, C, nh;
-    int wh, ww, sh, sw, masked;
+    int wh, ww, sh, sw, masked, fp8;
     int nWy, nWx;
     float scale;
 };
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             *(bf16x8*)(ldsV + li * (P * 2) + gq * 16) = v;
         }
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k, q, s, 0, 0, 0);  // s[r] = q_li . k_(4gq+r)
+        if (g.fp8) s = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf16x8_to_fp8(k), bf16x8_to_fp8(q), s, 0, 0, 0);
+        else s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k, q, s, 0, 0, 0);  // s[r] = q_li . k_(4gq+r)
         float mx = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
             k = *(const bf16x8*)(src + g.C);
             v = *(const bf16x8*)(src + 2 * g.C);
             d = *(const bf16x8*)(dout + (size_t)row * g.C + h * P + gq * 8);
+            if (g.fp8) { q = round_through_fp8(q); k = round_through_fp8(k); }     // the values the forward's scores saw
             const int off = li * (P * 2) + gq * 16;
             *(bf16x8*)(ldsQ + off) = q;
             *(bf16x8*)(ldsK + off) = k;
@@ -250,7 +252,8 @@ bool make_geom(AttnGeom& g, int B, int H, int W, int C, int nh, int wh, int ww, 
     const int P = C / nh;
     if (P != 16 && P != 32) return false;
     if (H % wh || W % ww || sh >= H + (sh == 0) || sw >= W + (sw == 0)) return false;
-    g.B = B; g.H = H; g.W = W; g.C = C; g.nh = nh; g.wh = wh; g.ww = ww; g.sh = sh; g.sw = sw; g.masked = masked;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.nh = nh; g.wh = wh; g.ww = ww; g.sh = sh; g.sw = sw;
+    g.masked = masked & TULIP_ATTN_MASKED; g.fp8 = (masked & TULIP_ATTN_FP8) ? 1 : 0;
     g.nWy = H / wh; g.nWx = W / ww;
     g.scale = 1.0f / sqrtf((float)P);
     return true;

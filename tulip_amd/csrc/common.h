@@ -30,6 +30,33 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
+// ---- fp8 (OCP e4m3, the gfx950 format) for the optional fp8 attention scores (BASELINE configs[4]) ------------------
+// eight bf16 values -> the 64-bit fp8 operand of v_mfma_f32_16x16x32_fp8_fp8 (v_cvt_pk_fp8_f32: round to nearest even)
+__device__ __forceinline__ long bf16x8_to_fp8(bf16x8 v) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)v[0]), bf2f((bf16_t)v[1]), lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)v[2]), bf2f((bf16_t)v[3]), lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)v[4]), bf2f((bf16_t)v[5]), hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)v[6]), bf2f((bf16_t)v[7]), hi, true);
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// the same values as bf16 again (every e4m3 value is a bf16 value): what the backward multiplies dS with, so that the
+// gradient is the one of the function the forward computed (straight-through across the rounding)
+__device__ __forceinline__ bf16x8 round_through_fp8(bf16x8 v) {
+    const long p = bf16x8_to_fp8(v);
+    const int lo = (int)(p & 0xffffffff), hi = (int)((unsigned long long)p >> 32);
+    const tulip_f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const tulip_f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    const uint32_t w0 = pack_bf16x2(a.x, a.y), w1 = pack_bf16x2(b.x, b.y), w2 = pack_bf16x2(c.x, c.y), w3 = pack_bf16x2(d.x, d.y);
+    typedef uint32_t u32x4_c __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(bf16x8, (u32x4_c){w0, w1, w2, w3});
+}
+// (the `masked` argument of the attention / block kernels is a bit set: TULIP_ATTN_MASKED | TULIP_ATTN_FP8, tulip_hip.h)
+#ifndef TULIP_ATTN_MASKED
+#define TULIP_ATTN_MASKED 1
+#define TULIP_ATTN_FP8 2
+#endif
+
 // a / d for a >= 0, d > 0 with d uniform over the launch (a kernel argument): the token grids, tokens per sample etc.
 // are powers of two in every configuration of the reference, and a 32-bit integer divide is ~40 VALU instructions
 // (a 64-bit one > 100) -- the scalar test picks a shift when it can.

@@ -51,6 +51,8 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
 __device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+__device__ __forceinline__ bf16x4 lo4(bf16x8 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3); }
+__device__ __forceinline__ bf16x4 hi4(bf16x8 v) { return __builtin_shufflevector(v, v, 4, 5, 6, 7); }
 // ds_read_b64_tr_b16 through the builtin: the compiler batches the waits of consecutive reads
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
@@ -181,12 +183,13 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         *(bf16x4*)(ldsV + t * 64 + (4 * gq) * 2) = qkvp[12 + 2 * h];            // V tile [token][d], d = 0..15
         *(bf16x4*)(ldsV + t * 64 + (16 + 4 * gq) * 2) = qkvp[13 + 2 * h];       // d = 16..31
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc, 0, 0, 0);
+        if (a.masked & TULIP_ATTN_FP8) sc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf16x8_to_fp8(kf), bf16x8_to_fp8(qf), sc, 0, 0, 0);
+        else sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc, 0, 0, 0);
         float mx = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float x = sc[r] * a.scale + rpb[h][r];
-            if (a.masked) {
+            if (a.masked & TULIP_ATTN_MASKED) {
                 const int kl = __shfl(lab, gq * 4 + r, 64);
                 if (kl != lab) x += -100.0f;
             }
@@ -561,13 +564,14 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     const int troff = (gq * 4 + (t >> 2)) * 64 + (t & 3) * 8;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
-        const bf16x8 qf = cat8(qkvr[2 * h], qkvr[2 * h + 1]);
-        const bf16x8 kf = cat8(qkvr[6 + 2 * h], qkvr[7 + 2 * h]);
+        bf16x8 qf = cat8(qkvr[2 * h], qkvr[2 * h + 1]);
+        bf16x8 kf = cat8(qkvr[6 + 2 * h], qkvr[7 + 2 * h]);
+        if (a.masked & TULIP_ATTN_FP8) { qf = round_through_fp8(qf); kf = round_through_fp8(kf); }   // what the forward's scores saw
         const bf16x8 vf = cat8(qkvr[12 + 2 * h], qkvr[13 + 2 * h]);
         const bf16x8 df = cat8(dop[2 * h], dop[2 * h + 1]);
         const int o0 = t * 64 + (4 * gq) * 2, o1 = t * 64 + (16 + 4 * gq) * 2;
-        *(bf16x4*)(ldsQ + o0) = qkvr[2 * h];      *(bf16x4*)(ldsQ + o1) = qkvr[2 * h + 1];
-        *(bf16x4*)(ldsK + o0) = qkvr[6 + 2 * h];  *(bf16x4*)(ldsK + o1) = qkvr[7 + 2 * h];
+        *(bf16x4*)(ldsQ + o0) = lo4(qf);  *(bf16x4*)(ldsQ + o1) = hi4(qf);
+        *(bf16x4*)(ldsK + o0) = lo4(kf);  *(bf16x4*)(ldsK + o1) = hi4(kf);
         *(bf16x4*)(ldsD + o0) = dop[2 * h];       *(bf16x4*)(ldsD + o1) = dop[2 * h + 1];
         f32x4 sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);    // S[t][4gq+r]
         f32x4 sk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);    // S[4gq+r][t]
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int r = 0; r < 4; ++r) {
             float xq = sq[r] * a.scale + bias_q[h][r];
             float xk = sk[r] * a.scale + bias_k[h][r];
-            if (a.masked) {
+            if (a.masked & TULIP_ATTN_MASKED) {
                 const int ol = __shfl(lab, gq * 4 + r, 64);
                 if (ol != lab) { xq += -100.0f; xk += -100.0f; }
             }

@@ -309,12 +309,13 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
         *(bf16x4*)(ldsV + t * 64 + (4 * gq) * 2) = qkvp[4][g];             // V tile [token][d], d = 0..15
         *(bf16x4*)(ldsV + t * 64 + (16 + 4 * gq) * 2) = qkvp[5][g];        // d = 16..31
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc, 0, 0, 0);
+        if (a.masked & TULIP_ATTN_FP8) sc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf16x8_to_fp8(kf), bf16x8_to_fp8(qf), sc, 0, 0, 0);
+        else sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc, 0, 0, 0);
         float mx = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float x = sc[r] * a.scale + rpb[r];
-            if (a.masked) {
+            if (a.masked & TULIP_ATTN_MASKED) {
                 const int kl = __shfl(lab[g], gq * 4 + r, 64);
                 if (kl != lab[g]) x += -100.0f;
             }
@@ -753,11 +754,13 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const bf16x8 qf = cat8(qkvr[0][g], qkvr[1][g]), kf = cat8(qkvr[2][g], qkvr[3][g]), vf = cat8(qkvr[4][g], qkvr[5][g]);
+            bf16x8 qf = cat8(qkvr[0][g], qkvr[1][g]), kf = cat8(qkvr[2][g], qkvr[3][g]);
+            if (a.masked & TULIP_ATTN_FP8) { qf = round_through_fp8(qf); kf = round_through_fp8(kf); }   // what the forward's scores saw
+            const bf16x8 vf = cat8(qkvr[4][g], qkvr[5][g]);
             const bf16x8 df = cat8(dop[0][g], dop[1][g]);
             const int o0 = t * 64 + (4 * gq) * 2, o1 = t * 64 + (16 + 4 * gq) * 2;
-            *(bf16x4*)(ldsQ + o0) = qkvr[0][g];  *(bf16x4*)(ldsQ + o1) = qkvr[1][g];
-            *(bf16x4*)(ldsK + o0) = qkvr[2][g];  *(bf16x4*)(ldsK + o1) = qkvr[3][g];
+            *(bf16x4*)(ldsQ + o0) = __builtin_shufflevector(qf, qf, 0, 1, 2, 3);  *(bf16x4*)(ldsQ + o1) = __builtin_shufflevector(qf, qf, 4, 5, 6, 7);
+            *(bf16x4*)(ldsK + o0) = __builtin_shufflevector(kf, kf, 0, 1, 2, 3);  *(bf16x4*)(ldsK + o1) = __builtin_shufflevector(kf, kf, 4, 5, 6, 7);
             *(bf16x4*)(ldsD + o0) = dop[0][g];   *(bf16x4*)(ldsD + o1) = dop[1][g];
             f32x4 sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);    // S[t][4gq+r]
             f32x4 sk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);    // S[4gq+r][t]
@@ -768,7 +771,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             for (int r = 0; r < 4; ++r) {
                 float xq = sq[r] * a.scale + bias_q[r];
                 float xk = sk[r] * a.scale + bias_k[r];
-                if (a.masked) {
+                if (a.masked & TULIP_ATTN_MASKED) {
                     const int ol = __shfl(lab[g], gq * 4 + r, 64);
                     if (ol != lab[g]) { xq += -100.0f; xk += -100.0f; }
                 }

@@ -440,6 +440,16 @@ class TulipEngine:
         return (sp.C == 96 and sp.nh == 3 and self.hidden(sp.C) == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
                 and sp.H % 2 == 0)
 
+    # BASELINE configs[4] "fp8 MFMA attention": the attention scores Q.K^T of every block from e4m3 operands
+    # (v_mfma_f32_16x16x32_fp8_fp8; q, k rounded from their bf16 values, round to nearest even; softmax, P.V and
+    # everything else unchanged); the backward differentiates exactly that function (it multiplies dS with the rounded
+    # q, k).  Off by default: the reference computes the scores from bf16 / fp16 operands.
+    attn_fp8 = os.environ.get("TULIP_ATTN_FP8", "0") == "1"
+
+    def _mask_arg(self, sp: BlockSpec) -> int:
+        """`masked` argument of the attention / block kernels: bit 0 shifted-window mask, bit 1 fp8 scores."""
+        return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0)
+
     fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
     fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
     # C = 192 always; C = 384 (stage 2: 3.5 MB of weights per block) from 128 windows per launch up (batch 8 at the KITTI
@@ -485,7 +495,7 @@ class TulipEngine:
                 norm2_weight=W_.p32(p + ".norm2.weight"), norm2_bias=W_.p32(p + ".norm2.bias"),
                 bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=B, H=sp.H, W=sp.W,
-                shift_h=sp.sft[0], shift_w=sp.sft[1], masked=int(sp.shift), eps=self.eps)
+                shift_h=sp.sft[0], shift_w=sp.sft[1], masked=self._mask_arg(sp), eps=self.eps)
             if out_bf16 is not None and not wide:
                 ops.cast_f32_bf16(xout, out_bf16, M, C)
             return
@@ -494,7 +504,7 @@ class TulipEngine:
         self._gemm(P[p + ".xn1"], W_.p16(p + ".attn.qkv.weight"), M, 3 * C, C, lda=C, ldb=C, epi=EPI_BF16,
                  bias=W_.p32(p + ".attn.qkv.bias"), out=P[p + ".qkv"])
         ops.window_attn_fwd(P[p + ".qkv"], W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, P[p + ".o"],
-                            B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
+                            B, sp.H, sp.W, C, nh, sp.win, sp.sft, self._mask_arg(sp))
         self._gemm(P[p + ".o"], W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, epi=EPI_RESID_F32,
                  bias=W_.p32(p + ".attn.proj.bias"), out=P[p + ".x1"], aux=xin, ldaux=C,
                  rowscale=self._ds(P, sp, 0), rows_per_sample=tok)
@@ -884,7 +894,7 @@ class TulipEngine:
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), d_out_mlp=dyb, d_fc1_pre=dh,
                 d_out_attn=P[p + ".dyb_a"], d_qkv=dqkv, dx_bf16=cb, dx_bf16_scale=cs, norm1_partials=ln1,
                 norm2_partials=ln2, bias_partials=apart, B=B, H=sp.H, W=sp.W, shift_h=sp.sft[0], shift_w=sp.sft[1],
-                masked=int(sp.shift))
+                masked=self._mask_arg(sp))
             self._release_deferred()
             self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
             self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
@@ -926,7 +936,7 @@ class TulipEngine:
         R = ops.window_attn_bwd_partial_rows(B, sp.H, sp.W, nh, sp.win)
         apart = P.scratch("apart." + p, R * nh * 256)
         ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
-                            apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, sp.shift)
+                            apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, self._mask_arg(sp))
         self._fold_bias_table(P, p, apart, R, nh, G(p + ".attn.relative_position_bias_table"))
         self._gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
                  out=dxn, ldo=C)

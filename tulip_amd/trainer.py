@@ -39,7 +39,8 @@ class Trainer:
     def __init__(self, model, batch_size: int, lr: float = 5e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, device=None, use_graph: bool = True, process_group=None,
                  bucket_mb: float = 16.0, accum_iter: int = 1, track_grad_norm: bool = False,
-                 force_segments: bool = False, bucket_adamw: Optional[bool] = None, grad_dtype: str = "fp32"):
+                 force_segments: bool = False, bucket_adamw: Optional[bool] = None, grad_dtype: str = "fp32",
+                 attn_fp8: Optional[bool] = None):
         """force_segments: run the N>1 step structure (graph segments cut at the bucket points, one all-reduce per
         bucket between replays) in a one-rank process group too -- how the RCCL path is exercised on a single GPU.
         bucket_adamw: None = environment default (TULIP_BUCKET_ADAMW, off).
@@ -50,6 +51,8 @@ class Trainer:
         device = device or torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.eng = model.engine()
+        if attn_fp8 is not None:      # BASELINE configs[4]: attention scores from e4m3 q, k (default: env TULIP_ATTN_FP8, off)
+            self.eng.attn_fp8 = bool(attn_fp8)
         self.eng.bind(device)
         self.P = self.eng.plan(batch_size)
         W = self.eng.params
