@@ -167,3 +167,21 @@ def test_cosine_lr_table(golden_dir):
     t = np.load(os.path.join(golden_dir, "g_lr_sched.npz"))["table"]
     for row in t:
         assert abs(cosine_lr(row[0], row[1], row[2], row[3], row[4]) - row[5]) <= 1e-12 * max(1.0, abs(row[5]))
+
+
+def test_oracle_e4m3_rounding_known_answers():
+    """The rounding model behind the fp8 attention scores (oracle._FP8Round = torch.float8_e4m3fn, the OCP e4m3 of
+    gfx950): round to nearest even on the 3-bit mantissa, subnormals down to 2^-9, largest finite value 448."""
+    import torch
+    from oracle import tulip_oracle as O
+    x = torch.tensor([1.0, 1.0625, 1.07, 1.1875, 17.0, 19.0, 448.0, 2.0 ** -9, 0.0009, 0.0015, -3.3, 0.0])
+    want = torch.tensor([1.0, 1.0, 1.125, 1.25, 16.0, 20.0, 448.0, 2.0 ** -9, 0.0, 2.0 ** -9, -3.25, 0.0])
+    got = O._FP8Round.apply(x)
+    assert torch.equal(got, want), (got, want)
+    # straight-through gradient, and every e4m3 value is a bf16 value (what the HIP backward relies on)
+    y = x.clone().requires_grad_(True)
+    O._FP8Round.apply(y).sum().backward()
+    assert torch.equal(y.grad, torch.ones_like(x))
+    grid = torch.arange(-448, 449, dtype=torch.float32) / 7.0
+    r = O._FP8Round.apply(grid)
+    assert torch.equal(r.to(torch.bfloat16).float(), r)
