@@ -402,7 +402,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
 }
 
 template <int BM, bool A_T, bool B_T, int KSUB>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+// (two waves per SIMD promised where the LDS footprint allows it: the compiler then keeps the accumulators in VGPRs --
+// MFMAs with AGPR accumulators issue at ~60 % of the rate, tools/probe_mfma.hip; the 128-deep k stages take 80-150 KB of LDS)
+__global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
     gemm_tile<BM, A_T, B_T, KSUB>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -416,7 +418,7 @@ struct GemmGroup {
     int n;
 };
 template <int BM, bool A_T, bool B_T, int KSUB>
-__global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroup G) {
+__global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_group_kernel(const GemmGroup G) {
     int i = 0;
     while (i + 1 < G.n && (int)blockIdx.x >= G.first[i + 1]) ++i;
     int b = blockIdx.x - G.first[i];
