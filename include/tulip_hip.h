@@ -127,6 +127,22 @@ int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, c
                         const float* dres, float* dx, int rows, int C, int merge, int B, int H, int W,
                         float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
                         int cast_rows_per_sample, hipStream_t stream);
+/* tulip_layernorm_bwd whose incoming gradient is still the `nslab` raw split-K slabs [nslab][rows][C] of the data-gradient
+ * GEMM in front (tulip_gemm_bf16 with TULIP_EPI_SPLIT_F32): folded in slab order and rounded to bf16 exactly as that
+ * GEMM's own fold launch would have stored them -- one launch less on the backward chain. */
+int tulip_layernorm_bwd_splitk(const float* slabs, int nslab, const float* x, const float* mean, const float* rstd,
+                               const float* gamma, const float* dres, float* dx, int rows, int C, int merge, int B, int H,
+                               int W, float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
+                               int cast_rows_per_sample, hipStream_t stream);
+/* Split-K fold + residual epilogue + the LayerNorm that follows (proj -> norm2, fc2 -> next block's norm1, tulip.py:344-347)
+ * in one launch, for a GEMM that left raw slabs [nslab][M][N]: out = aux + rowscale[row / rows_per_sample] * (sum slabs +
+ * bias) (aux NULL: no residual), optional bf16 copy, then ln_out = bf16(LayerNorm(out row)), mean, rstd.  N % 256 == 0,
+ * N <= 2048 (tulip_splitk_resid_ln_supported). */
+int tulip_splitk_resid_ln_supported(int N);
+int tulip_splitk_resid_ln(const float* slabs, int nslab, int M, int N, const float* bias, const float* aux, int ldaux,
+                          const float* rowscale, int rows_per_sample, float* out, int ldo, uint16_t* out_bf16, int ldo2,
+                          const float* gamma, const float* beta, uint16_t* ln_out, float* mean, float* rstd, float eps,
+                          hipStream_t stream);
 /* partial rows tulip_layernorm_bwd writes for (rows, C); 0 if C is too wide for the fused form (C > 2048) */
 int tulip_layernorm_bwd_partial_rows(int rows, int C);
 

@@ -324,3 +324,73 @@ def test_fp8_attention_scores_whole_model_vs_oracle():
     dev_orc = (opred - bpred).abs().max().item()
     print(f"fp8 vs bf16 prediction: HIP max {dev_hip:.3e}, oracle max {dev_orc:.3e}")
     assert dev_hip > 0 and dev_hip <= 4 * dev_orc + 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(512, 768, 768, 3), (512, 768, 3072, 4), (128, 1536, 1536, 4), (2048, 256, 1024, 2)])
+def test_splitk_fold_with_layernorm_fused_matches_two_launches(M, N, K, splits):
+    """tulip_splitk_resid_ln (fold of a GEMM's raw split-K slabs + bias + DropPath residual + the LayerNorm that follows, one
+    launch) against tulip_gemm_bf16's own fold launch followed by tulip_layernorm_fwd: the residual output bit for bit, the
+    normalised rows to bf16 rounding flips; and tulip_layernorm_bwd_splitk against fold + tulip_layernorm_bwd: bit for bit."""
+    from tulip_amd import ops as o
+    from tulip_amd._lib import EPI_RESID_F32, EPI_SPLIT_F32, EPI_BF16
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    rnd = lambda *s, scale=1.0: torch.randn(*s, device=DEV, generator=g) * scale
+    A, Wt = rnd(M, K, scale=0.5).bfloat16(), rnd(N, K, scale=0.05).bfloat16()
+    bias, aux = rnd(N, scale=0.1), rnd(M, N)
+    rows_per_sample = M // 4
+    rowscale = torch.tensor([1.0, 0.0, 1.1111, 1.1111], device=DEV)
+    gamma, beta = 1 + 0.1 * rnd(N), 0.1 * rnd(N)
+    ws = torch.empty(splits * M * N, device=DEV)
+    eff = o.gemm_effective_splits(K, splits)
+    # ---- two launches + LayerNorm
+    out_ref, ob_ref = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm(A, Wt, M, N, K, lda=K, ldb=K, epi=EPI_RESID_F32, bias=bias, out=out_ref, aux=aux, ldaux=N, rowscale=rowscale,
+           rows_per_sample=rows_per_sample, out2=ob_ref, ldo2=N, splits=splits, workspace=ws, workspace_bytes=ws.numel() * 4)
+    xn_ref = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    mu_ref, rs_ref = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    o.layernorm_fwd(out_ref, gamma, beta, xn_ref, mu_ref, rs_ref, M, N, 1e-6)
+    # ---- fused
+    assert o.splitk_resid_ln_supported(N)
+    o.gemm(A, Wt, M, N, K, lda=K, ldb=K, epi=EPI_SPLIT_F32, out=ws, ldo=N, splits=splits)
+    out, ob = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    xn = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    mu, rs = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    o.splitk_resid_ln(ws, eff, M, N, bias, aux, N, rowscale, rows_per_sample, out, N, ob, N, gamma, beta, xn, mu, rs, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref) and torch.equal(ob, ob_ref)
+    assert torch.allclose(mu, mu_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rs, rs_ref, rtol=1e-5, atol=1e-6)
+    d = (xn.float() - xn_ref.float()).abs()
+    assert (d > 2 ** -7 * (0.05 + xn_ref.float().abs())).float().mean().item() <= 1e-3
+    # ---- backward: the data gradient's slabs straight into the LayerNorm backward
+    dY = rnd(M, N, scale=0.5).bfloat16()                 # dxn = dY . W  with W [N][K]: C = K columns here
+    if K % 256 == 0 and o.layernorm_bwd_partial_rows(M, K) > 0:
+        x = rnd(M, K) + 0.2
+        xn2 = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+        m2, r2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        gam = 1 + 0.1 * rnd(K)
+        o.layernorm_fwd(x, gam, torch.zeros(K, device=DEV), xn2, m2, r2, M, K, 1e-6)
+        sp2 = o.gemm_effective_splits(N, 3)
+        ws2 = torch.empty(max(sp2, 1) * M * K, device=DEV)
+        dxn = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+        o.gemm(dY, Wt, M, K, N, lda=N, ldb=K, b_trans=True, epi=EPI_BF16, out=dxn, ldo=K, splits=3, workspace=ws2,
+               workspace_bytes=ws2.numel() * 4)
+        R = o.layernorm_bwd_partial_rows(M, K)
+        res = []
+        for fused in (False, True):
+            dres = rnd(M, K)
+            g.manual_seed(7)
+            dres = torch.randn(M, K, device=DEV, generator=g)
+            dx = torch.empty(M, K, device=DEV)
+            part = torch.full((R, 2 * K), float("nan"), device=DEV)
+            cast = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+            if fused:
+                o.gemm(dY, Wt, M, K, N, lda=N, ldb=K, b_trans=True, epi=EPI_SPLIT_F32, out=ws2, ldo=K, splits=3)
+                o.layernorm_bwd_splitk(ws2, sp2, x, m2, r2, gam, dres, dx, M, K, param_partials=part, dx_bf16=cast,
+                                       cast_rowscale=rowscale, cast_rows_per_sample=rows_per_sample)
+            else:
+                o.layernorm_bwd(dxn, x, m2, r2, gam, dres, dx, M, K, param_partials=part, dx_bf16=cast,
+                                cast_rowscale=rowscale, cast_rows_per_sample=rows_per_sample)
+            torch.cuda.synchronize()
+            res.append((dx.clone(), part.clone(), cast.clone()))
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)

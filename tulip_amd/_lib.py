@@ -65,6 +65,9 @@ SIGNATURES = {
     "tulip_pack_bf16_multi": [P, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
+    "tulip_layernorm_bwd_splitk": [P, I, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],
+    "tulip_splitk_resid_ln_supported": [I],
+    "tulip_splitk_resid_ln": [P, I, I, I, P, P, I, P, I, P, I, P, I, P, P, P, P, P, F, P],
     "tulip_layernorm_bwd_partial_rows": [I, I],
     "tulip_layernorm_bwd_params": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P, I, P],

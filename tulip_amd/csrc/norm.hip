@@ -83,7 +83,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, const float* dres, float* dx,
                                                      int rows, RowGeom g, float* __restrict__ ppart,
                                                      bf16_t* __restrict__ ycast, const float* __restrict__ cscale,
-                                                     int crps) {
+                                                     int crps, const float* __restrict__ slabs, int nslab) {
+    // slabs (optional, instead of dy): the incoming gradient is still the `nslab` raw split-K partial slabs
+    // [nslab][rows][C] of the data-gradient GEMM in front (tulip_gemm_bf16 with TULIP_EPI_SPLIT_F32): they are folded
+    // here, in slab order, and rounded to bf16 exactly as the GEMM's own fold launch would have stored them.
     // ycast (optional): the NEXT consumer of dx on the backward chain is always a GEMM that wants
     // bf16(dx * DropPath scale of the branch it enters) -- emitted here, from registers, instead of a cast pass.
     // PARTS: also accumulate d(gamma)=sum dy*xhat and d(beta)=sum dy over this block's rows and emit one
@@ -106,7 +109,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             const int c = lane + i * LPR;
             if (c < nch) {
                 const float4 xv = *(const float4*)(x + src_off(g, row, c * 4));
-                const uint2 d = *(const uint2*)(dy + (size_t)row * g.C + c * 4);
+                uint2 d;
+                if (slabs) {
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int sidx = 0; sidx < nslab; ++sidx) {
+                        const float4 v = *(const float4*)(slabs + ((size_t)sidx * rows + row) * g.C + c * 4);
+                        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                    }
+                    d = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+                } else {
+                    d = *(const uint2*)(dy + (size_t)row * g.C + c * 4);
+                }
                 const float4 ga = *(const float4*)(gamma + c * 4);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 const float d0 = bf2f((bf16_t)(d.x & 0xffff)), d1 = bf2f((bf16_t)(d.x >> 16));
@@ -606,6 +619,94 @@ extern "C" int tulip_layernorm_fwd(const float* x, const float* gamma, const flo
     });
 }
 
+// ------------------------------------------------------------------ split-K fold + residual epilogue + LayerNorm
+// One wave per output row of a GEMM that left raw split-K slabs (TULIP_EPI_SPLIT_F32): fold the slabs in slab order, add the
+// bias, form the residual output exactly as tulip_gemm_bf16's own fold launch would (out = aux + rowscale * v), and
+// normalise the row it already holds -- the LayerNorm that follows the proj / fc2 Linear of an unfused Swin block
+// (tulip.py:344-347) costs no launch of its own.
+template <int NCH>
+__global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __restrict__ slabs, int nslab, int M, int N,
+                                                              const float* __restrict__ bias, const float* __restrict__ aux,
+                                                              int ldaux, const float* __restrict__ rowscale, int rps,
+                                                              float* __restrict__ out, int ldo, bf16_t* __restrict__ out_bf16,
+                                                              int ldo2, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, bf16_t* __restrict__ ln_out,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float sc = rowscale ? rowscale[fast_div(row, rps)] : 1.0f;
+    float4 v[NCH];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + i * 64) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sidx = 0; sidx < nslab; ++sidx) {
+            const float4 t = *(const float4*)(slabs + ((size_t)sidx * M + row) * N + c);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (bias) {
+            const float4 b = *(const float4*)(bias + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (aux) {
+            const float4 q = *(const float4*)(aux + (size_t)row * ldaux + c);
+            a = make_float4(q.x + sc * a.x, q.y + sc * a.y, q.z + sc * a.z, q.w + sc * a.w);
+        }
+        *(float4*)(out + (size_t)row * ldo + c) = a;
+        if (out_bf16) *(uint2*)(out_bf16 + (size_t)row * ldo2 + c) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+        v[i] = a;
+        s1 += (a.x + a.y) + (a.z + a.w);
+    }
+    const float mu = group_sum<64>(s1) / (float)N;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const float d0 = v[i].x - mu, d1 = v[i].y - mu, d2 = v[i].z - mu, d3 = v[i].w - mu;
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float rs = rsqrtf(group_sum<64>(s2) / (float)N + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + i * 64) * 4;
+        const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+        *(uint2*)(ln_out + (size_t)row * N + c) =
+            make_uint2(pack_bf16x2((v[i].x - mu) * rs * ga.x + be.x, (v[i].y - mu) * rs * ga.y + be.y),
+                       pack_bf16x2((v[i].z - mu) * rs * ga.z + be.z, (v[i].w - mu) * rs * ga.w + be.w));
+    }
+}
+
+extern "C" int tulip_splitk_resid_ln_supported(int N) { return N > 0 && N % 256 == 0 && N <= 2048; }
+
+extern "C" int tulip_splitk_resid_ln(const float* slabs, int nslab, int M, int N, const float* bias, const float* aux,
+                                     int ldaux, const float* rowscale, int rows_per_sample, float* out, int ldo,
+                                     uint16_t* out_bf16, int ldo2, const float* gamma, const float* beta, uint16_t* ln_out,
+                                     float* mean, float* rstd, float eps, hipStream_t stream) {
+    if (M <= 0) return TULIP_OK;
+    if (!slabs || nslab < 1 || !tulip_splitk_resid_ln_supported(N) || !out || !gamma || !beta || !ln_out || !mean || !rstd ||
+        (ldo & 3) || (aux && (ldaux & 3)) || (out_bf16 && (ldo2 & 3)))
+        return TULIP_ERR_ARG;
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    const dim3 grid((M + 3) / 4);
+#define TULIP_SKLN(NCH)                                                                                                     \
+    hipLaunchKernelGGL((splitk_resid_ln_kernel<NCH>), grid, dim3(256), 0, stream, slabs, nslab, M, N, bias, aux, ldaux, rowscale, \
+                       rps, out, ldo, (bf16_t*)out_bf16, ldo2, gamma, beta, (bf16_t*)ln_out, mean, rstd, eps)
+    switch (N / 256) {
+        case 1: TULIP_SKLN(1); break;
+        case 2: TULIP_SKLN(2); break;
+        case 3: TULIP_SKLN(3); break;
+        case 4: TULIP_SKLN(4); break;
+        case 6: TULIP_SKLN(6); break;
+        case 8: TULIP_SKLN(8); break;
+        default: return TULIP_ERR_ARG;
+    }
+#undef TULIP_SKLN
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
 // partial rows ([2C] each) tulip_layernorm_bwd emits for (rows, C); 0 = fused parameter partials unsupported
 static int ln_bwd_part_rows(int rows, int C) {
     const int nch = C >> 2;
@@ -616,10 +717,32 @@ static int ln_bwd_part_rows(int rows, int C) {
 
 extern "C" int tulip_layernorm_bwd_partial_rows(int rows, int C) { return rows > 0 ? ln_bwd_part_rows(rows, C) : 0; }
 
+static int layernorm_bwd_impl(const uint16_t* dy, const float* slabs, int nslab, const float* x, const float* mean,
+                              const float* rstd, const float* gamma, const float* dres, float* dx, int rows, int C, int merge,
+                              int B, int H, int W, float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
+                              int cast_rows_per_sample, hipStream_t stream);
+
 extern "C" int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const float* mean, const float* rstd,
                                    const float* gamma, const float* dres, float* dx, int rows, int C, int merge, int B,
                                    int H, int W, float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
                                    int cast_rows_per_sample, hipStream_t stream) {
+    return layernorm_bwd_impl(dy, nullptr, 0, x, mean, rstd, gamma, dres, dx, rows, C, merge, B, H, W, param_partials, dx_bf16,
+                              cast_rowscale, cast_rows_per_sample, stream);
+}
+
+extern "C" int tulip_layernorm_bwd_splitk(const float* slabs, int nslab, const float* x, const float* mean, const float* rstd,
+                                          const float* gamma, const float* dres, float* dx, int rows, int C, int merge,
+                                          int B, int H, int W, float* param_partials, uint16_t* dx_bf16,
+                                          const float* cast_rowscale, int cast_rows_per_sample, hipStream_t stream) {
+    if (!slabs || nslab < 1) return TULIP_ERR_ARG;
+    return layernorm_bwd_impl(nullptr, slabs, nslab, x, mean, rstd, gamma, dres, dx, rows, C, merge, B, H, W, param_partials,
+                              dx_bf16, cast_rowscale, cast_rows_per_sample, stream);
+}
+
+static int layernorm_bwd_impl(const uint16_t* dy, const float* slabs, int nslab, const float* x, const float* mean,
+                              const float* rstd, const float* gamma, const float* dres, float* dx, int rows, int C, int merge,
+                              int B, int H, int W, float* param_partials, uint16_t* dx_bf16, const float* cast_rowscale,
+                              int cast_rows_per_sample, hipStream_t stream) {
     if (rows <= 0) return TULIP_OK;
     if (!geom_ok(rows, C, merge, B, H, W)) return TULIP_ERR_ARG;
     if (param_partials && ln_bwd_part_rows(rows, C) == 0) return TULIP_ERR_ARG;
@@ -632,7 +755,7 @@ extern "C" int tulip_layernorm_bwd(const uint16_t* dy, const float* x, const flo
         const size_t lds = param_partials ? (size_t)rpb * 2 * C * sizeof(float) : 0;
         hipLaunchKernelGGL((ln_bwd_kernel<LPR, NCH>), dim3(grid), dim3(256), lds, stream, dy, x, mean, rstd, gamma,
                            dres, dx, rows, g, param_partials, dx_bf16, cast_rowscale,
-                           cast_rows_per_sample > 0 ? cast_rows_per_sample : 1);
+                           cast_rows_per_sample > 0 ? cast_rows_per_sample : 1, slabs, nslab);
         TULIP_CHECK_LAUNCH();
         return TULIP_OK;
     });

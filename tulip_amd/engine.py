@@ -472,8 +472,34 @@ class TulipEngine:
     def _fused_bwd(self, sp: BlockSpec, B: int) -> bool:
         return (self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
 
-    def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout, out_bf16=None):
-        """out_bf16: the block output also leaves as a bf16 [M][C] copy (operand of a PatchUnmerging GEMM)."""
+    fuse_splitk_ln = os.environ.get("TULIP_FUSE_SPLITK_LN", "1") != "0"
+
+    def _unfused(self, sp: BlockSpec, B: int) -> bool:
+        return not ((self.fuse_wide and self._fusable_wide(sp, B)) or (self.fuse_block96 and self._fusable96(sp)))
+
+    def _gemm_resid_ln(self, A, Wt, M, N, K, *, lda, ldb, bias, out, aux, rowscale, tok, ln, out2=None):
+        """Linear + DropPath residual (EPI_RESID_F32) followed by a LayerNorm of its output rows, ln = (gamma, beta, xn, mean,
+        rstd).  Where the GEMM is split along K anyway (the M = 512..2048 GEMMs of the deep stages, see _gemm) its fold
+        launch also normalises the rows it holds (tulip_splitk_resid_ln); otherwise GEMM and LayerNorm are two launches."""
+        gamma, beta, xn, mean, rstd = ln
+        gn = (N + 95) // 96
+        blocks = ((M + 63) // 64) * gn if ((M + 127) // 128) * gn < 256 else ((M + 127) // 128) * gn
+        s = 1
+        if self.fuse_splitk_ln and blocks <= 96 and K >= 768 and ops.splitk_resid_ln_supported(N):
+            s = ops.gemm_effective_splits(K, max(1, min(256 // blocks, K // 256, (self.WS_ELEMS * 4) // (M * N * 4))))
+        if s > 1:
+            ops.gemm(A, Wt, M, N, K, lda=lda, ldb=ldb, epi=EPI_SPLIT_F32, out=self._ws_ptr, ldo=N, splits=s)
+            ops.splitk_resid_ln(self._ws_ptr, s, M, N, bias, aux, N, rowscale, tok, out, N, out2, N if out2 is not None else 0,
+                                gamma, beta, xn, mean, rstd, self.eps)
+            return
+        self._gemm(A, Wt, M, N, K, lda=lda, ldb=ldb, epi=EPI_RESID_F32, bias=bias, out=out, aux=aux, ldaux=N,
+                   rowscale=rowscale, rows_per_sample=tok, out2=out2, ldo2=N if out2 is not None else 0)
+        ops.layernorm_fwd(out, gamma, beta, xn, mean, rstd, M, N, self.eps)
+
+    def _block_fwd(self, P: Plan, sp: BlockSpec, xin, xout, out_bf16=None, ln1_done=False, next_sp=None):
+        """out_bf16: the block output also leaves as a bf16 [M][C] copy (operand of a PatchUnmerging GEMM).
+        ln1_done: the previous (unfused) block's fc2 launch already wrote this block's xn1 / mean1 / rstd1;
+        next_sp: the next block of the stage if it runs unfused too -- its norm1 then rides in this block's fc2 fold."""
         W_ = self.params
         p = sp.prefix
         B, C, nh = P.B, sp.C, sp.nh
@@ -499,19 +525,27 @@ class TulipEngine:
             if out_bf16 is not None and not wide:
                 ops.cast_f32_bf16(xout, out_bf16, M, C)
             return
-        ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
-                          P[p + ".mean1"], P[p + ".rstd1"], M, C, self.eps)
+        if not ln1_done:
+            ops.layernorm_fwd(xin, W_.p32(p + ".norm1.weight"), W_.p32(p + ".norm1.bias"), P[p + ".xn1"],
+                              P[p + ".mean1"], P[p + ".rstd1"], M, C, self.eps)
         self._gemm(P[p + ".xn1"], W_.p16(p + ".attn.qkv.weight"), M, 3 * C, C, lda=C, ldb=C, epi=EPI_BF16,
                  bias=W_.p32(p + ".attn.qkv.bias"), out=P[p + ".qkv"])
         ops.window_attn_fwd(P[p + ".qkv"], W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, P[p + ".o"],
                             B, sp.H, sp.W, C, nh, sp.win, sp.sft, self._mask_arg(sp))
-        self._gemm(P[p + ".o"], W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C, epi=EPI_RESID_F32,
-                 bias=W_.p32(p + ".attn.proj.bias"), out=P[p + ".x1"], aux=xin, ldaux=C,
-                 rowscale=self._ds(P, sp, 0), rows_per_sample=tok)
-        ops.layernorm_fwd(P[p + ".x1"], W_.p32(p + ".norm2.weight"), W_.p32(p + ".norm2.bias"), P[p + ".xn2"],
-                          P[p + ".mean2"], P[p + ".rstd2"], M, C, self.eps)
+        self._gemm_resid_ln(P[p + ".o"], W_.p16(p + ".attn.proj.weight"), M, C, C, lda=C, ldb=C,
+                            bias=W_.p32(p + ".attn.proj.bias"), out=P[p + ".x1"], aux=xin, rowscale=self._ds(P, sp, 0), tok=tok,
+                            ln=(W_.p32(p + ".norm2.weight"), W_.p32(p + ".norm2.bias"), P[p + ".xn2"], P[p + ".mean2"],
+                                P[p + ".rstd2"]))
         self._gemm(P[p + ".xn2"], W_.p16(p + ".mlp.fc1.weight"), M, Hd, C, lda=C, ldb=C, epi=EPI_GELU_DUAL,
                  bias=W_.p32(p + ".mlp.fc1.bias"), out=P[p + ".h"], out2=P[p + ".g"], ldo2=Hd)
+        if next_sp is not None:
+            q = next_sp.prefix
+            self._gemm_resid_ln(P[p + ".g"], W_.p16(p + ".mlp.fc2.weight"), M, C, Hd, lda=Hd, ldb=Hd,
+                                bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], rowscale=self._ds(P, sp, 1),
+                                tok=tok, out2=out_bf16,
+                                ln=(W_.p32(q + ".norm1.weight"), W_.p32(q + ".norm1.bias"), P[q + ".xn1"], P[q + ".mean1"],
+                                    P[q + ".rstd1"]))
+            return
         self._gemm(P[p + ".g"], W_.p16(p + ".mlp.fc2.weight"), M, C, Hd, lda=Hd, ldb=Hd, epi=EPI_RESID_F32,
                  bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], ldaux=C,
                  rowscale=self._ds(P, sp, 1), rows_per_sample=tok, out2=out_bf16, ldo2=C if out_bf16 is not None else 0)
@@ -519,8 +553,14 @@ class TulipEngine:
     def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin, out_bf16=None):
         """out_bf16: bf16 copy of the stage output, written by the last block's fc2 epilogue."""
         x = xin
+        ln1_done = False
         for k, sp in enumerate(specs):
-            self._block_fwd(P, sp, x, P[sp.prefix + ".out"], out_bf16 if k == len(specs) - 1 else None)
+            nxt = specs[k + 1] if k + 1 < len(specs) else None
+            chain = (nxt is not None and self._unfused(sp, P.B) and self._unfused(nxt, P.B) and nxt.C == sp.C
+                     and nxt.H == sp.H and nxt.W == sp.W)
+            self._block_fwd(P, sp, x, P[sp.prefix + ".out"], out_bf16 if k == len(specs) - 1 else None, ln1_done=ln1_done,
+                            next_sp=nxt if chain else None)
+            ln1_done = chain
             x = P[sp.prefix + ".out"]
         return x
 
@@ -836,8 +876,24 @@ class TulipEngine:
                  splits=splits, out2=wsb)
         ops.reduce_rows2(ws, Nw * Kw, gout, Nw * Kw, wsb, Nw, gbias, Nw if gbias is not None else 0, splits)
 
+    def _dgrad_ln_bwd(self, P: Plan, dY, Wt, M, C, K, dxn, ln_args, ln_kw):
+        """Data gradient of a Linear whose input came out of a LayerNorm (fc1 / qkv): dxn = dY . W, then the LayerNorm
+        backward.  Where the GEMM is split along K its raw slabs go straight into the LayerNorm backward, which folds them
+        (tulip_layernorm_bwd_splitk) -- the fold launch disappears; same bits as the two-launch form."""
+        gn = (C + 95) // 96
+        blocks = ((M + 63) // 64) * gn if ((M + 127) // 128) * gn < 256 else ((M + 127) // 128) * gn
+        s = 1
+        if self.fuse_splitk_ln and blocks <= 96 and K >= 768 and ops.layernorm_bwd_partial_rows(M, C) > 0:
+            s = ops.gemm_effective_splits(K, max(1, min(256 // blocks, K // 256, (self.WS_ELEMS * 4) // (M * C * 4))))
+        if s > 1:
+            ops.gemm(dY, Wt, M, C, K, lda=K, ldb=C, b_trans=True, epi=EPI_SPLIT_F32, out=self._ws_ptr, ldo=C, splits=s)
+            self._ln_bwd(P, None, *ln_args, slabs=(self._ws_ptr, s), **ln_kw)
+            return
+        self._gemm(dY, Wt, M, C, K, lda=K, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn, ldo=C)
+        self._ln_bwd(P, dxn, *ln_args, **ln_kw)
+
     def _ln_bwd(self, P: Plan, dy, x, mean, rstd, gamma, dres, dx, rows, C, gw, gb, tag, merge=False, H=0, W=0,
-                cast=None):
+                cast=None, slabs=None):
         """LayerNorm backward: dx (+= dres) on the main chain; the affine gradients leave as per-workgroup
         partial rows (private buffer `tag`) that are folded on the side stream.  cast = (bf16 buffer,
         rowscale address or None, tokens per sample): the operand of the next GEMM on the chain,
@@ -850,8 +906,12 @@ class TulipEngine:
                               dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
             return
         part = P.scratch("lnp." + tag, nrows * 2 * C)
-        ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
-                          param_partials=part, dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
+        if slabs is not None:          # the incoming gradient is still the raw split-K slabs of the GEMM in front
+            ops.layernorm_bwd_splitk(slabs[0], slabs[1], x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H,
+                                     W=W, param_partials=part, dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
+        else:
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
+                              param_partials=part, dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
         self._fold(part, 2 * C, gw, C, nrows)
         self._fold(part + 4 * C, 2 * C, gb, C, nrows)
 
@@ -918,12 +978,11 @@ class TulipEngine:
                  ldo=Hd, aux=P[p + ".h"], ldaux=Hd)
         self._release_deferred()
         self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
-        self._gemm(dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, lda=Hd, ldb=C, b_trans=True, epi=EPI_BF16, out=dxn,
-                 ldo=C)
+        self._dgrad_ln_bwd(P, dh, W_.p16(p + ".mlp.fc1.weight"), M, C, Hd, dxn,
+                           (P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
+                            G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2"),
+                           dict(cast=(P[p + ".dyb_a"], self._ds(P, sp, 0), tok)))
         self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
-        self._ln_bwd(P, dxn, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
-                     G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2",
-                     cast=(P[p + ".dyb_a"], self._ds(P, sp, 0), tok))
         if sp.prefix in self.early_flush:
             # the last blocks of the backward: nothing is left to hide their weight gradients behind, so the MLP
             # half starts as soon as its operands exist instead of at the end of the block
@@ -938,11 +997,10 @@ class TulipEngine:
         ops.window_attn_bwd(P[p + ".qkv"], dO, W_.p32(p + ".attn.relative_position_bias_table"), self._rel32, dqkv,
                             apart, B, sp.H, sp.W, C, nh, sp.win, sp.sft, self._mask_arg(sp))
         self._fold_bias_table(P, p, apart, R, nh, G(p + ".attn.relative_position_bias_table"))
-        self._gemm(dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, lda=3 * C, ldb=C, b_trans=True, epi=EPI_BF16,
-                 out=dxn, ldo=C)
+        self._dgrad_ln_bwd(P, dqkv, W_.p16(p + ".attn.qkv.weight"), M, C, 3 * C, dxn,
+                           (xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
+                            G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1"), dict(cast=next_cast))
         self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
-        self._ln_bwd(P, dxn, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
-                     G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1", cast=next_cast)
         if self._lagged_hook is not None:
             fn, self._lagged_hook = self._lagged_hook, None
             fn()                                    # bucket join + all-reduce of the previous group, one block late

@@ -59,6 +59,27 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0,
     check(rc, "tulip_layernorm_bwd")
 
 
+def layernorm_bwd_splitk(slabs, nslab, x, mean, rstd, gamma, dres, dx, rows, C, merge=False, B=0, H=0, W=0,
+                         param_partials=None, dx_bf16=None, cast_rowscale=None, cast_rows_per_sample=1):
+    """layernorm_bwd on the raw split-K slabs of the data-gradient GEMM in front (tulip_layernorm_bwd_splitk)."""
+    rc = _lib.load().tulip_layernorm_bwd_splitk(_p(slabs), nslab, _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx),
+                                                rows, C, int(merge), B, H, W, _p(param_partials), _p(dx_bf16),
+                                                _p(cast_rowscale), cast_rows_per_sample, _stream())
+    check(rc, "tulip_layernorm_bwd_splitk")
+
+
+def splitk_resid_ln_supported(N):
+    return bool(_lib.load().tulip_splitk_resid_ln_supported(N))
+
+
+def splitk_resid_ln(slabs, nslab, M, N, bias, aux, ldaux, rowscale, rows_per_sample, out, ldo, out_bf16, ldo2, gamma, beta,
+                    ln_out, mean, rstd, eps):
+    """Split-K fold + residual epilogue + the following LayerNorm in one launch (tulip_splitk_resid_ln)."""
+    check(_lib.load().tulip_splitk_resid_ln(_p(slabs), nslab, M, N, _p(bias), _p(aux), ldaux, _p(rowscale), rows_per_sample,
+                                            _p(out), ldo, _p(out_bf16), ldo2, _p(gamma), _p(beta), _p(ln_out), _p(mean),
+                                            _p(rstd), eps, _stream()), "tulip_splitk_resid_ln")
+
+
 def layernorm_bwd_partial_rows(rows, C):
     return _lib.load().tulip_layernorm_bwd_partial_rows(rows, C)
 
