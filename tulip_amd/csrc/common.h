@@ -30,6 +30,21 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
+// Two adjacent 16-column tiles of one output row in the MFMA accumulator layout -- lane (t, gq) holds 4 bf16 of tile A at
+// columns 4 gq and 4 bf16 of tile B at columns 16 + 4 gq -- leave as ONE 16-byte store per lane instead of two 8-byte
+// ones: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other, after which an
+// even-gq lane holds columns [4 gq, 4 gq + 8) of tile A and an odd-gq lane columns [4 (gq - 1), + 8) of tile B.  The
+// fused block kernels are store-ISSUE bound in their write-outs: same bytes, same addresses, half the instructions.
+__device__ __forceinline__ void store_bf16_tile_pair(bf16_t* rowp, bf16x4 A, bf16x4 B, int gq) {
+    typedef uint32_t u32x2_c __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4_c2 __attribute__((ext_vector_type(4)));
+    const u32x2_c a = __builtin_bit_cast(u32x2_c, A), b = __builtin_bit_cast(u32x2_c, B);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    const int col = (gq & 1) ? 16 + 4 * (gq - 1) : 4 * gq;
+    *(u32x4_c2*)(rowp + col) = (u32x4_c2){r0[0], r1[0], r0[1], r1[1]};
+}
+
 // ---- fp8 (OCP e4m3, the gfx950 format) for the optional fp8 attention scores (BASELINE configs[4]) ------------------
 // eight bf16 values -> the 64-bit fp8 operand of v_mfma_f32_16x16x32_fp8_fp8 (v_cvt_pk_fp8_f32: round to nearest even)
 __device__ __forceinline__ long bf16x8_to_fp8(bf16x8 v) {

@@ -153,10 +153,12 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const float4 ga = *(const float4*)(a.g1 + c0), be = *(const float4*)(a.be1 + c0);
             p1[n] = pack4((xv[n][0] - mu) * rs * ga.x + be.x, (xv[n][1] - mu) * rs * ga.y + be.y,
                           (xv[n][2] - mu) * rs * ga.z + be.z, (xv[n][3] - mu) * rs * ga.w + be.w);
-            *(bf16x4*)(a.xn1 + row * C + c0) = p1[n];
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s) xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
+        for (int s = 0; s < 3; ++s) {
+            store_bf16_tile_pair(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
+            xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
+        }
     }
     __syncthreads();                                        // weights of phase 1, W2 and the parameter vectors are in LDS
 
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), xfrag[s], acc, 0, 0, 0);
         const float4 bq = *(const float4*)(prm + P_BQKV + 16 * j + 4 * gq);
         qkvp[j] = pack4(acc[0] + bq.x, acc[1] + bq.y, acc[2] + bq.z, acc[3] + bq.w);
-        *(bf16x4*)(a.qkv + row * 288 + 16 * j + 4 * gq) = qkvp[j];
+        if (j & 1) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
     }
 
     // ---- attention, one head at a time (tulip.py:300-317); scores issued as K.Q^T: lane = query t, keys 4gq + r
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb, o, 0, 0, 0);   // o[r] = O[t][16dc + 4gq + r]
             op[dc] = pack4(o[0], o[1], o[2], o[3]);
-            *(bf16x4*)(a.o + row * C + 32 * h + 16 * dc + 4 * gq) = op[dc];
         }
+        store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
 
@@ -253,10 +255,12 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const float4 ga = *(const float4*)(prm + P_G2 + c0), be = *(const float4*)(prm + P_BE2 + c0);
             p2[n2] = pack4((xv[n2][0] - mu) * rs * ga.x + be.x, (xv[n2][1] - mu) * rs * ga.y + be.y,
                            (xv[n2][2] - mu) * rs * ga.z + be.z, (xv[n2][3] - mu) * rs * ga.w + be.w);
-            *(bf16x4*)(a.xn2 + row * C + c0) = p2[n2];
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s) x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
+        for (int s = 0; s < 3; ++s) {
+            store_bf16_tile_pair(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
+            x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
+        }
     }
 
     // ---- fc1 weights replace qkv/proj weights in LDS
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     for (int n2 = 0; n2 < 6; ++n2) acc3[n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int p = 0; p < 12; ++p) {
-        bf16x4 gp[2];
+        bf16x4 gp[2], hq[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * p + jj;
@@ -282,12 +286,13 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const int c0 = 16 * j + 4 * gq;
             const float4 bb = *(const float4*)(prm + P_B1 + c0);
             const bf16x4 hp = pack4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
-            *(bf16x4*)(a.h + row * HID + c0) = hp;
+            hq[jj] = hp;
             const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
             const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
             gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
-            *(bf16x4*)(a.g + row * HID + c0) = gp[jj];
         }
+        store_bf16_tile_pair(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
+        store_bf16_tile_pair(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
         const bf16x8 gf = cat8(gp[0], gp[1]);
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
@@ -463,10 +468,12 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
 #pragma unroll
         for (int n = 0; n < 6; ++n) {
             pk[n] = pack4(dy[n][0] * s1v, dy[n][1] * s1v, dy[n][2] * s1v, dy[n][3] * s1v);
-            *(bf16x4*)(a.dyb_m + row * C + 16 * n + 4 * gq) = pk[n];
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s) dyf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
+        for (int s = 0; s < 3; ++s) {
+            store_bf16_tile_pair(a.dyb_m + row * C + 32 * s, pk[2 * s], pk[2 * s + 1], gq);
+            dyf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
+        }
     }
     const float mu2 = a.mean2[row], rs2 = a.rstd2[row];
     // relative-position bias seen from the query side (query t, key 4gq+r) and from the key side (query 4gq+r, key t)
@@ -500,8 +507,8 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hc[jj][0]), bf2f((bf16_t)hc[jj][1])});
             const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hc[jj][2]), bf2f((bf16_t)hc[jj][3])});
             dp[jj] = pack4(acc[0] * d01.x, acc[1] * d01.y, acc[2] * d23.x, acc[3] * d23.y);
-            *(bf16x4*)(a.dh + row * HID + j0 + 4 * gq) = dp[jj];
         }
+        store_bf16_tile_pair(a.dh + row * HID + 32 * p, dp[0], dp[1], gq);
         const bf16x8 df = cat8(dp[0], dp[1]);
 #pragma unroll
         for (int n = 0; n < 6; ++n)
@@ -527,10 +534,12 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int n = 0; n < 6; ++n) {
             dy[n] += acc2[n];
             pk[n] = pack4(dy[n][0] * s0, dy[n][1] * s0, dy[n][2] * s0, dy[n][3] * s0);
-            *(bf16x4*)(a.dyb_a + row * C + 16 * n + 4 * gq) = pk[n];
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s) daf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
+        for (int s = 0; s < 3; ++s) {
+            store_bf16_tile_pair(a.dyb_a + row * C + 32 * s, pk[2 * s], pk[2 * s + 1], gq);
+            daf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
+        }
     }
     // q, k, v of this token, all heads, in the chained k order (dims 4gq.., 16+4gq.. of each head)
     bf16x4 qkvr[18];
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 18; ++j) *(bf16x4*)(a.dqkv + row * 288 + 16 * j + 4 * gq) = dqkvp[j];
+    for (int j = 0; j < 9; ++j) store_bf16_tile_pair(a.dqkv + row * 288 + 32 * j, dqkvp[2 * j], dqkvp[2 * j + 1], gq);
 
     // ---- qkv' : dxn1 = dqkv . Wqkv  (tulip.py:298 backwards), then norm1' and the residual
     f32x4 acc1[6], xv[6];
@@ -650,11 +659,16 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     float red1[3];
     ln_bwd_row(acc1, xv, mu1, rs1, gam + C, t, gq, red1);
     const float cs = a.dx_scale ? a.dx_scale[b] : 1.0f;
+    bf16x4 ob[6];
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
         const f32x4 o = dy[n] + acc1[n];
         *(float4*)(a.dx + row * C + 16 * n + 4 * gq) = make_float4(o[0], o[1], o[2], o[3]);
-        if (a.dx_bf16) *(bf16x4*)(a.dx_bf16 + row * C + 16 * n + 4 * gq) = pack4(o[0] * cs, o[1] * cs, o[2] * cs, o[3] * cs);
+        ob[n] = pack4(o[0] * cs, o[1] * cs, o[2] * cs, o[3] * cs);
+    }
+    if (a.dx_bf16) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) store_bf16_tile_pair(a.dx_bf16 + row * C + 32 * n, ob[2 * n], ob[2 * n + 1], gq);
     }
     put_red(redw + NW * 192 + wid * 192, red1, t, gq);
     __syncthreads();

@@ -287,7 +287,8 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 qkvp[i][g] = pack4(acc[i][g][0] + bqi[0], acc[i][g][1] + bqi[1], acc[i][g][2] + bqi[2], acc[i][g][3] + bqi[3]);
-                *(bf16x4*)(a.qkv + rows[g] * (3 * C) + n) = qkvp[i][g];
+                if (i & 1)      // two adjacent tiles: one 16-byte store per lane (common.h)
+                    store_bf16_tile_pair(a.qkv + rows[g] * (3 * C) + n - 16 - 4 * gq, qkvp[i - 1][g], qkvp[i][g], gq);
             }
         }
     }
@@ -331,16 +332,16 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
         const bf16x4 pb = pack4(sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv);
+        bf16x4 opp[2];
 #pragma unroll
         for (int dc = 0; dc < 2; ++dc) {
             const bf16x4 vt = trr(ldsV + (gq * 4 + (t >> 2)) * 64 + dc * 32 + (t & 3) * 8);
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb, o, 0, 0, 0);   // o[r] = O[t][16dc + 4gq + r]
-            const bf16x4 op = pack4(o[0], o[1], o[2], o[3]);
-            const int c = 32 * wid + 16 * dc + 4 * gq;
-            *(bf16x4*)(a.o + rows[g] * C + c) = op;
-            put4<T>(XO, 16 * g + t, c, op);
+            opp[dc] = pack4(o[0], o[1], o[2], o[3]);
+            put4<T>(XO, 16 * g + t, 32 * wid + 16 * dc + 4 * gq, opp[dc]);
         }
+        store_bf16_tile_pair(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
     }
     TULIP_STAMP(5);
     __syncthreads();
@@ -397,14 +398,15 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
         for (int w = 0; w < NWV; ++w) { const float d = st[w].x - mu; m2 += st[w].y + 32.0f * d * d; }
         const float rs = rsqrtf(m2 * (1.0f / C) + a.eps);
         if (wid == 0 && gq == 0) { a.mean2[rows[g]] = mu; a.rstd2[rows[g]] = rs; }
+        bf16x4 pk2[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c0 = 32 * wid + 16 * i + 4 * gq;
-            const bf16x4 pk = pack4((x1v[i][g][0] - mu) * rs * ga2[i][0] + be2[i][0], (x1v[i][g][1] - mu) * rs * ga2[i][1] + be2[i][1],
-                                    (x1v[i][g][2] - mu) * rs * ga2[i][2] + be2[i][2], (x1v[i][g][3] - mu) * rs * ga2[i][3] + be2[i][3]);
-            *(bf16x4*)(a.xn2 + rows[g] * C + c0) = pk;
-            put4<T>(XN, 16 * g + t, c0, pk);
+            pk2[i] = pack4((x1v[i][g][0] - mu) * rs * ga2[i][0] + be2[i][0], (x1v[i][g][1] - mu) * rs * ga2[i][1] + be2[i][1],
+                           (x1v[i][g][2] - mu) * rs * ga2[i][2] + be2[i][2], (x1v[i][g][3] - mu) * rs * ga2[i][3] + be2[i][3]);
+            put4<T>(XN, 16 * g + t, c0, pk2[i]);
         }
+        store_bf16_tile_pair(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
     }
     f32x4 b1v[D == 2 ? 2 : 1][4];
     if constexpr (D == 2) {
@@ -425,6 +427,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
     for (int i = 0; i < 2; ++i) w2s.wt[i] = wtile_ptr(a.w2, 2 * wid + i, HID, lane);
     auto fc1_out = [&](const f32x4 (&acc)[4][G], int ch) {
+        bf16x4 hprev[G], gprev[G];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
@@ -433,12 +436,17 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const bf16x4 hp = pack4(acc[i][g][0] + bb[0], acc[i][g][1] + bb[1], acc[i][g][2] + bb[2], acc[i][g][3] + bb[3]);
-                *(bf16x4*)(a.h + rows[g] * HID + n) = hp;
                 const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
                 const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
                 const bf16x4 gp = pack4(g01.x, g01.y, g23.x, g23.y);
-                *(bf16x4*)(a.g + rows[g] * HID + n) = gp;
                 put4<T>(GB, 16 * g + t, n, gp);
+                if (i & 1) {    // two adjacent tiles: one 16-byte store per lane (common.h)
+                    const size_t off = rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1);
+                    store_bf16_tile_pair(a.h + off, hprev[g], hp, gq);
+                    store_bf16_tile_pair(a.g + off, gprev[g], gp, gq);
+                } else {
+                    hprev[g] = hp; gprev[g] = gp;
+                }
             }
         }
     };
@@ -466,6 +474,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
         zero(acc);
         w2s.template run<G, T>(acc, GB, t, gq);
         TULIP_STAMP(14);
+        bf16x4 ob[2][G];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c0 = 32 * wid + 16 * i + 4 * gq;
@@ -473,8 +482,12 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             for (int g = 0; g < G; ++g) {
                 const f32x4 o = x1v[i][g] + s1v * (acc[i][g] + b2v[i]);
                 *(float4*)(a.xout + rows[g] * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
-                if (a.out_bf16) *(bf16x4*)(a.out_bf16 + rows[g] * C + c0) = pack4(o[0], o[1], o[2], o[3]);
+                ob[i][g] = pack4(o[0], o[1], o[2], o[3]);
             }
+        }
+        if (a.out_bf16) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) store_bf16_tile_pair(a.out_bf16 + rows[g] * C + 32 * wid, ob[0][g], ob[1][g], gq);
         }
     }
     TULIP_STAMP(15);
@@ -643,6 +656,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 #pragma unroll
     for (int i = 0; i < 2; ++i) w1s.wt[i] = wtile_ptr(a.w1t, 2 * wid + i, HID, lane);
     auto dh_out = [&](const f32x4 (&acc)[4][G], const bf16x4 (&hv)[4][G], int ch) {
+        bf16x4 dprev[G];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
@@ -651,8 +665,9 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[i][g][0]), bf2f((bf16_t)hv[i][g][1])});
                 const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[i][g][2]), bf2f((bf16_t)hv[i][g][3])});
                 const bf16x4 dp = pack4(acc[i][g][0] * d01.x, acc[i][g][1] * d01.y, acc[i][g][2] * d23.x, acc[i][g][3] * d23.y);
-                *(bf16x4*)(a.dh + rows[g] * HID + n) = dp;
                 put4<T>(DH, 16 * g + t, n, dp);
+                if (i & 1) store_bf16_tile_pair(a.dh + rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1), dprev[g], dp, gq);
+                else dprev[g] = dp;
             }
         }
     };
@@ -708,17 +723,19 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         __syncthreads();
         ln_bwd_part2<C, G, T, NWV>(dx1, xh, rs, STAT, t);
         // d(x1) = dy + norm2'(d(xn2))  (residual, tulip.py:351); its bf16 copy * s_attn feeds proj' and proj's wgrad
+        bf16x4 pka[2][G];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c0 = 32 * wid + 16 * i + 4 * gq;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 dx1[i][g] = dx1[i][g] + dyv[i][g];
-                const bf16x4 pk = pack4(dx1[i][g][0] * s0, dx1[i][g][1] * s0, dx1[i][g][2] * s0, dx1[i][g][3] * s0);
-                *(bf16x4*)(a.dyb_a + rows[g] * C + c0) = pk;
-                put4<T>(DY, 16 * g + t, c0, pk);
+                pka[i][g] = pack4(dx1[i][g][0] * s0, dx1[i][g][1] * s0, dx1[i][g][2] * s0, dx1[i][g][3] * s0);
+                put4<T>(DY, 16 * g + t, c0, pka[i][g]);
             }
         }
+#pragma unroll
+        for (int g = 0; g < G; ++g) store_bf16_tile_pair(a.dyb_a + rows[g] * C + 32 * wid, pka[0][g], pka[1][g], gq);
     }
     __syncthreads();
 
@@ -805,6 +822,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             const bf16x4 dsq_b = pack4(dsq[0], dsq[1], dsq[2], dsq[3]);
             const bf16x4 dsk_b = pack4(dsk[0], dsk[1], dsk[2], dsk[3]);
             const bf16x4 pk_b = pack4(pk[0], pk[1], pk[2], pk[3]);
+            bf16x4 oprev[3];
 #pragma unroll
             for (int dc = 0; dc < 2; ++dc) {
                 const bf16x4 kt = trr(ldsK + troff + dc * 32);     // K[4gq+e][16dc+t]
@@ -819,8 +837,9 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 #pragma unroll
                 for (int sec = 0; sec < 3; ++sec) {
                     const int n = sec * C + 32 * wid + 16 * dc + 4 * gq;
-                    *(bf16x4*)(a.dqkv + rows[g] * (3 * C) + n) = o[sec];
                     put4<T>(DQ, 16 * g + t, n, o[sec]);
+                    if (dc) store_bf16_tile_pair(a.dqkv + rows[g] * (3 * C) + sec * C + 32 * wid, oprev[sec], o[sec], gq);
+                    else oprev[sec] = o[sec];
                 }
             }
         }
@@ -847,6 +866,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         __syncthreads();
         ln_bwd_part2<C, G, T, NWV>(acc, xh, rs, STAT, t);
         const float cs = a.dx_scale ? a.dx_scale[tm.b] : 1.0f;
+        bf16x4 oc[2][G];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c0 = 32 * wid + 16 * i + 4 * gq;
@@ -854,8 +874,12 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             for (int g = 0; g < G; ++g) {
                 const f32x4 o = dx1[i][g] + acc[i][g];
                 *(float4*)(a.dx + rows[g] * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
-                if (a.dx_bf16) *(bf16x4*)(a.dx_bf16 + rows[g] * C + c0) = pack4(o[0] * cs, o[1] * cs, o[2] * cs, o[3] * cs);
+                oc[i][g] = pack4(o[0] * cs, o[1] * cs, o[2] * cs, o[3] * cs);
             }
+        }
+        if (a.dx_bf16) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) store_bf16_tile_pair(a.dx_bf16 + rows[g] * C + 32 * wid, oc[0][g], oc[1][g], gq);
         }
     }
 }
