@@ -397,6 +397,11 @@ int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hip
 int tulip_swinw_block_fwd_profiled(const tulip_swin96_desc* d, int C, void* out_bf16, uint64_t* stamps,
                                    hipStream_t stream);
 int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W);
+/* Launches of at most 256 workgroups (the whole grid resident at once) start by spreading the block's weights over the
+ * L2 of each XCD (every wave touches a few KiB nobody else touches): in a training step the weights are cold, and the
+ * per-wave streams would otherwise run at miss latency (tools/cold_probe.py).  on = 0 switches that off (measurement
+ * only; results are identical either way).  Process-wide, not re-entrant against concurrent launches. */
+int tulip_swinw_set_warm(int on);
 int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream);
 int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream);
 

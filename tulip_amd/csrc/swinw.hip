@@ -124,6 +124,45 @@ __device__ __forceinline__ const bf16_t* wtile_ptr(const bf16_t* w, int nt, int 
     return w + ((size_t)nt * (K >> 5)) * 512 + lane * 8;
 }
 
+// Cold caches.  In the training step a block's weights were last read a whole step ago (AdamW streams 0.8 GB through the
+// Infinity Cache in between), and every workgroup of an XCD walks the SAME 24 C^2 bytes in the same order with 6-12 KiB in
+// flight per wave: the stream then runs at (bytes in flight) / (miss latency) -- measured (tools/cold_probe.py) 73 us
+// for the C = 384 forward against 48 us with the weights in L2.  So when the whole grid is resident at once (<= 256
+// workgroups), the workgroups of an XCD (blockIdx % 8) first split the block's weights between them: every wave
+// touches a few KiB chunks nobody else touches, in order of use, and drops the data; the chunks land in the XCD's L2
+// within a few miss latencies and the streams behind them hit.
+typedef uint32_t u32x4_w __attribute__((ext_vector_type(4)));
+template <int ON>
+struct WeightWarm {
+    u32x4_w sink;
+    int nslots, slot, ws, loff;
+    // The loads are inline asm into ONE register quad (the data is dropped; returns are in order, so the quad may be
+    // rewritten in flight) that stays live until retire() has waited for them; the compiler's own vmcnt waits in between
+    // do not count them and so wait for them too (in-order retirement): one exposed miss latency at the head of the kernel.
+    __device__ __forceinline__ void init(int wid, int lane) {
+        if constexpr (ON) {
+            nslots = gridDim.x >> 3; slot = blockIdx.x >> 3; ws = __builtin_amdgcn_readfirstlane(wid); loff = lane * 16;
+            sink = (u32x4_w){0u, 0u, 0u, 0u};
+        }
+    }
+    // one fragment-major matrix of KIB KiB; sized for >= 192 waves per XCD (batch 8), fewer waves leave a tail cold
+    template <int NWV, int KIB>
+    __device__ __forceinline__ void touch(const bf16_t* w) {
+        if constexpr (ON) {
+#pragma unroll
+            for (int r = 0; r < (KIB + 191) / 192; ++r) {   // chunk and address are wave-uniform: scalar arithmetic
+                int c = (r * nslots + slot) * NWV + ws;
+                c = c < KIB ? c : KIB - 1;
+                const bf16_t* p = w + (size_t)c * 512;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink) : "v"(loff), "s"(p));
+            }
+        }
+    }
+    __device__ __forceinline__ void retire() {
+        if constexpr (ON) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));
+    }
+};
+
 struct SwinWArgs {
     const float* xin; float* x1; float* xout;
     bf16_t *xn1, *qkv, *o, *xn2, *h, *g;
@@ -138,6 +177,8 @@ struct SwinWArgs {
     float eps, scale;
 };
 #define TULIP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+int swinw_warm = 1;      // tulip_swinw_set_warm: the L2 warm-up of the single-wave launches (measurement switch)
 
 template <int C, int G>
 struct Geo {
@@ -185,7 +226,7 @@ __device__ __forceinline__ TokMap make_map(int B, int H, int W, int sh, int sw) 
     return m;
 }
 
-template <int C, int G>
+template <int C, int G, int WARM>
 __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWArgs a) {
     using Z = Geo<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
@@ -207,6 +248,12 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
     for (int i = 0; i < 6; ++i) wq.wt[i] = wtile_ptr(a.wqkv, (i >> 1) * (C / 16) + 2 * wid + (i & 1), C, lane);
     wq.start();
+    WeightWarm<WARM> warm;                          // the block's weights into this XCD's L2, in order of use
+    warm.init(wid, lane);
+    warm.template touch<NWV, 6 * C * C / 1024>(a.wqkv);
+    warm.template touch<NWV, 2 * C * C / 1024>(a.wproj);
+    warm.template touch<NWV, 8 * C * C / 1024>(a.w1);
+    warm.template touch<NWV, 8 * C * C / 1024>(a.w2);
     // ---- norm1 (tulip.py:340): 16 lanes per token, 4 tokens per wave pass; every pass's loads are issued first
     {
         constexpr int NP = (T + NWV * 4 - 1) / (NWV * 4);
@@ -264,6 +311,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
         for (int i = 0; i < 6; ++i) bq[i] = ld4(a.bqkv + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
     }
+    warm.retire();
     TULIP_STAMP(1);
     __syncthreads();
     TULIP_STAMP(2);
@@ -496,7 +544,11 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 template <int C, int G>
 int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
-    hipLaunchKernelGGL((swinw_fwd_kernel<C, G>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
+    // one wave of workgroups (all resident at once): they warm their XCD's L2 with the block's weights first (WeightWarm)
+    if (blocks <= 256 && blocks >= 8 && !a.prof && swinw_warm)
+        hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 1>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
+    else
+        hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 0>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }
@@ -590,7 +642,7 @@ __device__ __forceinline__ void ln_bwd_part2(f32x4 (&d)[2][G], const f32x4 (&xh)
     }
 }
 
-template <int C, int G>
+template <int C, int G, int WARM>
 __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinWBwdArgs a) {
     using Z = GeoB<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
@@ -609,6 +661,12 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 #pragma unroll
     for (int i = 0; i < 4; ++i) w2a.wt[i] = wtile_ptr(a.w2t, 8 * wid + i, C, lane);
     w2a.start();
+    WeightWarm<WARM> warm;                          // the four transposed weights into this XCD's L2, in order of use
+    warm.init(wid, lane);
+    warm.template touch<NWV, 8 * C * C / 1024>(a.w2t);
+    warm.template touch<NWV, 8 * C * C / 1024>(a.w1t);
+    warm.template touch<NWV, 2 * C * C / 1024>(a.wprojt);
+    warm.template touch<NWV, 6 * C * C / 1024>(a.wqkvt);
     // ---- bf16(dy * s_mlp): operand of fc2's weight gradient and of the first data-gradient GEMM
     {
         constexpr int NP = (T + NWV * 4 - 1) / (NWV * 4);
@@ -646,6 +704,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         bias_q[r] = a.bias_table[a.rel_index[t * 16 + gq * 4 + r] * NH + wid];
         bias_k[r] = a.bias_table[a.rel_index[(gq * 4 + r) * 16 + t] * NH + wid];
     }
+    warm.retire();
     __syncthreads();
 
     // ---- fc2' and GELU' (tulip.py:196-198 backwards): d(h) for this wave's 128 hidden channels = (dy . W2)[hid] * gelu'(h)
@@ -887,7 +946,10 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 template <int C, int G>
 int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
-    hipLaunchKernelGGL((swinw_bwd_kernel<C, G>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
+    if (blocks <= 256 && blocks >= 8 && swinw_warm)
+        hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 1>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
+    else
+        hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 0>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }
@@ -951,6 +1013,8 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const TrList L) {
 }
 
 }  // namespace
+
+extern "C" int tulip_swinw_set_warm(int on) { swinw_warm = on ? 1 : 0; return TULIP_OK; }
 
 extern "C" int tulip_swinw_supported(int C, int H, int W) {
     return (C == 192 || C == 384) && H > 0 && !(H & 1) && W > 0 && !(W & 15);

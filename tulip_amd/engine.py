@@ -303,6 +303,7 @@ class TulipEngine:
         self.model = model
         self.device = None
         ops.wgrad_set_mode(int(os.environ.get("TULIP_WGRAD_TILES", "1")))
+        ops.swinw_set_warm(os.environ.get("TULIP_SWINW_WARM", "1") != "0")      # A/B switch (tools/cold_probe.py)
         self.params: Optional[FlatParams] = None
         self.plans: Dict[int, Plan] = {}
         m = model

@@ -325,6 +325,11 @@ def swinw_block_fwd(C, out_bf16=None, stamps=None, **kw):
     check(_lib.load().tulip_swinw_block_fwd(ctypes.byref(d), C, _p(out_bf16), _stream()), "tulip_swinw_block_fwd")
 
 
+def swinw_set_warm(on) -> None:
+    """tulip_swinw_set_warm: the L2 warm-up at the head of the single-wave fused-block launches (measurement switch)."""
+    check(_lib.load().tulip_swinw_set_warm(int(bool(on))), "tulip_swinw_set_warm")
+
+
 def swinw_bwd_partial_rows(C, B, H, W) -> int:
     return _lib.load().tulip_swinw_bwd_partial_rows(C, B, H, W)
 
