@@ -15,6 +15,7 @@ python tools/pmc_summary.py $(find $O/cal_f -name "*counter_collection.csv" | he
 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-secondary > $O/kt.log 2>&1
 python tools/kstats.py $(find $O/kt -name "*.db" | head -1) 26 > $O/kernel_stats.txt
 python tools/timeline.py $(find $O/kt -name "*.db" | head -1) > $O/timeline_summary.txt
+python tools/timeline.py $(find $O/kt -name "*.db" | head -1) full > $O/timeline_full.txt
 python tools/instep_summary.py $(find $O/kt -name "*.db" | head -1) $O/instep_durations.json > /dev/null
 cp $O/instep_durations.json profiles/instep_durations.json
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
@@ -25,5 +26,6 @@ python tools/exp_chain.py > $O/exp_chain.txt 2>/dev/null
 python tools/wgrad_phases.py > $O/wgrad_phases.txt 2>/dev/null
 python tools/bench_wgrad.py > $O/wgrad_isolated.txt 2>/dev/null
 python tools/chain_gemms.py > $O/chain_gemms.txt 2>/dev/null
+python tools/cold_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/cold_probe.txt
 rm -rf $O/kt $O/kt64 $O/pmc_f $O/pmc_w $O/cal_f $O/cal_w
 ls -la $O
