@@ -406,6 +406,9 @@ int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t str
 int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream);
 
 /* library self-description */
+/* diagnostics: *dst = the 100 MHz constant device clock (s_memrealtime) when the stream reaches this point; capturable
+ * (tools/step_stamps.py time-lines a captured training step with it, no tracer attached) */
+int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream);
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);
 

@@ -39,11 +39,22 @@ def no_side(eng):
     eng._fold_bias_table = lambda *a, **k: None
 
 
+def no_folds(eng):
+    from tulip_amd import ops
+    real = ops.wgrad_group
+    ops.wgrad_group = lambda items, extra, ws, ws_bytes, fold=True: real(items, [], ws, ws_bytes, fold=False)
+    ops.reduce_rows_multi = lambda *a, **k: None
+
+
 def no_adamw(eng):
     Trainer._adamw = lambda self: None
 
 
 run("full step", lambda e: None)
 run("no weight-gradient GEMMs (folds stay)", no_wgrad)
+from tulip_amd import ops as _ops
+_rg, _rr = _ops.wgrad_group, _ops.reduce_rows_multi
+run("weight-gradient GEMMs, nothing folded", no_folds)
+_ops.wgrad_group, _ops.reduce_rows_multi = _rg, _rr
 run("no side work at all (chain only)", no_side)
 run("chain only, no AdamW / weight packing either", lambda e: (no_side(e), no_adamw(e)))

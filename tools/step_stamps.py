@@ -1,0 +1,52 @@
+"""dev tool: time-line of the CAPTURED training step with no tracer attached.  Stamp kernels (tulip_stamp_realtime: the
+100 MHz device clock, one base for all XCDs) are captured into the step's graph at the block boundaries of the backward
+chain and around every side-queue launch group; prints when each point was reached in the last replay.
+usage: python tools/step_stamps.py [batch=8]"""
+import os, sys, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from tulip_amd import ops
+from tulip_amd.trainer import Trainer
+from tulip_amd.engine import TulipEngine as E
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+a = argparse.Namespace(model="tulip_base", img=[16, 1024], target=[64, 1024], batch=B)
+dev = torch.device("cuda", 0)
+buf = torch.zeros(1024, dtype=torch.int64, device=dev)
+slots, seen = {}, {}
+
+def stamp(tag):
+    k = seen.get(tag, 0); seen[tag] = k + 1
+    i = slots.setdefault((tag, k), len(slots))
+    ops.stamp_realtime(buf[i:])
+
+def wrap(cls, name, before=None, after=None):
+    real = getattr(cls, name)
+    def f(self, *a, **kw):
+        if before: stamp(before(self, a, kw) if callable(before) else before)
+        r = real(self, *a, **kw)
+        if after: stamp(after(self, a, kw) if callable(after) else after)
+        return r
+    setattr(cls, name, f)
+
+real_fwd = E.run_forward
+def run_forward(self, *a, **kw):
+    seen.clear(); stamp("chain forward begins")
+    return real_fwd(self, *a, **kw)
+E.run_forward = run_forward
+wrap(E, "run_backward", before="chain backward begins", after="chain backward issued (side joined)")
+wrap(E, "_block_bwd", after=lambda s, a, kw: f"chain end of block bwd {a[1].prefix}")
+wrap(E, "_issue_pending", before="side  group begins", after="side  group ends")
+wrap(Trainer, "_adamw", before="chain adamw begins", after="chain adamw ends")
+
+m = bench.make_model(a).to(dev).train()
+tr = Trainer(m, B, device=dev)
+lo, hi = bench.synthetic(a, 0, dev); tr.load_batch(lo, hi)
+for _ in range(20): tr.step()
+torch.cuda.synchronize()
+v = buf.cpu().tolist()
+ev = sorted(((v[i], tag, k) for (tag, k), i in slots.items() if v[i]), key=lambda e: e[0])
+t0 = ev[0][0]
+print(f"{len(ev)} stamps; 10-ns ticks since the first one; every stamp is a 1-thread launch of its own (~3-5 us each)")
+for t, tag, k in ev:
+    print(f"  +{(t - t0) / 100.0:9.1f} us  {tag}" + (f" #{k}" if tag.startswith("side") else ""))

@@ -106,6 +106,7 @@ SIGNATURES = {
     "tulip_range_to_xyz_durlar": [P, P, P, P, F, F, D, I, I, P, P],
     "tulip_voxel_metrics": [P, L, P, L, I, D, P, P, L, P, P, P],
     "tulip_chamfer_sq": [P, L, P, L, I, P, P, P, P, P],
+    "tulip_stamp_realtime": [P, P],
     "tulip_abi_version": [],
     "tulip_build_arch": [],
 }

@@ -446,5 +446,15 @@ extern "C" int tulip_grad_norm(const float* g, int64_t n, double* partials, cons
     return TULIP_OK;
 }
 
+// diagnostics: the constant-rate 100 MHz device clock (one base for every XCD, unlike s_memtime) at this point of the
+// stream -- a graph node like any other, so tools/step_stamps.py can time-line a captured step without a tracer
+__global__ void stamp_kernel(unsigned long long* dst) { *dst = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream) {
+    if (!dst) return TULIP_ERR_ARG;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long*)dst);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
 extern "C" int tulip_abi_version(void) { return 1; }
 extern "C" const char* tulip_build_arch(void) { return "gfx950"; }

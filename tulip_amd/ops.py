@@ -325,6 +325,11 @@ def swinw_block_fwd(C, out_bf16=None, stamps=None, **kw):
     check(_lib.load().tulip_swinw_block_fwd(ctypes.byref(d), C, _p(out_bf16), _stream()), "tulip_swinw_block_fwd")
 
 
+def stamp_realtime(dst) -> None:
+    """tulip_stamp_realtime: dst (int64 device tensor element) = the 100 MHz device clock at this point of the stream."""
+    check(_lib.load().tulip_stamp_realtime(_p(dst), _stream()), "tulip_stamp_realtime")
+
+
 def swinw_set_warm(on) -> None:
     """tulip_swinw_set_warm: the L2 warm-up at the head of the single-wave fused-block launches (measurement switch)."""
     check(_lib.load().tulip_swinw_set_warm(int(bool(on))), "tulip_swinw_set_warm")
