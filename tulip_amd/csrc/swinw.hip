@@ -132,16 +132,21 @@ __device__ __forceinline__ const bf16_t* wtile_ptr(const bf16_t* w, int nt, int 
 // touches a few KiB chunks nobody else touches, in order of use, and drops the data; the chunks land in the XCD's L2
 // within a few miss latencies and the streams behind them hit.
 typedef uint32_t u32x4_w __attribute__((ext_vector_type(4)));
+// ON = 1: every workgroup takes part (grids of at most 256 workgroups); ON = 2: larger grids -- the first 256 workgroups
+// (the ones that find the caches cold) do it for the ones behind them.
 template <int ON>
 struct WeightWarm {
     u32x4_w sink;
     int nslots, slot, ws, loff;
+    bool on;
     // The loads are inline asm into ONE register quad (the data is dropped; returns are in order, so the quad may be
     // rewritten in flight) that stays live until retire() has waited for them; the compiler's own vmcnt waits in between
     // do not count them and so wait for them too (in-order retirement): one exposed miss latency at the head of the kernel.
     __device__ __forceinline__ void init(int wid, int lane) {
         if constexpr (ON) {
-            nslots = gridDim.x >> 3; slot = blockIdx.x >> 3; ws = __builtin_amdgcn_readfirstlane(wid); loff = lane * 16;
+            nslots = (ON == 2 ? 256 : (int)gridDim.x) >> 3; slot = blockIdx.x >> 3;
+            on = ON == 1 || blockIdx.x < 256;
+            ws = __builtin_amdgcn_readfirstlane(wid); loff = lane * 16;
             sink = (u32x4_w){0u, 0u, 0u, 0u};
         }
     }
@@ -149,12 +154,14 @@ struct WeightWarm {
     template <int NWV, int KIB>
     __device__ __forceinline__ void touch(const bf16_t* w) {
         if constexpr (ON) {
+            if (on) {                                       // workgroup-uniform
 #pragma unroll
-            for (int r = 0; r < (KIB + 191) / 192; ++r) {   // chunk and address are wave-uniform: scalar arithmetic
-                int c = (r * nslots + slot) * NWV + ws;
-                c = c < KIB ? c : KIB - 1;
-                const bf16_t* p = w + (size_t)c * 512;
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink) : "v"(loff), "s"(p));
+                for (int r = 0; r < (KIB + 191) / 192; ++r) {   // chunk and address are wave-uniform: scalar arithmetic
+                    int c = (r * nslots + slot) * NWV + ws;
+                    c = c < KIB ? c : KIB - 1;
+                    const bf16_t* p = w + (size_t)c * 512;
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink) : "v"(loff), "s"(p));
+                }
             }
         }
     }
@@ -178,7 +185,7 @@ struct SwinWArgs {
 };
 #define TULIP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-int swinw_warm = 1;      // tulip_swinw_set_warm: the L2 warm-up of the single-wave launches (measurement switch)
+int swinw_warm = 1;      // tulip_swinw_set_warm: the L2 warm-up at the head of the launches (measurement switch)
 
 template <int C, int G>
 struct Geo {
@@ -544,9 +551,11 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 template <int C, int G>
 int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
-    // one wave of workgroups (all resident at once): they warm their XCD's L2 with the block's weights first (WeightWarm)
+    // the workgroups that are resident first warm their XCD's L2 with the block's weights (WeightWarm)
     if (blocks <= 256 && blocks >= 8 && !a.prof && swinw_warm)
         hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 1>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
+    else if (blocks > 256 && !a.prof && swinw_warm)
+        hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 2>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
     else
         hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 0>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
@@ -948,6 +957,8 @@ int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
     if (blocks <= 256 && blocks >= 8 && swinw_warm)
         hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 1>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
+    else if (blocks > 256 && swinw_warm)
+        hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 2>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
     else
         hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 0>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
