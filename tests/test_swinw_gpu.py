@@ -177,6 +177,33 @@ def _backward(stage, shifted, B, fp8):
         assert rel <= (1e-1 if "bias_table" in n else 1.5e-2), (n, rel)
 
 
+@pytest.mark.parametrize("stage,B", [(1, 2), (2, 2), (1, 64), (2, 64)])
+def test_l2_warm_up_changes_no_bit(stage, B):
+    """The L2 warm-up at the head of the fused kernels (WeightWarm in csrc/swinw.hip: every workgroup of a one-wave grid,
+    the first 256 workgroups of a larger one, batch 64 here) only touches weights: the forward's outputs and saved
+    activations and the backward's data gradient and weight-gradient operands are bit-identical with it switched off."""
+    from tulip_amd import ops
+    m, eng, P, sp, M, x, xin = _setup(stage, True, B, seed=21)
+    p = sp.prefix
+    res = {}
+    for warm in (0, 1):
+        ops.swinw_set_warm(warm)
+        out = torch.empty(M, sp.C, device=DEV)
+        eng._block_fwd(P, sp, xin, out)
+        dx = torch.randn(M, sp.C, device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+        saved, eng.overlap_wgrad = eng.overlap_wgrad, False
+        gflat = torch.zeros(eng.params.total, device=DEV)
+        eng._pending, eng._lagged_hook = [], None
+        eng._block_bwd(P, sp, xin, dx, lambda name: gflat.data_ptr() + 4 * eng.params.offset[name], have_dyb=False)
+        eng.overlap_wgrad = saved
+        torch.cuda.synchronize()
+        res[warm] = [out.clone(), dx.clone(), gflat.clone()] + [P[p + s].clone() for s in
+                                                               (".xn1", ".qkv", ".o", ".xn2", ".h", ".g", ".dh", ".dqkv")]
+    ops.swinw_set_warm(1)
+    for a, b in zip(res[0], res[1]):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 def test_pack_multi():
     """tulip_pack_bf16_multi: fragment-major copies of weights and of their transposes (include/tulip_hip.h)."""
     from tulip_amd import ops
