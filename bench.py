@@ -429,7 +429,10 @@ def main():
     imgs = args.batch * world * args.steps
     value = imgs / dt
 
-    out = {"metric": "range-images/sec training (KITTI 16->64x1024, bs=8/GPU)", "value": round(value, 2),
+    headline = args.model == "tulip_base" and tuple(args.img) == (16, 1024) and tuple(args.target) == (64, 1024) and args.batch == 8
+    out = {"metric": "range-images/sec training (KITTI 16->64x1024, bs=8/GPU)" if headline else
+           f"range-images/sec training ({args.model} {args.img[0]}x{args.img[1]}->{args.target[0]}x{args.target[1]}, bs={args.batch}/GPU)",
+           "value": round(value, 2),
            "unit": "range-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "step_ms_median": round(per_step[len(per_step) // 2], 4),
            "step_ms_min": round(per_step[0], 4), "higher_is_better": True, "scaling": "weak",

@@ -26,6 +26,9 @@ python tools/exp_chain.py > $O/exp_chain.txt 2>/dev/null
 python tools/wgrad_phases.py > $O/wgrad_phases.txt 2>/dev/null
 python tools/bench_wgrad.py > $O/wgrad_isolated.txt 2>/dev/null
 python tools/chain_gemms.py > $O/chain_gemms.txt 2>/dev/null
+bash tools/other_configs.sh > $O/other_configs.txt 2>/dev/null
+python tools/step_stamps.py 2>/dev/null | grep -v amdgpu.ids > $O/step_stamps.txt
+python tools/exp_wgrad_contig.py 2>/dev/null | grep -v amdgpu.ids > $O/exp_wgrad_contig.txt
 python tools/cold_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/cold_probe.txt
 rm -rf $O/kt $O/kt64 $O/pmc_f $O/pmc_w $O/cal_f $O/cal_w
 ls -la $O
