@@ -204,6 +204,65 @@ def test_l2_warm_up_changes_no_bit(stage, B):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)
 
 
+def _setup96(shifted, B, seed, fp8=False):
+    m, eng = _model(seed)
+    eng.attn_fp8 = fp8
+    P = eng.plan(B)
+    sp = eng.enc_blocks[0][1 if shifted else 0]
+    assert sp.shift == shifted and sp.C == 96 and eng._fusable96(sp) and eng.fuse_block96 and eng.fuse_block96_bwd
+    M = B * sp.H * sp.W
+    x = torch.randn(M, sp.C, device=DEV) * 1.5 + 0.2
+    xin = P["enc0.in"]
+    xin.copy_(x.view_as(xin))
+    du = 0.5 + 0.5 * torch.rand(eng.n_drop_slots, B, device=DEV)
+    du[:, 0] = 0.01                                           # sample 0: both branches of every block dropped
+    eng.draw_drop_scales(P, True, du)
+    return m, eng, P, sp, M, x, xin
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_c96_fused_block_directly_against_the_oracle(shifted, fp8):
+    """swin96_fwd_kernel / swin96_bwd_kernel (csrc/swin96.hip, one launch each way for a stage-0 block) against the oracle's
+    SwinTransformerBlock.forward (tulip.py:338-352) and its autograd under the same rounding model -- no unfused kernel in
+    the loop (tests/test_ops_gpu.py compares the fused kernels with the launch sequences they replace)."""
+    B = 2
+    m, eng, P, sp, M, x, xin = _setup96(shifted, B, seed=31, fp8=fp8)
+    C, p = sp.C, sp.prefix
+    out = torch.full((M, C), float("nan"), device=DEV)
+    eng._block_fwd(P, sp, xin, out)
+    torch.cuda.synchronize()
+    oo, xc, sd = _oracle_block(m, eng, P, sp, x, B, need_grad=True)
+    a, b = out.cpu().reshape(-1), oo.detach().reshape(-1)
+    d = (a - b).abs()
+    rel = (d.norm() / b.norm()).item()
+    print(f"fused C=96 block vs oracle: rel L2 {rel:.3e} max {d.max().item():.3e}")
+    assert torch.isfinite(a).all() and rel <= 2e-3 and d.max().item() <= 3e-2, (rel, d.max().item())
+    if sp.slot >= 0:
+        assert torch.equal(out[: M // B], x[: M // B])
+    # backward
+    dy = torch.randn(M, C, device=DEV)
+    saved, eng.overlap_wgrad = eng.overlap_wgrad, False       # weight gradients and folds inline, on this stream
+    gflat = torch.zeros(eng.params.total, device=DEV)
+    dx = dy.clone()
+    eng._pending, eng._lagged_hook = [], None
+    eng._block_bwd(P, sp, xin, dx, lambda name: gflat.data_ptr() + 4 * eng.params.offset[name], have_dyb=False)
+    eng.overlap_wgrad = saved
+    torch.cuda.synchronize()
+    (oo.reshape(M, C) * dy.cpu()).sum().backward()
+    ra = ((dx.cpu() - xc.grad.reshape(M, C)).norm() / xc.grad.norm()).item()
+    print(f"fused C=96 backward vs oracle autograd: dx rel L2 {ra:.3e}")
+    assert ra <= 1e-2, ra
+    for n, v in sd.items():
+        if not v.is_floating_point():
+            continue
+        o = eng.params.offset[n]
+        g = gflat[o:o + v.numel()].cpu().reshape(v.shape)
+        rel = ((g - v.grad).norm() / (v.grad.norm() + 1e-30)).item()
+        print(f"  {n[len(p) + 1:]:40s} vs oracle rel {rel:.3e}")
+        assert rel <= (1e-1 if "bias_table" in n else 1.5e-2), (n, rel)
+
+
 def test_pack_multi():
     """tulip_pack_bf16_multi: fragment-major copies of weights and of their transposes (include/tulip_hip.h)."""
     from tulip_amd import ops
