@@ -63,7 +63,7 @@ int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb,
  * i < n (n, stride multiples of 4).  With scatter_index != NULL the region is the dense [scatter_nh][scatter_len]
  * relative-position-bias gradient and its sums are added to out[scatter_index[ij]*scatter_nh + h] instead
  * (tulip.py:304-308 backwards; one launch, deterministic: no atomics). */
-#define TULIP_REDUCE_REGIONS_MAX 16
+#define TULIP_REDUCE_REGIONS_MAX 48
 typedef struct tulip_reduce_region {
     const float* partials; float* out;
     int64_t stride; int64_t n;
@@ -77,8 +77,10 @@ int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream
  * One grouped GEMM launch covers all items (token dimension cut `splits` ways into fp32 slabs in `workspace`, or
  * accumulated in place when splits == 1), one tulip_reduce_rows_multi launch folds the slabs -- and the `extra`
  * regions (LayerNorm / bias-table partial rows of the same block) ride along in that launch.  fold = 0 skips the
- * second launch and leaves the slabs in the workspace (profiling the GEMM alone). */
-#define TULIP_WGRAD_GROUP_MAX 4
+ * second launch and leaves the slabs in the workspace (profiling the GEMM alone).  A launch is sized by its caller to
+ * about one workgroup per CU in total (`splits`), so the slab traffic is per LAUNCH, not per linear: the engine puts a
+ * whole stage (two Swin blocks + boundary linears, up to 12 items) into one. */
+#define TULIP_WGRAD_GROUP_MAX 16
 typedef struct tulip_wgrad_item {
     const void* dY; const void* X; float* dW; float* db;
     int ldy; int ldx; int Nw; int Kw; int Mtok; int splits;

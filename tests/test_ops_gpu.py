@@ -690,10 +690,12 @@ def test_wgrad_group_and_multi_region_fold(ops):
                   accumulate=True)
     assert torch.allclose(tab, rt, atol=2e-3)
     # the fold alone, more regions than one weight-gradient group carries
-    outs = [torch.zeros(C, device=DEV) for _ in range(16)]
-    ops.reduce_rows_multi([ops.reduce_region(part.data_ptr() + 4 * (k % 2) * C, 2 * C, outs[k], C, R) for k in range(16)])
+    from tulip_amd import _lib
+    NR = _lib.REDUCE_REGIONS_MAX
+    outs = [torch.zeros(C, device=DEV) for _ in range(NR)]
+    ops.reduce_rows_multi([ops.reduce_region(part.data_ptr() + 4 * (k % 2) * C, 2 * C, outs[k], C, R) for k in range(NR)])
     torch.cuda.synchronize()
-    for k in range(16):
+    for k in range(NR):
         assert torch.allclose(outs[k], part[:, (k % 2) * C:(k % 2 + 1) * C].sum(0), atol=1e-4)
 
 
@@ -758,7 +760,13 @@ def test_patch_embed_bf16_copy(ops):
     [(2048, 1152, 384, 2), (2048, 384, 384, 2), (2048, 1536, 384, 2), (2048, 384, 1536, 2)],      # a C = 384 block
     [(1000, 256, 384, 3), (520, 136, 200, 2)],                                                    # ragged sizes
     [(1000, 192, 384, 3), (520, 576, 192, 2), (72, 384, 96, 1), (4104, 96, 288, 5)],              # ragged token counts, large tiles
-    [(512, 2304, 768, 1), (512, 768, 3072, 1)]])                                                  # C = 768, no split
+    [(512, 2304, 768, 1), (512, 768, 3072, 1)],                                                   # C = 768, no split
+    # a whole stage in one launch (the engine's default grouping): two C = 192 blocks + the stage's boundary linears
+    [(8192, 576, 192, 2), (8192, 192, 192, 2), (8192, 768, 192, 2), (8192, 192, 768, 2), (8192, 576, 192, 2), (8192, 192, 192, 2),
+     (8192, 768, 192, 2), (8192, 192, 768, 2), (8192, 192, 384, 2), (2048, 384, 768, 1)],
+    # two C = 96 blocks + boundary linears: 384 x 96 / 96 x 384 tiles beside 192 x 192 ones, 12 linears
+    [(32768, 288, 96, 16), (32768, 96, 96, 16), (32768, 384, 96, 16), (32768, 96, 384, 16), (32768, 288, 96, 16), (32768, 96, 96, 16),
+     (32768, 384, 96, 16), (32768, 96, 384, 16), (32768, 96, 192, 8), (8192, 192, 384, 4), (32768, 1536, 96, 4), (8192, 192, 192, 2)]])
 def test_wgrad_group_wide_stage_shapes(ops, shapes):
     """tulip_wgrad_group on the problem groups of the wider stages (C = 192 / 384 / 768 blocks, ragged sizes): dW += dY^T . X
     and db += column sums of dY, split-K slabs folded deterministically (bit-identical from run to run)."""
@@ -771,7 +779,7 @@ def test_wgrad_group_wide_stage_shapes(ops, shapes):
         dW, db = dW0.clone(), db0.clone()
         items.append((ops.wgrad_item(dY, Nw, X, Kw, Nw, Kw, Mtok, dW, db, sp), dY, X, dW, db))
         refs.append((dW0 + dY.float().t() @ X.float(), db0 + dY.float().sum(0)))
-    ws = torch.empty(16 << 20, device=DEV)
+    ws = torch.empty(24 << 20, device=DEV)
     ops.wgrad_group([it[0] for it in items], [], ws, ws.numel() * 4)
     torch.cuda.synchronize()
     for (it, dY, X, dW, db), (rW, rb) in zip(items, refs):
