@@ -120,38 +120,6 @@ def test_trainer_checkpoint_resume_in_the_reference_order():
     assert torch.equal(b.m, a.m) and torch.equal(b.v, a.v)
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_split_adamw_beside_the_side_queue_changes_no_bit(use_graph):
-    """Trainer on one GPU: the optimizer update of everything but the backward's last two parameter groups runs beside the
-    side queue's last weight-gradient launches, behind an event on the side stream (run_backward(head_update=...)), the
-    rest after the join.  Same parameters, moments, bf16 shadow and fragment-major weight copies as the single AdamW launch
-    behind the join, after 4 steps, captured and eager."""
-    from tests.test_model_gpu import build
-    from tulip_amd.trainer import Trainer
-    cfg = O.tulip_base_config()
-    lo, hi = O.synthetic_batch(cfg, 2, seed=9)
-    res = []
-    for split in (False, True):
-        torch.manual_seed(33)
-        t = Trainer(build(cfg, O.key_seeded_state_dict(cfg, seed=3), train=True), 2, lr=2e-3, use_graph=use_graph)
-        t.split_adamw = split
-        assert t._split_update() == split
-        t.load_batch(lo.to(DEV), hi.to(DEV))
-        losses = [t.step().clone() for _ in range(4)]
-        torch.cuda.synchronize()
-        W = t.eng.params
-        assert 0 < W.tail_start < W.total and W.tail_tag == "enc1"
-        packed = [W.packed.clone(), W.packed_t.clone()]
-        res.append((torch.stack(losses), W.flat.clone(), W.shadow.clone(), t.m.clone(), t.v.clone(), t.g.clone(), packed))
-    a, b = res
-    assert torch.isfinite(a[0]).all() and a[6][0].any() and a[6][1].any()
-    for x, y in zip(a[:6], b[:6]):
-        assert torch.equal(x, y)
-    for x, y in zip(a[6], b[6]):
-        assert torch.equal(x, y)
-    assert not b[5].any()                      # every gradient consumed and cleared
-
-
 def test_pixel_loss_is_marked_non_differentiable():
     from tests.test_model_gpu import build
     cfg = O.tiny_config()

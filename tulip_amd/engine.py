@@ -81,10 +81,6 @@ class FlatParams:
         # gradient in [previous end, end) has been launched
         self.groups: List[Tuple[str, int]] = [
             (tag, self.offset[order[cnt]] if cnt < len(order) else self.total) for tag, cnt in marks]
-        # the backward's last two groups (encoder stage 0, patch embedding) start here; tail_tag: the group in front of them
-        tags = [t for t, _ in self.groups]
-        k = tags.index("enc0") if "enc0" in tags and tags.index("enc0") > 0 else len(tags) - 1
-        self.tail_tag, self.tail_start = tags[k - 1], self.groups[k - 1][1]
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
         mask = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
@@ -858,31 +854,6 @@ class TulipEngine:
         st.wait_event(ev)
         with torch.cuda.stream(st):
             self._issue_pending(ws, pending)
-        if getattr(self, "_mark_pending", False):
-            self._mark_pending = False
-            self._record_mark()
-
-    _want_mark = False
-    _mark_pending = False
-    _mark_event = None
-
-    def _record_mark(self):
-        """An event on the side stream behind everything issued on it so far (and the scatters still carried)."""
-        self._flush_carry()
-        self._mark_event = torch.cuda.Event()
-        self._mark_event.record(self._side_streams[0])
-
-    def _issue_mark(self):
-        """Called right behind a _flush_wgrads(): the mark belongs behind THAT batch -- which, with deferred side launches,
-        reaches the side stream only when the chain's next kernel has been enqueued (_release_deferred)."""
-        if not self._want_mark:
-            return
-        self._want_mark = False
-        if self.overlap_wgrad and self.n_side == 1:
-            if self._deferred is not None:
-                self._mark_pending = True
-            else:
-                self._record_mark()
 
     def _wait_side(self):
         """The current stream waits for everything issued on the side streams so far (queued work stays queued)."""
@@ -1080,20 +1051,14 @@ class TulipEngine:
         self._release_deferred()
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
-                     join_tags=None, head_update=None):
+                     join_tags=None):
         """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
         (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
-        each parameter group has been *launched* (DDP overlap).
-        head_update (one GPU, no buckets): called once, behind the chain's last kernel and BEFORE the side queue is
-        joined, when every gradient of the flat range [0, params.tail_start) -- all groups but the backward's last two,
-        encoder stage 0 and the patch embedding -- is complete on the current stream: the caller's optimizer update of
-        that range (99 % of the parameters) then runs beside the side queue's last weight-gradient launches instead of
-        behind them."""
+        each parameter group has been *launched* (DDP overlap)."""
         m, W_ = self.model, self.params
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
-        self._want_mark = self._mark_pending = False
         gbase = gflat.data_ptr()
         G = lambda name: gbase + 4 * W_.offset[name]
         user_hook = bucket_hook or (lambda tag: None)
@@ -1102,20 +1067,13 @@ class TulipEngine:
             self._wait_side()
             user_hook(tag)
 
-        self._mark_event = None
-        pre_tail = self.params.tail_tag if head_update is not None else None
-
         def hook(tag):
             # a bucket is complete only once its side-stream weight gradients are in; without buckets the
             # side streams are joined once, at the end
             if self._lagged_hook is not None:           # two hooks without a block in between
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
-            if tag == pre_tail:
-                self._want_mark = True                  # an event behind this group's side launches (see _issue_mark)
             self._flush_wgrads()
-            if tag == pre_tail:
-                self._issue_mark()
             bucket = join_tags is not None and tag in join_tags
             if tag == "embed":
                 join_and_fire(tag)
@@ -1236,11 +1194,6 @@ class TulipEngine:
                             self.eps, partial_stride=P.embed_stride)
         gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
         self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
-        if head_update is not None and self._mark_event is not None:
-            self._flush_wgrads()
-            self._release_deferred()                    # the side queue's last launches are enqueued ...
-            torch.cuda.current_stream().wait_event(self._mark_event)
-            head_update()                               # ... and this runs beside them
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge

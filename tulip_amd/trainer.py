@@ -122,34 +122,13 @@ class Trainer:
             self._hyper_events[k] = torch.cuda.Event()
         self._hyper_events[k].record()
 
-    def _fwd_bwd(self, hook, update: bool = True, head_update=None):
+    def _fwd_bwd(self, hook, update: bool = True):
         eng, P = self.eng, self.P
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training)
         eng.run_forward(P)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
-                         join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None,
-                         head_update=head_update)
-
-    # One GPU, no gradient exchange: the optimizer update of everything but the backward's last two parameter groups
-    # (encoder stage 0 + patch embedding: 1 % of the parameters) does not wait for the side queue's last weight-gradient
-    # launches -- it runs beside them, behind the chain's last kernel (run_backward(head_update=...)); the rest follows the
-    # join.  AdamW is element-wise: same bits as one launch.  TULIP_SPLIT_ADAMW=0 switches it off.
-    split_adamw = os.environ.get("TULIP_SPLIT_ADAMW", "1") != "0"
-
-    def _split_update(self) -> bool:
-        W = self.eng.params
-        return (self.split_adamw and not self.segmented and self.gb is None and not self.track_grad_norm
-                and 0 < W.tail_start < W.total and self.eng.overlap_wgrad and self.eng.n_side == 1)
-
-    def _adamw_head(self):
-        W = self.eng.params
-        self._adamw_range(0, W.tail_start)
-        W.refresh_transposes()          # the fused blocks' weight copies: all of them are in the head range
-
-    def _adamw_tail(self):
-        W = self.eng.params
-        self._adamw_range(W.tail_start, W.total)
+                         join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None)
 
     def _adamw_range(self, lo: int, hi: int):
         W = self.eng.params
@@ -251,13 +230,12 @@ class Trainer:
                     cur = torch.cuda.CUDAGraph()
                     cur.capture_begin(capture_error_mode="thread_local")
 
-            self._split_now = update and self._split_update()
-            self._fwd_bwd(hook, update, head_update=self._adamw_head if self._split_now else None)
+            self._fwd_bwd(hook, update)
             if not update:
                 cur.capture_end()
                 segs.append((cur, None))
             elif not self.segmented:
-                self._adamw_tail() if self._split_now else self._adamw()
+                self._adamw()
                 cur.capture_end()
                 segs.append((cur, None))
             else:
@@ -307,12 +285,9 @@ class Trainer:
             self.eng.params.refresh_shadow()
         if not self.use_graph:
             if update:
-                split = self._split_update()
-                self._fwd_bwd(lambda tag: self._bucket_done(tag, cast=True), head_update=self._adamw_head if split else None)
+                self._fwd_bwd(lambda tag: self._bucket_done(tag, cast=True))
                 if self.segmented:
                     self._finish_buckets()
-                elif split:
-                    self._adamw_tail()
                 else:
                     self._adamw()
             else:
