@@ -83,6 +83,33 @@ __device__ __forceinline__ void stage_weights(const bf16_t* __restrict__ w, unsi
     }
 }
 
+// the same in two steps: the loads early (before a burst of stores -- vmcnt retires in order, a load issued behind stores
+// cannot be consumed before they are acknowledged), the LDS writes once the region is free
+template <int ROWS, int COLS>
+struct StagedWeights {
+    static constexpr int CPR = COLS / 8, N = ROWS * CPR, PER = (N + NT - 1) / NT;
+    uint4 v[PER];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ w, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + i * NT;
+            v[i] = *(const uint4*)(w + (size_t)((N % NT == 0 || c < N) ? c : N - 1) * 8);     // rows are contiguous: chunk c
+        }
+    }
+    template <int PITCH>
+    __device__ __forceinline__ void store(unsigned char* dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + i * NT;
+            if (N % NT == 0 || c < N) {
+                unsigned char* d = dst + (c / CPR) * PITCH + (c % CPR) * 16;
+                *(uint2*)d = make_uint2(v[i].x, v[i].y);
+                *(uint2*)(d + 8) = make_uint2(v[i].z, v[i].w);
+            }
+        }
+    }
+};
+
 __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
@@ -176,6 +203,11 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         if (j & 1) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
     }
 
+    // fc1.weight rows 0..287 replace qkv.weight in LDS once every wave is through the qkv GEMM: fetched now, written
+    // behind the attention core (the stall of a restage between two barriers was ~10 % of this kernel)
+    StagedWeights<288, C> w1a;
+    w1a.load(a.w1, tid);
+
     // ---- attention, one head at a time (tulip.py:300-317); scores issued as K.Q^T: lane = query t, keys 4gq + r
     bf16x8 ofrag[3];
 #pragma unroll
@@ -218,6 +250,11 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
+
+    __syncthreads();                                        // nobody reads qkv.weight any more
+    w1a.template store<PW>(smem + OFF_A, tid);
+    StagedWeights<96, C> w1b;                               // rows 288..383 go where proj.weight is: behind the proj GEMM
+    w1b.load(a.w1 + 288 * C, tid);
 
     // ---- proj Linear + DropPath + residual (tulip.py:318,344), then norm2 (:347); x1 replaces x in xv
     const float s0 = a.ds0 ? a.ds0[b] : 1.0f, s1v = a.ds1 ? a.ds1[b] : 1.0f;
@@ -263,9 +300,9 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         }
     }
 
-    // ---- fc1 weights replace qkv/proj weights in LDS
+    // ---- the rest of fc1.weight replaces proj.weight
     __syncthreads();
-    stage_weights<HID, C, PW>(a.w1, smem + OFF_A, tid);
+    w1b.template store<PW>(smem + OFF_WPROJ, tid);
     __syncthreads();
 
     // ---- fc1 -> exact-erf GELU -> fc2 (tulip.py:195-198), 32 hidden channels at a time, chained in registers

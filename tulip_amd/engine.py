@@ -727,8 +727,8 @@ class TulipEngine:
         GEMMs overlap on the chip (captured as parallel branches of the HIP graph)."""
         if not self.overlap_wgrad:
             return self._wgrad_launch(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, self._ws_ptr)
-        # queued: forks cost a few microseconds each inside a HIP graph, so a Swin block's four weight
-        # gradients share ONE fork (their inputs are per-block buffers, so deferring them is hazard-free)
+        # queued: forks cost a few microseconds each inside a HIP graph and every side launch has a fixed cost, so the
+        # weight gradients of a whole stage share ONE fork (their inputs are per-block buffers: deferring them is hazard-free)
         self._pending.append(("w", (dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias)))
 
     def _side(self, fn):
