@@ -299,12 +299,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         sa[r].load(p.A, p.lda, m0, p.M, kbeg + t * BKS, kend, tid);
         sb[r].load(p.B, p.ldb, n0, p.N, kbeg + t * BKS, kend, tid);
     };
+    // Cold weights.  In the training step a Linear's weights were last read a step ago; the k loop below has two or three
+    // stages in flight and so walks its [BN][k range] weight panel at miss latency.  The M-tile workgroups of one N panel
+    // (blockIdx.y; on one XCD, i.e. one L2, when gridDim.x % 8 == 0) first split the panel between them and touch it with
+    // loads whose data is dropped (one register quad, returns are in order; see WeightWarm in swinw.hip): everything is in
+    // flight at once and the loop's own loads hit L2.  The dropped loads are older than stage 0's, so they have retired
+    // when stage 0 is written to LDS.
+    typedef uint32_t u32x4_g __attribute__((ext_vector_type(4)));
+    u32x4_g sink = {0u, 0u, 0u, 0u};
+    if constexpr (!A_T) {
+        const int rowsN = min(BN, p.N - n0), kw = kend - kbeg;
+        // 16-byte pieces of the panel: B_T: [k][n] rows of rowsN elements; else [n][k] rows of kw elements
+        const int ppr = ((B_T ? rowsN : kw) * 2) >> 4, prow = B_T ? kw : rowsN;
+        const int npieces = ppr * prow;
+        const unsigned char* base = (const unsigned char*)(B_T ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg);
+        for (int q = (by * 4 + wid) * 64 + lane; q < npieces; q += (int)gridDim.y * 256) {
+            const int r = q / ppr, c16 = q - r * ppr;
+            const unsigned char* a16 = base + ((size_t)r * p.ldb) * 2 + c16 * 16;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(a16));
+        }
+    }
     static_for<RING - 1>([&](auto R) { if (nt > decltype(R)::value) issue(R, decltype(R)::value); });
     if (nt > 0) {
         sa[0].store(ldsA(0), tid);
         sb[0].store(ldsB(0), tid);
     }
     __syncthreads();
+    asm volatile("" : "+v"(sink));      // the dropped loads were issued before stage 0's and have retired with it
 
     const int g = lane >> 4, li = lane & 15;
     // wgrad only: row sums of opA (= bias gradient, sum over tokens of dY) from one extra MFMA per
