@@ -14,7 +14,9 @@ m = bench.make_model(a).to(dev).train()
 tr = Trainer(m, B, device=dev)
 lo, hi = bench.synthetic(a, 0, dev); tr.load_batch(lo, hi)
 for _ in range(3): tr.step()
-names = ("swin96_block_fwd", "swin96_block_bwd", "swinw_block_fwd", "swinw_block_bwd", "gemm")
+names = ("swin96_block_fwd", "swin96_block_bwd", "swinw_block_fwd", "swinw_block_bwd", "gemm", "tail_fwd", "tail_bwd", "layernorm_fwd",
+         "layernorm_bwd", "layernorm_bwd_splitk", "splitk_resid_ln", "patch_embed_fwd", "patch_embed_bwd", "window_attn_fwd",
+         "window_attn_bwd")
 real = {n: getattr(ops, n) for n in names}
 rec = []
 def wrap(n):
