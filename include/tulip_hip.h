@@ -390,7 +390,7 @@ int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream);
  * they are ([3C][C], [C][C], [4C][C], [C][4C]); backward: packed copies of their TRANSPOSES (item.transpose = 1).
  * rows % 16 == 0 and cols % 32 == 0 of the matrix being packed (after the transpose, if any); up to TULIP_PACK_MAX
  * matrices per launch. */
-#define TULIP_PACK_MAX 32
+#define TULIP_PACK_MAX 64
 typedef struct tulip_pack_item { const void* src; void* dst; int rows; int cols; int transpose; } tulip_pack_item;
 int tulip_swinw_supported(int C, int H, int W);
 int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hipStream_t stream);

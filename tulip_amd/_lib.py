@@ -49,7 +49,7 @@ class PackItem(ctypes.Structure):
     _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I), ("transpose", I)]
 
 
-REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 32
+REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 64
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {

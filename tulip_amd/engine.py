@@ -166,14 +166,14 @@ class FlatParams:
                 off = _ceil(off + self.numel[n], ALIGN)
         self.packed = torch.zeros(max(off, ALIGN), dtype=torch.bfloat16, device=self.device)
         self.packed_t = torch.zeros(max(off, ALIGN) if with_transposes else ALIGN, dtype=torch.bfloat16, device=self.device)
-        self._pk_lists = {}
+        self._pk_entries, self._pk_joined = {}, {}
         for width, names in names_by_width.items():
             ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
                    for n in names]
             if with_transposes:
                 ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
                         for n in names]
-            self._pk_lists[width] = ops.pack_items(ent)
+            self._pk_entries[width] = ent
         self.pk_active = set()
 
     def p16p(self, name: str) -> int:
@@ -183,10 +183,15 @@ class FlatParams:
         return self.packed_t.data_ptr() + 2 * self.pk_offset[name]
 
     def refresh_transposes(self):
-        for width in sorted(getattr(self, "pk_active", ())):
-            items, n = self._pk_lists[width]
-            if n:
-                ops.pack_bf16_multi(items, n)
+        """One launch for the copies of every active width (up to TULIP_PACK_MAX matrices per launch)."""
+        key = tuple(sorted(getattr(self, "pk_active", ())))
+        if not key:
+            return
+        if key not in self._pk_joined:
+            self._pk_joined[key] = ops.pack_items([e for width in key for e in self._pk_entries[width]])
+        items, n = self._pk_joined[key]
+        if n:
+            ops.pack_bf16_multi(items, n)
 
 
 class Plan:
