@@ -110,6 +110,9 @@ struct StagedWeights {
     }
 };
 
+// SAVE = false: the inference form (eval / MC-dropout forward: nothing is kept for a backward) -- 116 of the 129 MB a launch
+// moves at batch 8 are the saved activations
+template <bool SAVE>
 __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             for (int r = 0; r < 4; ++r) { const float d = xv[n][r] - mu; s2 += d * d; }
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
-        if (gq == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+        if (SAVE && gq == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
         bf16x4 p1[6];
 #pragma unroll
         for (int n = 0; n < 6; ++n) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            store_bf16_tile_pair(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
+            if constexpr (SAVE) store_bf16_tile_pair(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
             xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
         }
     }
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), xfrag[s], acc, 0, 0, 0);
         const float4 bq = *(const float4*)(prm + P_BQKV + 16 * j + 4 * gq);
         qkvp[j] = pack4(acc[0] + bq.x, acc[1] + bq.y, acc[2] + bq.z, acc[3] + bq.w);
-        if (j & 1) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
+        if (SAVE && (j & 1)) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
     }
 
     // fc1.weight rows 0..287 replace qkv.weight in LDS once every wave is through the qkv GEMM: fetched now, written
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb, o, 0, 0, 0);   // o[r] = O[t][16dc + 4gq + r]
             op[dc] = pack4(o[0], o[1], o[2], o[3]);
         }
-        store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
+        if constexpr (SAVE) store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
 
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const float4 bp = *(const float4*)(prm + P_BPROJ + c0);
             xv[n2] = (f32x4){xv[n2][0] + s0 * (acc[0] + bp.x), xv[n2][1] + s0 * (acc[1] + bp.y),
                              xv[n2][2] + s0 * (acc[2] + bp.z), xv[n2][3] + s0 * (acc[3] + bp.w)};
-            *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
+            if constexpr (SAVE) *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
             sum += (xv[n2][0] + xv[n2][1]) + (xv[n2][2] + xv[n2][3]);
         }
         sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             for (int r = 0; r < 4; ++r) { const float d = xv[n2][r] - mu; s2 += d * d; }
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
-        if (gq == 0) { a.mean2[row] = mu; a.rstd2[row] = rs; }
+        if (SAVE && gq == 0) { a.mean2[row] = mu; a.rstd2[row] = rs; }
         bf16x4 p2[6];
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            store_bf16_tile_pair(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
+            if constexpr (SAVE) store_bf16_tile_pair(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
             x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
         }
     }
@@ -328,8 +331,10 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
             gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
         }
-        store_bf16_tile_pair(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
-        store_bf16_tile_pair(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
+        if constexpr (SAVE) {
+            store_bf16_tile_pair(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
+            store_bf16_tile_pair(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
+        }
         const bf16x8 gf = cat8(gp[0], gp[1]);
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
@@ -741,7 +746,14 @@ extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t st
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
-    hipLaunchKernelGGL(swin96_fwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
+    // every saved-activation pointer NULL: the inference form
+    const bool save = d->xn1 || d->qkv || d->attn_out || d->x1 || d->xn2 || d->fc1_pre || d->fc1_act || d->mean1 || d->rstd1 ||
+                      d->mean2 || d->rstd2;
+    if (save && !(d->xn1 && d->qkv && d->attn_out && d->x1 && d->xn2 && d->fc1_pre && d->fc1_act && d->mean1 && d->rstd1 &&
+                  d->mean2 && d->rstd2))
+        return TULIP_ERR_ARG;
+    if (save) hipLaunchKernelGGL(swin96_fwd_kernel<true>, dim3(blocks), dim3(NT), 0, stream, a);
+    else hipLaunchKernelGGL(swin96_fwd_kernel<false>, dim3(blocks), dim3(NT), 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

@@ -233,8 +233,12 @@ __device__ __forceinline__ TokMap make_map(int B, int H, int W, int sh, int sw) 
     return m;
 }
 
-template <int C, int G, int WARM>
+// MODE: bits 0-1 = the L2 warm-up (0 none, 1 every workgroup, 2 the first 256); bit 2 = the inference form (eval / MC-dropout
+// forward: the activations a backward would need are not written)
+template <int C, int G, int MODE>
 __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWArgs a) {
+    constexpr int WARM = MODE & 3;
+    constexpr bool SAVE = !(MODE & 4);
     using Z = Geo<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
@@ -292,13 +296,13 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                     q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 }
                 const float rs = rsqrtf(group_sum<16>(q) * (1.0f / C) + a.eps);
-                if (t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+                if (SAVE && t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
 #pragma unroll
                 for (int j = 0; j < C / 64; ++j) {
                     const int c = 4 * t + 64 * j;
                     const bf16x4 pk = pack4((xv[p][j].x - mu) * rs * ga[j].x + be[j].x, (xv[p][j].y - mu) * rs * ga[j].y + be[j].y,
                                             (xv[p][j].z - mu) * rs * ga[j].z + be[j].z, (xv[p][j].w - mu) * rs * ga[j].w + be[j].w);
-                    *(bf16x4*)(a.xn1 + row * C + c) = pk;
+                    if constexpr (SAVE) *(bf16x4*)(a.xn1 + row * C + c) = pk;
                     put4<T>(XN, tt, c, pk);
                 }
             }
@@ -342,7 +346,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 qkvp[i][g] = pack4(acc[i][g][0] + bqi[0], acc[i][g][1] + bqi[1], acc[i][g][2] + bqi[2], acc[i][g][3] + bqi[3]);
-                if (i & 1)      // two adjacent tiles: one 16-byte store per lane (common.h)
+                if (SAVE && (i & 1))      // two adjacent tiles: one 16-byte store per lane (common.h)
                     store_bf16_tile_pair(a.qkv + rows[g] * (3 * C) + n - 16 - 4 * gq, qkvp[i - 1][g], qkvp[i][g], gq);
             }
         }
@@ -396,7 +400,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             opp[dc] = pack4(o[0], o[1], o[2], o[3]);
             put4<T>(XO, 16 * g + t, 32 * wid + 16 * dc + 4 * gq, opp[dc]);
         }
-        store_bf16_tile_pair(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
+        if constexpr (SAVE) store_bf16_tile_pair(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
     }
     TULIP_STAMP(5);
     __syncthreads();
@@ -422,7 +426,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             for (int i = 0; i < 2; ++i) {
                 const int c0 = 32 * wid + 16 * i + 4 * gq;
                 x1v[i][g] = x1v[i][g] + s0 * (acc[i][g] + bp[i]);
-                *(float4*)(a.x1 + rows[g] * C + c0) = make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]);
+                if constexpr (SAVE) *(float4*)(a.x1 + rows[g] * C + c0) = make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]);
                 sm += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
             }
             // statistics of this wave's 32 channels of token t: (mean, sum of squared deviations)
@@ -452,7 +456,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
         for (int w = 0; w < NWV; ++w) { const float d = st[w].x - mu; m2 += st[w].y + 32.0f * d * d; }
         const float rs = rsqrtf(m2 * (1.0f / C) + a.eps);
-        if (wid == 0 && gq == 0) { a.mean2[rows[g]] = mu; a.rstd2[rows[g]] = rs; }
+        if (SAVE && wid == 0 && gq == 0) { a.mean2[rows[g]] = mu; a.rstd2[rows[g]] = rs; }
         bf16x4 pk2[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -461,7 +465,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                            (x1v[i][g][2] - mu) * rs * ga2[i][2] + be2[i][2], (x1v[i][g][3] - mu) * rs * ga2[i][3] + be2[i][3]);
             put4<T>(XN, 16 * g + t, c0, pk2[i]);
         }
-        store_bf16_tile_pair(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
+        if constexpr (SAVE) store_bf16_tile_pair(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
     }
     f32x4 b1v[D == 2 ? 2 : 1][4];
     if constexpr (D == 2) {
@@ -497,8 +501,10 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                 put4<T>(GB, 16 * g + t, n, gp);
                 if (i & 1) {    // two adjacent tiles: one 16-byte store per lane (common.h)
                     const size_t off = rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1);
-                    store_bf16_tile_pair(a.h + off, hprev[g], hp, gq);
-                    store_bf16_tile_pair(a.g + off, gprev[g], gp, gq);
+                    if constexpr (SAVE) {
+                        store_bf16_tile_pair(a.h + off, hprev[g], hp, gq);
+                        store_bf16_tile_pair(a.g + off, gprev[g], gp, gq);
+                    }
                 } else {
                     hprev[g] = hp; gprev[g] = gp;
                 }
@@ -552,12 +558,17 @@ template <int C, int G>
 int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
     // the workgroups that are resident first warm their XCD's L2 with the block's weights (WeightWarm)
-    if (blocks <= 256 && blocks >= 8 && !a.prof && swinw_warm)
-        hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 1>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
-    else if (blocks > 256 && !a.prof && swinw_warm)
-        hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 2>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
-    else
-        hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 0>), dim3(blocks), dim3(Geo<C, G>::NT), 0, stream, a);
+    const int warm = (a.prof || !swinw_warm || blocks < 8) ? 0 : (blocks <= 256 ? 1 : 2);
+    const dim3 grid(blocks), block(Geo<C, G>::NT);
+    if (a.qkv) {
+        if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 1>), grid, block, 0, stream, a);
+        else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 0>), grid, block, 0, stream, a);
+    } else {                                                // inference form: no saved activations
+        if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 5>), grid, block, 0, stream, a);
+        else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 6>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 4>), grid, block, 0, stream, a);
+    }
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }
@@ -1055,6 +1066,13 @@ static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, uns
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.out_bf16 = (bf16_t*)out_bf16;
     a.prof = prof;
+    {   // every saved-activation pointer NULL: the inference form
+        const bool any = d->xn1 || d->qkv || d->attn_out || d->x1 || d->xn2 || d->fc1_pre || d->fc1_act || d->mean1 || d->rstd1 ||
+                         d->mean2 || d->rstd2;
+        const bool all = d->xn1 && d->qkv && d->attn_out && d->x1 && d->xn2 && d->fc1_pre && d->fc1_act && d->mean1 && d->rstd1 &&
+                         d->mean2 && d->rstd2;
+        if (any && !all) return TULIP_ERR_ARG;
+    }
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
     if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_fwd<192, 4>(a, stream) : launch_fwd<192, 2>(a, stream);

@@ -438,6 +438,8 @@ class TulipEngine:
             return None
         return P.drop_scale.data_ptr() + 4 * (sp.slot + branch) * P.B
 
+    infer_no_save = os.environ.get("TULIP_INFER_NO_SAVE", "1") != "0"   # fused blocks' inference form in with_loss=False forwards
+    _no_save = False
     fuse_block96 = os.environ.get("TULIP_FUSE_BLOCK96", "1") != "0"
     fuse_block96_bwd = os.environ.get("TULIP_FUSE_BLOCK96_BWD", "1") != "0"
 
@@ -515,10 +517,13 @@ class TulipEngine:
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
             launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
             wf = W_.p16p if wide else W_.p16           # the wide kernel streams fragment-major copies of the weights
+            # forward without a backward behind it (run_forward(with_loss=False): eval / MC-dropout inference): the kernels'
+            # inference form -- none of the activations a backward would read is written (90 % of the C = 96 kernel's traffic)
+            sv = (lambda k: None) if self._no_save else (lambda k: P[p + k])
             launch(
-                x_in=xin, x1=P[p + ".x1"], x_out=xout, xn1=P[p + ".xn1"], qkv=P[p + ".qkv"], attn_out=P[p + ".o"],
-                xn2=P[p + ".xn2"], fc1_pre=P[p + ".h"], fc1_act=P[p + ".g"], mean1=P[p + ".mean1"],
-                rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
+                x_in=xin, x1=sv(".x1"), x_out=xout, xn1=sv(".xn1"), qkv=sv(".qkv"), attn_out=sv(".o"),
+                xn2=sv(".xn2"), fc1_pre=sv(".h"), fc1_act=sv(".g"), mean1=sv(".mean1"),
+                rstd1=sv(".rstd1"), mean2=sv(".mean2"), rstd2=sv(".rstd2"),
                 w_qkv=wf(p + ".attn.qkv.weight"), w_proj=wf(p + ".attn.proj.weight"),
                 w_fc1=wf(p + ".mlp.fc1.weight"), w_fc2=wf(p + ".mlp.fc2.weight"),
                 b_qkv=W_.p32(p + ".attn.qkv.bias"), b_proj=W_.p32(p + ".attn.proj.bias"),
@@ -595,6 +600,7 @@ class TulipEngine:
         m, W_ = self.model, self.params
         if W_.shadow_dirty:
             W_.refresh_shadow()
+        self._no_save = not with_loss and self.infer_no_save
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
         kw = 8 if m.circular_padding else m.patch_size[1]
