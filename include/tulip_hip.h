@@ -341,7 +341,9 @@ int tulip_kitti_range_map(const float* points, int64_t n, int rows, int cols, fl
  * shift_h/shift_w != 0, mask when `masked`) -> +DropPath residual -> norm2 -> Mlp.forward (:194-200) -> +residual.
  * Tokens (B,H,W,96) fp32, H even, W % 64 == 0.  Every tensor the backward reads is written exactly as the separate
  * kernels write it: xn1 [M][96] bf16, qkv [M][288] bf16, attn_out [M][96] bf16, x1 [M][96] fp32, xn2 [M][96] bf16,
- * fc1_pre / fc1_act [M][384] bf16, mean/rstd [M] fp32.  drop_scale_* : per-sample DropPath multipliers or NULL. */
+ * fc1_pre / fc1_act [M][384] bf16, mean/rstd [M] fp32.  drop_scale_* : per-sample DropPath multipliers or NULL.
+ * Inference form: ALL eleven saved-activation pointers (x1, xn1, qkv, attn_out, xn2, fc1_pre, fc1_act, mean1, rstd1, mean2,
+ * rstd2) NULL -- only x_out (and the wide kernels' out_bf16) is written; some but not all NULL is an argument error. */
 typedef struct tulip_swin96_desc {
     const float* x_in; float* x1; float* x_out;
     void* xn1; void* qkv; void* attn_out; void* xn2; void* fc1_pre; void* fc1_act;
