@@ -1,0 +1,38 @@
+"""GPU: the bench.py contract the driver depends on -- `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with
+the metric of BASELINE.json, the whole-job value, and the `roofline` / `cpu_baseline` objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
+                        "--no-secondary", "--cpu-steps", "1", "--cpu-warmup", "0", "--cpu-batch", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["unit"] == base.get("unit", d["unit"]) and "range-images" in d["metric"]
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3      # whole-job img/s of batch 8
+    assert d["step_ms_min"] <= d["step_ms_median"] <= 1.5 * d["ms_per_step"]
+    ro = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in ro
+    assert ro["bound"] in ("hbm", "mfma") and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert ro["traffic"] is None or ro["traffic"] > 0
+    assert len(ro["others"]) >= 4 and all("frac" in e and "in_step" in e for e in ro["others"])
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
