@@ -4,8 +4,11 @@
 Workload (BASELINE.json configs[1]): tulip_base, KITTI 16x1024 -> 64x1024, per-GPU batch 8, bf16 GEMM
 operands / fp32 accumulate, train mode (DropPath active), synthetic inputs of SURVEY.md 8(d) resident
 in HBM.  A step = forward + L1 loss + backward + gradient all-reduce (N>1) + fused AdamW, replayed
-from HIP graphs.  `python bench.py --gpus N --steps K --warmup W`; for N>1 launch one rank per GPU
-with torch.distributed.run (RCCL).  Rank 0 prints ONE JSON line.
+from HIP graphs.  `python bench.py --gpus N --steps K --warmup W`.  N > 1 = one rank per GPU over RCCL: either
+launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in the
+environment; the reference's recipe, bash_scripts/tulip_upsampling_kitti.sh:35 + util/misc.py:253-285), or, when no
+launcher set WORLD_SIZE, bench.py starts the N ranks itself through the same module (spawn_ranks).  Rank 0 prints ONE
+JSON line.
 
 Extra objects:  "roofline" -- the dominant kernel (the bf16 MFMA GEMM family): algorithmic FLOPs of
 its launches in one step / their summed duration, each launch bracketed by HIP events on the launch
@@ -14,9 +17,13 @@ oracle (plain PyTorch fp32 restatement of the reference, oracle/tulip_oracle.py)
 training step on the host cores, rank 0, N=1 only, bounded sample.
 """
 import argparse
+import faulthandler
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -316,8 +323,143 @@ def comm_report(trainer, args, world, device, steps=10):
             "per_bucket_adamw": trainer.bucket_adamw, "step_ms": round(with_coll, 4),
             "step_ms_collectives_skipped": round(without, 4), "exposed_exchange_ms": round(with_coll - without, 4),
             "rccl_version": ver, "wgrad_workgroups_per_launch": trainer.eng.wgrad_ctas or trainer.eng.WGRAD_BIG_CTAS,
+            # None = not set: RCCL's own choice (channel count, algorithm, protocol) is in force
             "env": {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO",
-                                                   "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ}}
+                                                   "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")}}
+
+
+# ---------------------------------------------------------------------------------------------- N > 1 plumbing
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` with no launcher in the environment: run the N ranks under torch.distributed.run on
+    this node (one process per GPU, rendezvous on 127.0.0.1 -- the reference's `torchrun --nproc_per_node N`,
+    bash_scripts/tulip_upsampling_kitti.sh:35).  The ranks inherit stdout: rank 0's JSON line is this process's output.
+    If the captured-graph step fails on the first attempt the run is repeated once with --no-graph (eager launches, the
+    same kernels and collectives), so that a multi-GPU number exists either way; the line then says "hip_graph": false."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    env["TULIP_BENCH_SPAWNED"] = "1"
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    rc = subprocess.call(base + list(argv), env=env)
+    if rc != 0 and "--no-graph" not in argv and os.environ.get("TULIP_BENCH_NO_RETRY", "0") != "1":
+        sys.stderr.write(f"bench.py: the {n}-rank run exited with status {rc}; retrying once with --no-graph\n")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            base[base.index("--master-port") + 1] = str(sk.getsockname()[1])
+        rc = subprocess.call(base + list(argv) + ["--no-graph"], env=env)
+    return rc
+
+
+_PHASE = ["start", 0]
+
+
+def phase(name: str):
+    _PHASE[0] = name
+    _PHASE[1] += 1
+
+
+def start_watchdog(rank: int, limit_s: float, trainer_ref: list):
+    """A rank that makes no host-side progress for `limit_s` seconds (a collective that never completes blocks the
+    host in the next synchronize) reports where it stopped -- bench phase, optimizer step, the graph segment or
+    all-reduce it issued last -- dumps its Python stacks and exits with status 124, which takes the whole
+    torch.distributed.run job down instead of hanging the node."""
+    def state():
+        tr = trainer_ref[0]
+        return (tuple(_PHASE), tr.progress if tr is not None else None)
+
+    def run():
+        last, t_last = state(), time.time()
+        while True:
+            time.sleep(1.0)
+            cur = state()
+            if cur[0][0] == "done":
+                return
+            if cur != last:
+                last, t_last = cur, time.time()
+            elif time.time() - t_last > limit_s:
+                sys.stderr.write(json.dumps({"bench_watchdog": "no progress", "rank": rank, "seconds": round(time.time() - t_last, 1),
+                                             "phase": cur[0][0], "trainer_progress": cur[1]}) + "\n")
+                sys.stderr.flush()
+                faulthandler.dump_traceback(file=sys.stderr)
+                os._exit(124)
+    threading.Thread(target=run, daemon=True, name="bench-watchdog").start()
+
+
+def collective_smoke(device, world: int, nbytes: int):
+    """Before anything is captured: one checked all-reduce, then the largest gradient bucket's size timed (5 x, HIP
+    events on the current stream, which RCCL's stream joins) and a 4-KB one for the latency floor.  busbw follows
+    nccl-tests: algbw x 2 (N-1)/N."""
+    chk = torch.full((1024,), float(dist.get_rank() + 1), device=device)
+    dist.all_reduce(chk)
+    torch.cuda.synchronize()
+    want = world * (world + 1) / 2
+    if not bool((chk == want).all()):
+        raise SystemExit(f"collective smoke: all-reduce returned {chk[0].item()}, expected {want}")
+    out = {}
+    for tag, nb in (("bucket", nbytes), ("small", 4096)):
+        buf = torch.ones(nb // 4, device=device)
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / 5
+        tt = torch.tensor([t], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = tt.item()
+        out[tag] = {"bytes": nb, "ms": round(t * 1e3, 4), "algbw_GBps": round(nb / t / 1e9, 2),
+                    "busbw_GBps": round(nb / t / 1e9 * 2 * (world - 1) / world, 2)}
+        del buf
+    return out
+
+
+def reference_loop(args, device, steps=20, warmup=5):
+    """The reference's OWN calling convention on the drop-in module, unchanged (engine_upsampling.py:69-100,
+    util/misc.py:292-305, main_lidar_upsampling.py:282-283): torch.autocast around model(lo, hi), GradScaler
+    scale -> backward -> unscale_ -> step -> update, torch.optim.AdamW(betas=(0.9, 0.95)) over timm-style decay groups,
+    the per-iteration loss read-back and torch.cuda.synchronize().  Eager launches through the autograd bridge: what a
+    user gets with zero edits, next to the fused Trainer step of the headline."""
+    model = make_model(args).to(device).train()
+    decay = [p for p in model.parameters() if p.ndim > 1]
+    no_decay = [p for p in model.parameters() if p.ndim <= 1]
+    opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.01}],
+                            lr=5e-4, betas=(0.9, 0.95))
+    scaler = torch.amp.GradScaler("cuda")
+    lo, hi = synthetic(args, 0, device)
+    opt.zero_grad()
+
+    def one():
+        with torch.autocast("cuda"):
+            _, total_loss, pixel_loss = model(lo, hi, eval=False)
+        v = total_loss.item()
+        pixel_loss.item()
+        scaler.scale(total_loss).backward()
+        scaler.unscale_(opt)
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        return v
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        v = one()
+    dt = time.perf_counter() - t0
+    del model, opt
+    torch.cuda.empty_cache()
+    return {"metric": "range-images/sec training, the reference's loop body unchanged (autocast + GradScaler + "
+                      "torch.optim.AdamW + loss.item() + synchronize per step) on the drop-in module",
+            "value": round(args.batch * steps / dt, 2), "unit": "range-images/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup, "final_loss": round(v, 6), "grad_scale": scaler.get_scale()}
 
 
 def secondary_batch64(args, device, steps=30, warmup=15, attn_fp8=False):
@@ -370,35 +512,59 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--no-secondary", action="store_true", help="skip the batch-64 line (BASELINE config 5, bf16)")
+    ap.add_argument("--no-reference-loop", action="store_true",
+                    help="skip the secondary line that times the reference's own loop body on the drop-in module")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("TULIP_BENCH_WATCHDOG", "240")),
+                    help="N>1: seconds without host-side progress before a rank reports where it hangs and exits 124")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks here (the driver's `python bench.py --gpus N`); under torch.distributed.run
+        # the environment carries WORLD_SIZE and this process IS a rank
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: torch.distributed.run --nproc-per-node must equal --gpus")
     # rehearsal of the N > 1 path on a one-GPU box (dev only): TULIP_BENCH_BACKEND=gloo lets the ranks share cuda:0
     backend = os.environ.get("TULIP_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU over RCCL)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    trainer_ref = [None]
     if world > 1:
+        start_watchdog(rank, args.watchdog, trainer_ref)
+        phase("init_process_group")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
         else:
             dist.init_process_group(backend=backend, init_method="env://")
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group reports {dist.get_world_size()} ranks, expected {world}")
 
     from tulip_amd.trainer import Trainer
+    phase("model")
     model = make_model(args).to(device).train()
+    smoke = None
+    if world > 1:
+        phase("collective_smoke")
+        # the largest gradient bucket of tulip_base (stage 3: 66 MB fp32) before any graph is captured
+        smoke = collective_smoke(device, world, 66 << 20)
+    phase("trainer")
     trainer = Trainer(model, args.batch, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, device=device,
                       use_graph=not args.no_graph, grad_dtype=args.grad_dtype, bucket_mb=args.bucket_mb)
+    trainer_ref[0] = trainer
     lo, hi = synthetic(args, rank, device)
     trainer.load_batch(lo, hi)
 
+    phase("warmup")
     for _ in range(args.warmup):
         trainer.step()
     torch.cuda.synchronize()
@@ -408,6 +574,7 @@ def main():
     # wall clock brackets the K steps (the contract's number); one HIP event per step boundary on the launch stream
     # gives the per-step distribution (median and min)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    phase("timed")
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -452,17 +619,26 @@ def main():
                         "reference's own bf16-autocast band (max 8e-3 abs); gradients <= 1.5e-2 rel L2 per tensor "
                         "(tests/test_model_gpu.py)")
     if world > 1:
+        phase("comm_report")
         out["comm"] = comm_report(trainer, args, world, device)
+        out["comm"]["world_size_rccl"] = dist.get_world_size()
+        out["comm"]["backend"] = dist.get_backend()
+        out["comm"]["collective_smoke"] = smoke
+        out["comm"]["launcher"] = "bench.py spawn_ranks" if os.environ.get("TULIP_BENCH_SPAWNED") else "external (torch.distributed.run)"
     if rank == 0 and world == 1 and not args.no_secondary and args.batch == 8 and args.model == "tulip_base":
         out["secondary"] = secondary_batch64(args, device)
         out["secondary_fp8_attention"] = secondary_batch64(args, device, attn_fp8=True)
+    if rank == 0 and world == 1 and not args.no_reference_loop and headline:
+        out["secondary_reference_loop"] = reference_loop(args, device)
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = kernel_rooflines(trainer)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    phase("done")
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -406,6 +406,10 @@ int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W);
  * per-wave streams would otherwise run at miss latency (tools/cold_probe.py).  on = 0 switches that off (measurement
  * only; results are identical either way).  Process-wide, not re-entrant against concurrent launches. */
 int tulip_swinw_set_warm(int on);
+/* The same first touch in tulip_gemm_bf16 (forward / data-gradient form: the M-tile workgroups of an N panel split the
+ * cold [96][k range] weight panel between them before their k loops start).  on = 0 switches it off (measurement and the
+ * bit-compare test only; results are identical either way).  Process-wide. */
+int tulip_gemm_set_touch(int on);
 int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream);
 int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream);
 

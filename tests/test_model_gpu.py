@@ -149,8 +149,10 @@ def test_tiny_gradients_vs_reference(golden_dir, name):
         # g12 (PatchExpanding / FinalPatchExpanding): the extra LayerNorms of the alternates sit behind bf16-rounded
         # gradients the oracle keeps in fp32 -> bounds x1.6 (measured worst 1.7e-2 / 1.4e-2, tables 5.6e-2)
         k32, klp = (2.4e-2, 1.6e-2) if name.startswith("g12") else (1.5e-2, 1.0e-2)
-        assert e32 <= (1.5e-1 if table else k32), (k, e32)
-        assert elp <= ((1.5e-1 if name.startswith("g12") else 8e-2) if table else klp), (k, elp)
+        # bias tables: 1e-1 / 5e-2 for the default model (module docstring); the wider 1.5e-1 only for the g12 alternates
+        t32, tlp = (1.5e-1, 1.5e-1) if name.startswith("g12") else (1e-1, 5e-2)
+        assert e32 <= (t32 if table else k32), (k, e32)
+        assert elp <= (tlp if table else klp), (k, elp)
     print(f"worst per-tensor relative L2 gradient error (non-table): vs fp32 {worst[0]:.3e}, vs lowp {worst[1]:.3e}")
     for k in z.files:
         if k.startswith("grad::"):

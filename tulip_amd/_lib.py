@@ -62,6 +62,7 @@ SIGNATURES = {
     "tulip_swinw_block_fwd_profiled": [P, I, P, P, P],
     "tulip_swinw_bwd_partial_rows": [I, I, I, I],
     "tulip_swinw_set_warm": [I],
+    "tulip_gemm_set_touch": [I],
     "tulip_swinw_block_bwd": [P, I, P],
     "tulip_pack_bf16_multi": [P, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],

@@ -30,6 +30,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
+// L2 warm-up touch: 16 bytes per lane at `gptr` are pulled through the caches and DROPPED into `lds_scratch` (a KiB of LDS
+// per wave instruction, lane i lands at scratch + 16 i; nothing reads it, so every wave may share one KiB).
+// global_load_lds_dwordx4 via the compiler's builtin: no VGPR destination for the register allocator to move underneath an
+// in-flight load, and the compiler's own vmcnt accounting covers it.
+__device__ __forceinline__ void warm_touch16(const void* gptr, void* lds_scratch) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_scratch, 16, 0, 0);
+}
+
 // Two adjacent 16-column tiles of one output row in the MFMA accumulator layout -- lane (t, gq) holds 4 bf16 of tile A at
 // columns 4 gq and 4 bf16 of tile B at columns 16 + 4 gq -- leave as ONE 16-byte store per lane instead of two 8-byte
 // ones: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other, after which an

@@ -50,7 +50,10 @@ struct GemmArgs {
     int rows_per_sample;
     int accumulate;
     int psH, psW;
+    int touch;   // first touch of the cold weight panel split between the M-tile workgroups (tulip_gemm_set_touch)
 };
+
+int gemm_touch_on = 1;
 
 // launch heuristics (compile-time; mirrored by bench.py's kernel-name bookkeeping)
 #define TULIP_GEMM_BIG_TILES 2048   // 128-row tiles only for launches with at least this many of them
@@ -268,6 +271,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     constexpr int STG_BYTES = 64 * STG_PITCH;              // 64 output rows per write-out pass
     constexpr int PIPE_BYTES = 2 * (A_BYTES + B_BYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem[PIPE_BYTES > STG_BYTES ? PIPE_BYTES : STG_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char warm_sink[1024];      // where the panel touch drops its data
     auto ldsA = [&](int buf) -> unsigned char* { return smem + buf * (A_BYTES + B_BYTES); };
     auto ldsB = [&](int buf) -> unsigned char* { return smem + buf * (A_BYTES + B_BYTES) + A_BYTES; };
 
@@ -302,21 +306,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // Cold weights.  In the training step a Linear's weights were last read a step ago; the k loop below has two or three
     // stages in flight and so walks its [BN][k range] weight panel at miss latency.  The M-tile workgroups of one N panel
     // (blockIdx.y; on one XCD, i.e. one L2, when gridDim.x % 8 == 0) first split the panel between them and touch it with
-    // loads whose data is dropped (one register quad, returns are in order; see WeightWarm in swinw.hip): everything is in
-    // flight at once and the loop's own loads hit L2.  The dropped loads are older than stage 0's, so they have retired
-    // when stage 0 is written to LDS.
-    typedef uint32_t u32x4_g __attribute__((ext_vector_type(4)));
-    u32x4_g sink = {0u, 0u, 0u, 0u};
+    // loads whose data is dropped into a KiB of LDS nobody reads (warm_touch16, common.h: LDS-destination loads the
+    // compiler tracks itself; see WeightWarm in swinw.hip): everything is in flight at once and the loop's own loads hit
+    // L2.  The dropped loads are older than stage 0's, so they have retired when stage 0 is written to LDS.
     if constexpr (!A_T) {
-        const int rowsN = min(BN, p.N - n0), kw = kend - kbeg;
-        // 16-byte pieces of the panel: B_T: [k][n] rows of rowsN elements; else [n][k] rows of kw elements
-        const int ppr = ((B_T ? rowsN : kw) * 2) >> 4, prow = B_T ? kw : rowsN;
-        const int npieces = ppr * prow;
-        const unsigned char* base = (const unsigned char*)(B_T ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg);
-        for (int q = (by * 4 + wid) * 64 + lane; q < npieces; q += (int)gridDim.y * 256) {
-            const int r = q / ppr, c16 = q - r * ppr;
-            const unsigned char* a16 = base + ((size_t)r * p.ldb) * 2 + c16 * 16;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(a16));
+        if (p.touch) {
+            const int rowsN = min(BN, p.N - n0), kw = kend - kbeg;
+            // 16-byte pieces of the panel: B_T: [k][n] rows of rowsN elements; else [n][k] rows of kw elements
+            const int ppr = ((B_T ? rowsN : kw) * 2) >> 4, prow = B_T ? kw : rowsN;
+            const int npieces = ppr * prow;
+            const unsigned char* base = (const unsigned char*)(B_T ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg);
+            for (int q = (by * 4 + wid) * 64 + lane; q < npieces; q += (int)gridDim.y * 256) {
+                const int r = q / ppr, c16 = q - r * ppr;
+                warm_touch16(base + ((size_t)r * p.ldb) * 2 + c16 * 16, warm_sink);
+            }
         }
     }
     static_for<RING - 1>([&](auto R) { if (nt > decltype(R)::value) issue(R, decltype(R)::value); });
@@ -325,7 +328,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
         sb[0].store(ldsB(0), tid);
     }
     __syncthreads();
-    asm volatile("" : "+v"(sink));      // the dropped loads were issued before stage 0's and have retired with it
 
     const int g = lane >> 4, li = lane & 15;
     // wgrad only: row sums of opA (= bias gradient, sum over tokens of dY) from one extra MFMA per
@@ -774,7 +776,7 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     splits = (K + kchunk - 1) / kchunk;
     p.epi = epi; p.bias = bias; p.out = out; p.ldo = ldo; p.out2 = out2; p.ldo2 = ldo2;
     p.aux = aux; p.ldaux = ldaux; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-    p.accumulate = accumulate; p.psH = psH; p.psW = psW;
+    p.accumulate = accumulate; p.psH = psH; p.psW = psW; p.touch = gemm_touch_on;
     GemmArgs q = p;  // what the GEMM kernel itself does
     const bool fold = splits > 1 && !raw_split;
     if (fold) {
@@ -851,7 +853,7 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
         p.A = (const bf16_t*)it.dY; p.B = (const bf16_t*)it.X; p.lda = it.ldy; p.ldb = it.ldx;
         p.M = it.Nw; p.N = it.Kw; p.K = it.Mtok; p.kchunk = kchunk;
         p.bias = nullptr; p.ldo = it.Kw; p.ldo2 = 0; p.aux = nullptr; p.ldaux = 0; p.rowscale = nullptr;
-        p.rows_per_sample = 1; p.psH = 0; p.psW = 0;
+        p.rows_per_sample = 1; p.psH = 0; p.psW = 0; p.touch = 0;
         if (splits > 1) {
             const int64_t nw = (int64_t)it.Nw * it.Kw, need = (nw + (it.db ? it.Nw : 0)) * splits;
             if (!ws || (ws_used + need) * 4 > workspace_bytes) return TULIP_ERR_ARG;
@@ -891,3 +893,5 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
     for (int i = 0; i < n_extra; ++i) folds[nf++] = extra[i];
     return nf ? tulip_reduce_rows_multi(folds, nf, stream) : TULIP_OK;
 }
+
+extern "C" int tulip_gemm_set_touch(int on) { gemm_touch_on = on ? 1 : 0; return TULIP_OK; }

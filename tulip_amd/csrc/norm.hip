@@ -678,7 +678,13 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
     }
 }
 
-extern "C" int tulip_splitk_resid_ln_supported(int N) { return N > 0 && N % 256 == 0 && N <= 2048; }
+// exactly the widths the launcher below instantiates (N / 256 in {1, 2, 3, 4, 6, 8}): a caller that gets "no" falls back to the
+// two-launch form instead of an argument error mid-forward
+extern "C" int tulip_splitk_resid_ln_supported(int N) {
+    if (N <= 0 || N % 256 != 0) return 0;
+    const int q = N / 256;
+    return q == 1 || q == 2 || q == 3 || q == 4 || q == 6 || q == 8;
+}
 
 extern "C" int tulip_splitk_resid_ln(const float* slabs, int nslab, int M, int N, const float* bias, const float* aux,
                                      int ldaux, const float* rowscale, int rows_per_sample, float* out, int ldo,

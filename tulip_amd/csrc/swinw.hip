@@ -131,23 +131,24 @@ __device__ __forceinline__ const bf16_t* wtile_ptr(const bf16_t* w, int nt, int 
 // workgroups), the workgroups of an XCD (blockIdx % 8) first split the block's weights between them: every wave
 // touches a few KiB chunks nobody else touches, in order of use, and drops the data; the chunks land in the XCD's L2
 // within a few miss latencies and the streams behind them hit.
-typedef uint32_t u32x4_w __attribute__((ext_vector_type(4)));
 // ON = 1: every workgroup takes part (grids of at most 256 workgroups); ON = 2: larger grids -- the first 256 workgroups
 // (the ones that find the caches cold) do it for the ones behind them.
 template <int ON>
 struct WeightWarm {
-    u32x4_w sink;
+    unsigned char* scratch;
     int nslots, slot, ws, loff;
     bool on;
-    // The loads are inline asm into ONE register quad (the data is dropped; returns are in order, so the quad may be
-    // rewritten in flight) that stays live until retire() has waited for them; the compiler's own vmcnt waits in between
-    // do not count them and so wait for them too (in-order retirement): one exposed miss latency at the head of the kernel.
-    __device__ __forceinline__ void init(int wid, int lane) {
+    // The touches are LDS-destination loads (global_load_lds_dwordx4 through the compiler's builtin): the data is dropped
+    // into a 1-KiB LDS scratch that nothing ever reads (every wave of the workgroup writes the same KiB), so no VGPR is the
+    // target of an in-flight load -- nothing the register allocator could move or reuse underneath it -- and the compiler
+    // counts them (vmcnt) like any other memory operation.  Returns are in order: the first wait for a younger load
+    // also waits for them, one exposed miss latency at the head of the kernel.
+    __device__ __forceinline__ void init(int wid, int lane, unsigned char* lds_scratch) {
         if constexpr (ON) {
             nslots = (ON == 2 ? 256 : (int)gridDim.x) >> 3; slot = blockIdx.x >> 3;
             on = ON == 1 || blockIdx.x < 256;
             ws = __builtin_amdgcn_readfirstlane(wid); loff = lane * 16;
-            sink = (u32x4_w){0u, 0u, 0u, 0u};
+            scratch = lds_scratch;
         }
     }
     // one fragment-major matrix of KIB KiB; sized for >= 192 waves per XCD (batch 8), fewer waves leave a tail cold
@@ -159,14 +160,11 @@ struct WeightWarm {
                 for (int r = 0; r < (KIB + 191) / 192; ++r) {   // chunk and address are wave-uniform: scalar arithmetic
                     int c = (r * nslots + slot) * NWV + ws;
                     c = c < KIB ? c : KIB - 1;
-                    const bf16_t* p = w + (size_t)c * 512;
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink) : "v"(loff), "s"(p));
+                    const unsigned char* p = (const unsigned char*)(w + (size_t)c * 512) + loff;
+                    warm_touch16(p, scratch);
                 }
             }
         }
-    }
-    __device__ __forceinline__ void retire() {
-        if constexpr (ON) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));
     }
 };
 
@@ -194,7 +192,8 @@ struct Geo {
     static constexpr int BIG_BYTES = T * HID * 2;              // attention output | V tiles, later gelu(fc1)
     static constexpr int OFF_XN = 0, OFF_BIG = XN_BYTES, OFF_V = OFF_BIG + XN_BYTES;
     static constexpr int OFF_STAT = OFF_BIG + BIG_BYTES;
-    static constexpr int SMEM = OFF_STAT + NWV * T * 8;
+    static constexpr int OFF_WARM = OFF_STAT + NWV * T * 8;     // 1-KiB sink of the L2 warm-up loads (WeightWarm)
+    static constexpr int SMEM = OFF_WARM + 1024;
     static_assert(OFF_V + NWV * 1024 <= OFF_STAT, "V tiles must fit beside the attention output");
     static_assert(SMEM <= 163840, "LDS");
 };
@@ -260,7 +259,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     for (int i = 0; i < 6; ++i) wq.wt[i] = wtile_ptr(a.wqkv, (i >> 1) * (C / 16) + 2 * wid + (i & 1), C, lane);
     wq.start();
     WeightWarm<WARM> warm;                          // the block's weights into this XCD's L2, in order of use
-    warm.init(wid, lane);
+    warm.init(wid, lane, smem + Z::OFF_WARM);
     warm.template touch<NWV, 6 * C * C / 1024>(a.wqkv);
     warm.template touch<NWV, 2 * C * C / 1024>(a.wproj);
     warm.template touch<NWV, 8 * C * C / 1024>(a.w1);
@@ -322,7 +321,6 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
         for (int i = 0; i < 6; ++i) bq[i] = ld4(a.bqkv + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
     }
-    warm.retire();
     TULIP_STAMP(1);
     __syncthreads();
     TULIP_STAMP(2);
@@ -599,7 +597,8 @@ struct GeoB {
     static constexpr int BIG_BYTES = T * HID * 2;              // d(fc1 pre-activation), later d(qkv) (3/4 of it)
     static constexpr int OFF_DY = 0, OFF_BIG = DY_BYTES, OFF_ATT = OFF_BIG + BIG_BYTES;   // NWV x (Q | K | dO) 1-KiB tiles
     static constexpr int OFF_STAT = OFF_ATT + NWV * 3072;
-    static constexpr int SMEM = OFF_STAT + NWV * T * 8;
+    static constexpr int OFF_WARM = OFF_STAT + NWV * T * 8;     // 1-KiB sink of the L2 warm-up loads (WeightWarm)
+    static constexpr int SMEM = OFF_WARM + 1024;
     static_assert(SMEM <= 163840, "LDS");
 };
 
@@ -682,7 +681,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     for (int i = 0; i < 4; ++i) w2a.wt[i] = wtile_ptr(a.w2t, 8 * wid + i, C, lane);
     w2a.start();
     WeightWarm<WARM> warm;                          // the four transposed weights into this XCD's L2, in order of use
-    warm.init(wid, lane);
+    warm.init(wid, lane, smem + Z::OFF_WARM);
     warm.template touch<NWV, 8 * C * C / 1024>(a.w2t);
     warm.template touch<NWV, 8 * C * C / 1024>(a.w1t);
     warm.template touch<NWV, 2 * C * C / 1024>(a.wprojt);
@@ -724,7 +723,6 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         bias_q[r] = a.bias_table[a.rel_index[t * 16 + gq * 4 + r] * NH + wid];
         bias_k[r] = a.bias_table[a.rel_index[(gq * 4 + r) * 16 + t] * NH + wid];
     }
-    warm.retire();
     __syncthreads();
 
     // ---- fc2' and GELU' (tulip.py:196-198 backwards): d(h) for this wave's 128 hidden channels = (dy . W2)[hid] * gelu'(h)

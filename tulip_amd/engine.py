@@ -384,6 +384,10 @@ class TulipEngine:
                     by_width.setdefault(sp.C, []).extend(sp.prefix + suffix for suffix in (
                         ".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"))
         self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd)
+        # every width that CAN run fused keeps its fragment-major copies fresh from the start: a Trainer's captured AdamW
+        # bakes in the pack launch for the widths active at capture time, so a width first activated by a later plan
+        # (GraphedForward at another batch size) would otherwise stream stale weights after every replayed step
+        self.params.pk_active = set(by_width)
         rel = self.model.layers[0].blocks[0].attn.relative_position_index
         self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
         rates = torch.ones(max(1, self.n_drop_slots), 1)
@@ -807,7 +811,8 @@ class TulipEngine:
             grp, used = [], 0
             gmax = self.wgrad_group_max
             cand = items[:gmax]
-            big = all(ops.wgrad_tiles(a[4], a[5]) != ((a[4] + 63) // 64) * ((a[5] + 95) // 96) for a in cand)
+            # (the large-tile kernel also needs whole 32-token k-steps: same test as tulip_wgrad_group, csrc/gemm.hip)
+            big = all(ops.wgrad_tiles(a[4], a[5]) != ((a[4] + 63) // 64) * ((a[5] + 95) // 96) and a[6] % 32 == 0 for a in cand)
             # large tiles run one workgroup per CU: the token splits of a launch are sized so that the whole group is
             # about one round of the chip
             group_tiles = sum(ops.wgrad_tiles(a[4], a[5]) for a in cand) if big else 0

@@ -335,6 +335,11 @@ def swinw_set_warm(on) -> None:
     check(_lib.load().tulip_swinw_set_warm(int(bool(on))), "tulip_swinw_set_warm")
 
 
+def gemm_set_touch(on):
+    """tulip_gemm_set_touch: the split first touch of the cold weight panel in tulip_gemm_bf16 (measurement switch)."""
+    check(_lib.load().tulip_gemm_set_touch(int(bool(on))), "tulip_gemm_set_touch")
+
+
 def swinw_bwd_partial_rows(C, B, H, W) -> int:
     return _lib.load().tulip_swinw_bwd_partial_rows(C, B, H, W)
 

@@ -94,6 +94,12 @@ class Trainer:
         # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
         # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
+        # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
+        # set before the first step (the choice is baked into the captured graphs)
+        self.inject_drop_u: Optional[torch.Tensor] = None
+        # (optimizer step, what the host issued last): read by bench.py's watchdog thread to say WHERE a multi-rank
+        # step stopped making progress (a hung collective shows as the segment tag it followed)
+        self.progress = (0, "init")
         self._side = torch.cuda.Stream(device=device) if use_graph else None
         self.process_group = process_group
         if self.world > 1:
@@ -125,7 +131,7 @@ class Trainer:
     def _fwd_bwd(self, hook, update: bool = True):
         eng, P = self.eng, self.P
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
-        eng.draw_drop_scales(P, self.model.training)
+        eng.draw_drop_scales(P, self.model.training, self.inject_drop_u)
         eng.run_forward(P)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None)
@@ -309,12 +315,14 @@ class Trainer:
             if self.accum_iter > 1:
                 self._segments[False] = self._capture(False)
         for graph, tag in self._segments[update]:
+            self.progress = (self.t, f"segment:{tag}")
             if tag == "adamw":
                 self.bucketer.wait_all()
                 graph.replay()
             else:
                 graph.replay()
                 if tag is not None:
+                    self.progress = (self.t, f"all_reduce:{tag}")
                     self._bucket_done(tag)
         if update and self.bucket_adamw:
             self._finish_buckets()
