@@ -86,26 +86,20 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
-def _pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected +
-    WRITE_SIZE, collected as MI355X_MICROARCH.md prescribes: separate --pmc passes, tools/pmc_summary.py); counters cannot
-    be read from inside bench.py.  None when the file is missing or was measured on other kernel sources."""
+FAMILIES = {   # kernel-name prefixes per family: shared with tools/instep_summary.py, pmc_summary.py, mfma_summary.py
+    "wgrad": ("wgrad_group_kernel", "gemm_group_kernel"),
+    "gemm": ("gemm_kernel",),
+    "swin96_fwd": ("swin96_fwd_kernel",), "swin96_bwd": ("swin96_bwd_kernel",),
+    "swinw_fwd": ("swinw_fwd_kernel",), "swinw_bwd": ("swinw_bwd_kernel",),
+    "fold": ("reduce_rows_multi_kernel",), "adamw": ("adamw_kernel",)}
+
+
+def _stamped(fname, family):
+    """One family's entry of a committed counter / trace summary under profiles/ (each carries the hash of the kernel
+    sources it was measured on: a file measured on other sources is not reported -- the GPU box has no .git)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", fname)) as f:
             d = json.load(f)
-        if d.get("source_stamp") != kernel_source_stamp():
-            return None
-        return round(d["families"][family]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def _instep(family):
-    """In-step mean duration of a kernel family from the committed kernel trace (profiles/instep_durations.json,
-    tools/instep_summary.py), under the same stamp rule as the PMC traffic."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "instep_durations.json")
-    try:
-        d = json.load(open(path))
         if d.get("source_stamp") != kernel_source_stamp():
             return None
         return d["families"][family]
@@ -113,30 +107,59 @@ def _instep(family):
         return None
 
 
+def _pmc_traffic(family):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc
+    passes as MI355X_MICROARCH.md prescribes, tools/pmc_summary.py); counters cannot be read from inside bench.py."""
+    e = _stamped("pmc_traffic.json", family)
+    return round(e["hbm_bytes_per_launch"]) if e else None
+
+
+def _instep(family):
+    """In-step mean duration from the committed kernel trace (profiles/instep_durations.json, tools/instep_summary.py)."""
+    return _stamped("instep_durations.json", family)
+
+
+def _mfma_counter(family):
+    """MFMA utilisation from counters (profiles/pmc_mfma.json, tools/mfma_summary.py: SQ_VALU_MFMA_BUSY_CYCLES over
+    GRBM_GUI_ACTIVE x 1024 SIMDs, its own --pmc pass)."""
+    e = _stamped("pmc_mfma.json", family)
+    return round(e["mfma_util"], 4) if e else None
+
+
 def kernel_rooflines(trainer, reps=5):
-    """Roofline of every kernel family that matters in the step.  The launches of one step are recorded in an eager pass
-    (ops.* wrappers), then each is re-issued `reps` times back to back between ONE HIP-event pair on the launch stream
-    (graph nodes cannot be instrumented, and single eager launches would include host gaps): these are ISOLATED
-    durations -- operands of the small launches sit in the Infinity Cache and nothing runs beside them; the in-step
-    averages of the same kernels are in profiles/ (rocprofv3 --kernel-trace --stats of this command), ~10-25 % longer.
-    Per family: algorithmic FLOPs and bytes (operands read once + outputs written once, the per-launch figures of
-    DESIGN.md section 4) / summed duration; `bound` is the side of the ridge (2.5 PF / 8 TB/s = 312 FLOP/B) the
-    family's arithmetic intensity falls on."""
+    """Roofline of every kernel family that matters in the step; the top object is the DOMINANT one (largest summed
+    in-step time): the grouped weight-gradient kernel.
+
+    Durations.  `frac` / `achieved` use the mean launch duration INSIDE the step, from the committed rocprofv3 kernel
+    trace of this command (profiles/instep_durations.json, kernels between consecutive AdamW launches; accepted only when
+    its source stamp equals the kernel sources this process runs, `timing` says which).  Graph nodes cannot be bracketed
+    by HIP events, so the LIVE measurement of this run is the `isolated` sub-object: the launches of one step are recorded
+    in an eager pass and each is re-issued `reps` times back to back between one HIP-event pair on the launch stream --
+    warm caches, nothing beside it, 10-40 % shorter than in the step; it is what `frac` falls back to when the committed
+    trace is stale.
+
+    Bytes.  `algorithmic_bytes_per_launch` is SURVEY 8(d)'s convention: every operand read once, every result written once
+    at its final precision -- a weight gradient's operands + fp32 dW (+ db) ONCE (split-K slabs are design traffic, not
+    algorithmic); a Linear's two operands + its output; a fused Swin block's fp32 stream in + out and its weights once (the
+    activations it saves for the backward are design traffic too: `bytes_with_saved_activations` /
+    `frac_with_saved_activations` price them in); AdamW 30 B per parameter.  `traffic` = HBM bytes per launch from the PMC
+    passes (profiles/pmc_traffic.json); traffic / algorithmic = the overhead of the design.  `mfma_util_counter` =
+    SQ_VALU_MFMA_BUSY_CYCLES-based utilisation (profiles/pmc_mfma.json) next to the FLOP-based `frac_mfma`."""
     from tulip_amd import ops
-    rec = []                                  # (family, detail-name, callable, flops, bytes)
+    rec = []                                  # (family, detail-name, callable, flops, algorithmic bytes, bytes incl. design outputs)
     real = {n: getattr(ops, n) for n in ("gemm", "wgrad_group", "swin96_block_fwd", "swin96_block_bwd", "swinw_block_fwd",
-                                         "swinw_block_bwd")}
+                                         "swinw_block_bwd", "reduce_rows_multi")}
 
     def gemm(A, B, M, N, K, **kw):
         f = 2.0 * M * N * K
         by = 2.0 * (M * K + N * K) + M * N * (4.0 if kw.get("epi", 0) in (3, 4, 5, 6, 7) else 2.0)
         name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
-        rec.append(("gemm", name, lambda: real["gemm"](A, B, M, N, K, **kw), f, by))
+        rec.append(("gemm", name, lambda: real["gemm"](A, B, M, N, K, **kw), f, by, by))
         real["gemm"](A, B, M, N, K, **kw)
 
     def wgrad_group(items, extra, ws, ws_bytes, fold=True):
         items = list(items)
-        f = by = 0.0
+        f = by = slab = 0.0
         tiles, deep = 0, True
         for it in items:
             eff = ops.gemm_effective_splits(it.Mtok, it.splits)
@@ -144,13 +167,14 @@ def kernel_rooflines(trainer, reps=5):
             tiles += -(-it.Kw // 96) * -(-it.Nw // 64) * eff
             deep = deep and kchunk >= 256
             f += 2.0 * it.Nw * it.Kw * it.Mtok
-            by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw * eff
+            by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw + 4.0 * it.Nw      # operands once, fp32 dW + db once
+            slab += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * (it.Nw * it.Kw + it.Nw) * eff      # what the launch writes: slabs
         ksub = 4 if (tiles <= 400 and deep) else 1
         big = all(ops.wgrad_tiles(it.Nw, it.Kw) != -(-it.Nw // 64) * -(-it.Kw // 96) and it.Mtok % 32 == 0 for it in items)
-        # the weight gradients of a block leave as ONE grouped launch; timed without its fold
-        rec.append(("gemm", "wgrad_group_kernel (192x192 / 384x96 / 96x384 tiles)" if big
+        # the weight gradients of a stage leave as ONE grouped launch; timed without its fold (the `fold` family)
+        rec.append(("wgrad", "wgrad_group_kernel (192x192 / 384x96 / 96x384 tiles)" if big
                     else f"gemm_group_kernel<64, true, true, {ksub}>",
-                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False), f, by))
+                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False), f, by, slab))
         real["wgrad_group"](items, extra, ws, ws_bytes, fold)
 
     def block(name, fam, bwd, C_of):
@@ -160,8 +184,9 @@ def kernel_rooflines(trainer, reps=5):
             # four linears (data gradients only in the backward: the weight gradients are GEMM launches) + the
             # 16x16 attention core (fwd: QK^T, PV; bwd: S twice, dP twice, dQ, dK, dV)
             fl = M * (24.0 * C * C + (224.0 if bwd else 64.0) * C)
-            by = (48 if bwd else 40) * C * M + 16.0 * M + 24.0 * C * C
-            rec.append((fam, name, lambda: real[name](*a, **kw), fl, by))
+            by = 8.0 * C * M + 24.0 * C * C                                   # fp32 stream in + out, weights once
+            saved = (48 if bwd else 40) * C * M + 16.0 * M + 24.0 * C * C     # + every saved / re-read activation
+            rec.append((fam, name, lambda: real[name](*a, **kw), fl, by, saved))
             real[name](*a, **kw)
         return f
 
@@ -176,14 +201,14 @@ def kernel_rooflines(trainer, reps=5):
         trainer._fwd_bwd(lambda tag: None)
         torch.cuda.synchronize()
     finally:
-        for n, fn in real.items():
-            setattr(ops, n, fn)
+        for n in patched:
+            setattr(ops, n, real[n])
     W = trainer.eng.params
     rec.append(("adamw", "adamw_kernel",
                 lambda: ops.adamw(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, W.total, trainer.hyper, W.decay_mask,
-                                  zero_grad=True), 0.0, 28.0 * W.total + 2.0 * W.total))
+                                  zero_grad=True), 0.0, 30.0 * W.total, 30.0 * W.total))
     fams, detail = {}, {}
-    for fam, name, call, fl, by in rec:
+    for fam, name, call, fl, by, by2 in rec:
         call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -192,45 +217,64 @@ def kernel_rooflines(trainer, reps=5):
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
-        a = fams.setdefault(fam, [0, 0.0, 0.0, 0.0])
-        a[0] += 1; a[1] += t; a[2] += fl; a[3] += by
+        a = fams.setdefault(fam, [0, 0.0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += t; a[2] += fl; a[3] += by; a[4] += by2
         d = detail.setdefault(fam, {}).setdefault(name, [0, 0.0, 0.0])
         d[0] += 1; d[1] += t; d[2] += fl
     ridge = PEAK_BF16 / PEAK_HBM
     kernels = {
-        "gemm": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv fwd + dgrad outside the fused blocks) + "
-                "wgrad_group_kernel / gemm_group_kernel (every weight gradient)",
+        "wgrad": "wgrad_group_kernel (every weight + bias gradient of a stage in one grouped launch; gemm_group_kernel for "
+                 "shapes without a large tile)",
+        "gemm": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv forward and data gradient outside the fused blocks)",
         "swin96_fwd": "swin96_fwd_kernel (whole C=96 Swin block, forward)", "swin96_bwd": "swin96_bwd_kernel",
         "swinw_fwd": "swinw_fwd_kernel<C,G> (whole C=192/384 Swin block, forward)", "swinw_bwd": "swinw_bwd_kernel<C,G>",
         "adamw": "adamw_kernel (fp32 master + moments + bf16 shadow, 30 B / parameter)"}
     out = []
-    for fam, (n, t, fl, by) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
+    for fam, (n, t, fl, by, by2) in fams.items():
         ai = fl / by
         bound = "mfma" if ai >= ridge else "hbm"
-        tf, tb = fl / t / 1e12, by / t / 1e12
-        traffic = _pmc_traffic(fam)
-        e = {"kernel": kernels[fam], "bound": bound,
-             "achieved": round(tf if bound == "mfma" else tb * 1e3, 2), "peak": PEAK_BF16 / 1e12 if bound == "mfma" else PEAK_HBM / 1e9,
-             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-             "frac": round((tf * 1e12 / PEAK_BF16) if bound == "mfma" else (tb * 1e12 / PEAK_HBM), 4),
-             "traffic": traffic, "timing": f"isolated: mean of {reps} back-to-back launches per recorded call, HIP events",
-             "launches_per_step": n, "ms_per_step": round(t * 1e3, 3), "mean_launch_us": round(t / n * 1e6, 2),
-             "arithmetic_intensity_flop_per_byte": round(ai, 1), "algorithmic_bytes_per_launch": round(by / n),
-             "flops_per_launch": round(fl / n), "frac_mfma": round(tf * 1e12 / PEAK_BF16, 4),
-             "frac_hbm_algorithmic": round(tb * 1e12 / PEAK_HBM, 4),
-             "frac_hbm_of_traffic": round(traffic / (t / n) / PEAK_HBM, 4) if traffic else None}
         ins = _instep(fam)
-        if ins:     # the same family inside the traced step (other kernels running beside it): the honest, lower figure
-            ti = ins["mean_launch_us"] * 1e-6
-            e["in_step"] = {"mean_launch_us": round(ins["mean_launch_us"], 2), "launches_per_step": round(ins["launches_per_step"], 1),
-                            "frac_hbm_algorithmic": round(by / n / ti / PEAK_HBM, 4), "frac_mfma": round(fl / n / ti / PEAK_BF16, 4),
-                            "source": "profiles/instep_durations.json (rocprofv3 --kernel-trace of this command)"}
-        if fam == "gemm":
-            e["by_kernel"] = {k: {"launches": c, "avg_us": round(tt / c * 1e6, 2), "tflops": round(f / tt / 1e12, 1)}
-                              for k, (c, tt, f) in sorted(detail[fam].items(), key=lambda kv: -kv[1][1])}
+        t_iso = t / n
+        t_use = ins["mean_launch_us"] * 1e-6 if ins else t_iso
+        n_step = ins["launches_per_step"] if ins else n
+        fpl, bpl, b2pl = fl / n, by / n, by2 / n
+        traffic = _pmc_traffic(fam)
+        ach = fpl / t_use / 1e12 if bound == "mfma" else bpl / t_use / 1e9
+        peak = PEAK_BF16 / 1e12 if bound == "mfma" else PEAK_HBM / 1e9
+        e = {"kernel": kernels[fam], "bound": bound, "achieved": round(ach, 2), "peak": peak,
+             "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
+             "timing": ("in-step: mean launch duration inside the traced step, profiles/instep_durations.json (rocprofv3 "
+                        "--kernel-trace of this command, source stamp matches)") if ins else
+                       (f"isolated (live): mean of {reps} back-to-back launches per recorded call, HIP events; the committed "
+                        "trace was measured on other kernel sources"),
+             "mean_launch_us": round(t_use * 1e6, 2), "launches_per_step": round(n_step, 1),
+             "us_per_step": round(t_use * n_step * 1e6, 1),
+             "arithmetic_intensity_flop_per_byte": round(ai, 1), "algorithmic_bytes_per_launch": round(bpl),
+             "flops_per_launch": round(fpl), "frac_mfma": round(fpl / t_use / PEAK_BF16, 4),
+             "frac_hbm_algorithmic": round(bpl / t_use / PEAK_HBM, 4),
+             "traffic_over_algorithmic": round(traffic / bpl, 2) if traffic else None,
+             "frac_hbm_of_traffic": round(traffic / t_use / PEAK_HBM, 4) if traffic else None,
+             "mfma_util_counter": _mfma_counter(fam),
+             "isolated": {"mean_launch_us": round(t_iso * 1e6, 2), "launches": n,
+                          "frac_hbm_algorithmic": round(bpl / t_iso / PEAK_HBM, 4), "frac_mfma": round(fpl / t_iso / PEAK_BF16, 4),
+                          "timing": f"live, this run: mean of {reps} back-to-back launches per recorded call, HIP events"}}
+        if by2 != by:
+            e["bytes_with_saved_activations" if fam.startswith("swin") else "bytes_with_splitk_slabs"] = round(b2pl)
+            e["frac_with_saved_activations" if fam.startswith("swin") else "frac_with_splitk_slabs"] = round(b2pl / t_use / PEAK_HBM, 4)
+        if fam in ("gemm", "wgrad"):
+            e["by_kernel_isolated"] = {k: {"launches": c, "avg_us": round(tt / c * 1e6, 2), "tflops": round(f / tt / 1e12, 1)}
+                                       for k, (c, tt, f) in sorted(detail[fam].items(), key=lambda kv: -kv[1][1])}
         out.append(e)
-    top = dict(out[0])
-    top["others"] = out[1:]
+    fold = _instep("fold")
+    if fold:      # the launches that fold the slabs + partial rows (no FLOPs, design traffic only): listed for the time they take
+        out.append({"kernel": "reduce_rows_multi_kernel (folds of split-K slabs and per-workgroup partial rows)", "bound": "hbm",
+                    "mean_launch_us": round(fold["mean_launch_us"], 2), "launches_per_step": round(fold["launches_per_step"], 1),
+                    "us_per_step": round(fold["mean_launch_us"] * fold["launches_per_step"], 1), "traffic": _pmc_traffic("fold"),
+                    "frac": None, "algorithmic_bytes_per_launch": 0, "timing": "in-step (profiles/instep_durations.json)"})
+    out.sort(key=lambda e: -e["us_per_step"])
+    k = next(i for i, e in enumerate(out) if e.get("frac") is not None)
+    top = dict(out.pop(k))
+    top["others"] = out
     return top
 
 
@@ -487,7 +531,7 @@ def secondary_batch64(args, device, steps=30, warmup=15, attn_fp8=False):
                      ("fp8 MFMA attention scores, bf16 elsewhere)" if attn_fp8 else "bf16)"), "value": round(64 * steps / dt, 2),
            "unit": "range-images/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
            "step_mfma_frac": round(64 * steps / dt * FLOP_FWD_BWD_PER_IMG / PEAK_BF16, 5),
-           "step_hbm_frac_oplevel": round(64 * steps / dt * 3 * BYTES_FWD_OPLEVEL_PER_IMG / PEAK_HBM, 5)}
+           "step_oplevel_bytes_convention_over_hbm_peak": round(64 * steps / dt * 3 * BYTES_FWD_OPLEVEL_PER_IMG / PEAK_HBM, 5)}
     del tr, model
     torch.cuda.empty_cache()
     return res
@@ -612,8 +656,9 @@ def main():
            "final_loss": round(loss_val, 6),
            "step_mfma_frac": round(value * FLOP_FWD_BWD_PER_IMG / world / PEAK_BF16, 5)
            if args.model == "tulip_base" and tuple(args.img) == (16, 1024) else None,
-           # SURVEY.md 8(d) op-level convention: 3 x 245 MB per image (forward op traffic x3 for training)
-           "step_hbm_frac_oplevel": round(value * 3 * BYTES_FWD_OPLEVEL_PER_IMG / world / PEAK_HBM, 5)
+           # NOT an achieved bandwidth: SURVEY.md 8(d)'s op-level byte convention (3 x 245 MB per image: the unfused
+           # forward's op traffic x3 for training) over the step time -- bytes the fused kernels never move
+           "step_oplevel_bytes_convention_over_hbm_peak": round(value * 3 * BYTES_FWD_OPLEVEL_PER_IMG / world / PEAK_HBM, 5)
            if args.model == "tulip_base" and tuple(args.img) == (16, 1024) else None}
     out["tolerance"] = ("index ops bit-exact; loss within 1e-3 rel of the reference's fp32 forward; prediction inside the "
                         "reference's own bf16-autocast band (max 8e-3 abs); gradients <= 1.5e-2 rel L2 per tensor "

@@ -31,7 +31,13 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in ro
     assert ro["bound"] in ("hbm", "mfma") and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
     assert ro["traffic"] is None or ro["traffic"] > 0
-    assert len(ro["others"]) >= 4 and all("frac" in e and "in_step" in e for e in ro["others"])
+    # the dominant family leads; every family says where its duration comes from (the committed in-step trace when its
+    # source stamp matches the kernels that ran, the live isolated measurement otherwise) and carries the live one
+    assert len(ro["others"]) >= 5 and all("frac" in e and "timing" in e for e in ro["others"])
+    assert ro["timing"].startswith(("in-step", "isolated (live)")) and ro["isolated"]["mean_launch_us"] > 0
+    assert "wgrad_group_kernel" in ro["kernel"] or "gemm_kernel" in ro["kernel"]
+    assert ro["algorithmic_bytes_per_launch"] > 0 and "mfma_util_counter" in ro
+    assert "secondary_reference_loop" in d and d["secondary_reference_loop"]["grad_scale"] == 65536.0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb

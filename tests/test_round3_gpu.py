@@ -42,7 +42,7 @@ def test_kitti_b8_train_step_vs_oracle():
             u = torch.rand(2, B, generator=g)
             table[sp.slot:sp.slot + 2] = u
             du[sp.prefix] = u
-    assert len(du) == 13                       # every block but the first has a non-zero rate (tulip.py:409-410)
+    assert len(du) == 12                       # 14 blocks; rate 0 for encoder block 0 and its decoder twin (tulip.py:409-410,447)
     tr.inject_drop_u = table.to(DEV)
     tr.load_batch(lo.to(DEV), hi.to(DEV))
     p0 = W.flat.clone()

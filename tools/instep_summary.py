@@ -4,7 +4,7 @@ for `roofline.*.in_step` (stamped with the hash of the kernel sources, like prof
 usage: python tools/instep_summary.py trace.db out.json [skip=8]"""
 import json, os, re, sqlite3, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import kernel_source_stamp
+from bench import FAMILIES, kernel_source_stamp
 
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 8
@@ -13,9 +13,7 @@ clean = lambda n: re.sub(r"\(.*$", "", re.sub(r"\(anonymous namespace\)::|^void 
 rows = [(clean(n), s, e) for n, s, e in rows]
 ad = [i for i, r in enumerate(rows) if r[0].startswith("adamw_kernel")]
 steps = [rows[ad[k] + 1: ad[k + 1] + 1] for k in range(skip, len(ad) - 1)]
-FAM = {"gemm": ("gemm_kernel", "gemm_group_kernel", "wgrad_group_kernel"), "swin96_fwd": ("swin96_fwd_kernel",),
-       "swin96_bwd": ("swin96_bwd_kernel",), "swinw_fwd": ("swinw_fwd_kernel",), "swinw_bwd": ("swinw_bwd_kernel",),
-       "adamw": ("adamw_kernel",)}
+FAM = FAMILIES
 fams = {}
 for fam, pre in FAM.items():
     n = sum(1 for st in steps for r in st if r[0].startswith(pre))

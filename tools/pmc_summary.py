@@ -25,10 +25,8 @@ print(f"TOTAL over run: fetch {tot_f:.0f} MB (x2 corrected), write {tot_w:.0f} M
 if len(sys.argv) > 3:
     import json, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import kernel_source_stamp
-    FAM = {"gemm": ("gemm_kernel", "gemm_group_kernel", "wgrad_group_kernel"), "swin96_fwd": ("swin96_fwd_kernel",),
-           "swin96_bwd": ("swin96_bwd_kernel",), "swinw_fwd": ("swinw_fwd_kernel",), "swinw_bwd": ("swinw_bwd_kernel",),
-           "adamw": ("adamw_kernel",)}
+    from bench import FAMILIES, kernel_source_stamp
+    FAM = FAMILIES
     fams = {}
     for fam, pre in FAM.items():
         n = sum(v[0] for k, v in f.items() if k.startswith(pre))
