@@ -210,6 +210,21 @@ int tulip_tail_fwd(const uint16_t* xn, const uint16_t* We, const float* be, cons
 int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
                    uint16_t* dz, float* dwd_partials, int B, int H, int W, int E, const float* target,
                    const float* gscale_dev, float gscale, hipStream_t stream);
+/* The same backward WITHOUT the (B,16E,H,W) gradient tensor (100 MB at batch 8, written once and read twice): both
+ * consumers recompute it.  tulip_tail_bwd_dgrad (the chain): dxn[B*H*W][E] (bf16) = dz . We, the input of norm_up's
+ * backward (autograd of tulip.py:724-731), and the decoder_pred partial rows exactly as tulip_tail_bwd writes them.
+ * tulip_tail_wgrad (beside the chain): the expand conv's weight / bias gradient as tulip_tail_wgrad_splits(B,H,W,E) plain
+ * slabs slabs_w[split][16E*E], slabs_b[split][16E] (fold with tulip_reduce_rows_multi, stride 16E*E resp. 16E).
+ * dpred / target / gscale as in tulip_tail_bwd.  E % 16 == 0, E <= 128 (tulip_tail_fused_bwd_supported). */
+int tulip_tail_fused_bwd_supported(int E);
+int tulip_tail_bwd_dgrad(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
+                         uint16_t* dxn, float* dwd_partials, int B, int H, int W, int E, const float* target,
+                         const float* gscale_dev, float gscale, hipStream_t stream);
+int tulip_tail_wgrad_splits(int B, int H, int W, int E);
+int tulip_tail_wgrad(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
+                     float* slabs_w, float* slabs_b, int B, int H, int W, int E, const float* target,
+                     const float* gscale_dev, float gscale, hipStream_t stream);
+
 
 /* The non-default decoder alternates PatchExpanding (tulip.py:126-140, patch_unmerging=False; P = 2, Cn = C/2) and
  * FinalPatchExpanding (tulip.py:144-159, pixel_shuffle=False; P = upscale_factor, Cn = embed_dim):

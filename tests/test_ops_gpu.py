@@ -439,6 +439,69 @@ def test_tail_fwd_bwd(ops, B, H, W, E):
     close(dzf.t() @ xn.float(), sd["ps_head.conv_expand.0.weight"].grad.reshape(16 * E, E), 2e-2, 4e-3, "tail dWe")
 
 
+@pytest.mark.parametrize("B,H,W,E", [(2, 8, 64, 48), (1, 16, 256, 96), (1, 3, 24, 96), (3, 16, 64, 96), (1, 2, 8, 16)])
+@pytest.mark.parametrize("l1", [False, True])
+def test_tail_bwd_without_the_expand_gradient_tensor(ops, B, H, W, E, l1):
+    """tulip_tail_bwd_dgrad + tulip_tail_wgrad: the head backward with d(expand pre-activation) recomputed by both consumers
+    instead of written (100 MB at batch 8), against the oracle's autograd of ps_head_and_pred (tulip.py:724-731) -- with a
+    given upstream gradient and with the L1 gradient formed in-kernel from (pred, target); ragged token counts included."""
+    M = B * H * W
+    cfg = O.TulipConfig(img_size=(H, W * 4), target_img_size=(4 * H, 4 * W), embed_dim=E)
+    xn = bf(rnd(M, E))
+    We, be, wd = bf(rnd(16 * E, E, scale=0.1, seed=1)), rnd(16 * E, scale=0.1, seed=2), rnd(E, scale=0.2, seed=3)
+    sd = {"ps_head.conv_expand.0.weight": We.float().reshape(16 * E, E, 1, 1).requires_grad_(True),
+          "ps_head.conv_expand.0.bias": be.clone().requires_grad_(True),
+          "decoder_pred.weight": wd.reshape(1, E, 1, 1).clone().requires_grad_(True)}
+    xr = xn.float().reshape(B, H, W, E).requires_grad_(True)
+    ref = O.ps_head_and_pred(O._Prec(False), sd, cfg, xr)
+    pred = torch.empty(B, 1, 4 * H, 4 * W, device=DEV)
+    ops.tail_fwd(xn, We, be, wd, pred, B, H, W, E)
+    if l1:
+        target = rnd(B, 1, 4 * H, 4 * W, seed=8)
+        (3.0 * (ref - target).abs().mean()).backward()
+        kw = dict(target=target, gscale=3.0)
+        dsrc = pred
+    else:
+        dsrc = rnd(B, 1, 4 * H, 4 * W, seed=4)
+        ref.backward(dsrc)
+        kw = {}
+    assert ops.tail_fused_bwd_supported(E)
+    dxn = torch.full((M, E), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dpart = torch.full(((M + 31) // 32, 128), float("nan"), device=DEV)
+    ops.tail_bwd_dgrad(xn, We, be, wd, dsrc, dxn, dpart, B, H, W, E, **kw)
+    sp = ops.tail_wgrad_splits(B, H, W, E)
+    assert 1 <= sp <= (M + 31) // 32
+    sw = torch.full((sp, 16 * E * E), float("nan"), device=DEV)
+    sb = torch.full((sp, 16 * E), float("nan"), device=DEV)
+    ops.tail_wgrad(xn, We, be, wd, dsrc, sw, sb, B, H, W, E, **kw)
+    dwd = torch.zeros(E, device=DEV)
+    ops.reduce_rows2(dpart, 128, dwd, E, None, 0, None, 0, dpart.shape[0])
+    dWe, dbe = torch.zeros(16 * E * E, device=DEV), torch.zeros(16 * E, device=DEV)
+    ops.reduce_rows_multi([ops.reduce_region(sw, 16 * E * E, dWe, 16 * E * E, sp), ops.reduce_region(sb, 16 * E, dbe, 16 * E, sp)])
+    torch.cuda.synchronize()
+    scale = float(sd["ps_head.conv_expand.0.weight"].grad.abs().max())
+    close(dwd, sd["decoder_pred.weight"].grad.reshape(E), 1e-3, 1e-4 * max(1.0, float(dwd.abs().max())), "tail dwd")
+    # bf16 rounding of dz (as in the three-launch form) bounds these: relative to the largest entry of each tensor
+    for got, want, what in [(dxn.float(), xr.grad.reshape(M, E), "dxn"), (dWe.reshape(16 * E, E), sd["ps_head.conv_expand.0.weight"].grad.reshape(16 * E, E), "dWe"),
+                            (dbe, sd["ps_head.conv_expand.0.bias"].grad, "dbe")]:
+        assert torch.isfinite(got).all(), what
+        err = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        rl2 = ((got - want).norm() / want.norm()).item()
+        assert err <= 1e-2 and rl2 <= 6e-3, (what, err, rl2)
+    # and it is the same function as the dz-materialising form (tulip_tail_bwd + GEMMs), up to accumulation order
+    dz = torch.empty(M, 16 * E, dtype=torch.bfloat16, device=DEV)
+    dpart2 = torch.zeros_like(dpart)
+    ops.tail_bwd(xn, We, be, wd, dsrc, dz, dpart2, B, H, W, E, **kw)
+    torch.cuda.synchronize()
+    assert (dpart2 - dpart).abs().max().item() <= 2e-6 * max(dpart2.abs().max().item(), 1e-30)     # (dp 0.01) z vs dp (0.01 z)
+    dzf = dz.float()
+    # (the weight-gradient kernel rounds dz / decoder_pred.weight[c] to bf16 and applies the factor to the sums: same
+    # precision, different rounding points)
+    assert ((dzf.t() @ xn.float()).reshape(-1) - dWe).norm().item() <= 5e-3 * max(dWe.norm().item(), 1e-30) + 1e-12
+    assert (dzf.sum(0) - dbe).norm().item() <= 5e-3 * max(dbe.norm().item(), 1e-30) + 1e-12
+    assert ((dzf @ We.float()) - dxn.float()).abs().max().item() <= 1e-2 * max(dxn.float().abs().max().item(), 1e-30)
+
+
 # ------------------------------------------------------------------ loss
 @pytest.mark.parametrize("log_transform", [True, False])
 def test_l1_loss(ops, log_transform):

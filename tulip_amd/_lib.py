@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtulip_hip.so")
+LIB_PATH = os.environ.get("TULIP_HIP_LIB") or os.path.join(_PKG, "libtulip_hip.so")   # (TULIP_HIP_LIB: dev, A/B builds)
 
 P, I, F, L, D = c_void_p, c_int, c_float, c_int64, c_double
 
@@ -91,6 +91,10 @@ SIGNATURES = {
     "tulip_cast_bf16_f32": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],
     "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
+    "tulip_tail_fused_bwd_supported": [I],
+    "tulip_tail_bwd_dgrad": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
+    "tulip_tail_wgrad_splits": [I, I, I, I],
+    "tulip_tail_wgrad": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
     "tulip_expand_norm_fwd": [P, P, P, P, I, P, P, P, P, I, I, I, I, I, F, P],
     "tulip_expand_norm_bwd": [P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "tulip_expand_norm_bwd_partial_rows": [I, I, I, I],

@@ -98,6 +98,10 @@ class FlatParams:
         self.base32 = self.flat.data_ptr()
         self.base16 = self.shadow.data_ptr()
         self.shadow_dirty = True
+        # the bf16 shadow is current but the fragment-major copies of the fused wide blocks are not: a Trainer rewrites them
+        # at the START of its next step, beside the head of the forward (Trainer.pack_at_step_start); every other consumer of
+        # the copies (run_forward outside a Trainer step, GraphedForward) refreshes them first when this is set
+        self.pack_dirty = False
 
     @staticmethod
     def _completion_order(model, named) -> List[str]:
@@ -192,6 +196,7 @@ class FlatParams:
         items, n = self._pk_joined[key]
         if n:
             ops.pack_bf16_multi(items, n)
+        self.pack_dirty = False
 
 
 class Plan:
@@ -485,6 +490,8 @@ class TulipEngine:
         return (self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
 
     fuse_splitk_ln = os.environ.get("TULIP_FUSE_SPLITK_LN", "1") != "0"
+    fuse_tail_bwd = os.environ.get("TULIP_FUSE_TAIL_BWD", "1") != "0"      # head backward without the d(expand) tensor
+    _tail_fused = False
 
     def _unfused(self, sp: BlockSpec, B: int) -> bool:
         return not ((self.fuse_wide and self._fusable_wide(sp, B)) or (self.fuse_block96 and self._fusable96(sp)))
@@ -519,6 +526,8 @@ class TulipEngine:
         wide = self.fuse_wide and self._fusable_wide(sp, B)
         if wide or (self.fuse_block96 and self._fusable96(sp)):
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
+            if wide:
+                self._join_pack()                  # the fragment-major weight copies being rewritten beside the forward's head
             launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
             wf = W_.p16p if wide else W_.p16           # the wide kernel streams fragment-major copies of the weights
             # forward without a backward behind it (run_forward(with_loss=False): eval / MC-dropout inference): the kernels'
@@ -565,6 +574,26 @@ class TulipEngine:
                  bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], ldaux=C,
                  rowscale=self._ds(P, sp, 1), rows_per_sample=tok, out2=out_bf16, ldo2=C if out_bf16 is not None else 0)
 
+    _pack_event = None      # run_forward(pack_on_side=True): fork point of the weight-copy refresh
+    _pack_issued = False
+
+    def _issue_pack(self):
+        """The refresh of the fused wide blocks' fragment-major weight copies (FlatParams.refresh_transposes) on the side
+        stream, forked behind the forward's first kernel and enqueued only after the chain's next one (the graph executor
+        keeps a node's first-created successor on the node's queue, see defer_side)."""
+        if self._pack_event is not None and not self._pack_issued:
+            st = self._side_streams[0]
+            st.wait_event(self._pack_event)
+            with torch.cuda.stream(st):
+                self.params.refresh_transposes()
+            self._pack_issued = True
+
+    def _join_pack(self):
+        if self._pack_event is not None:
+            self._issue_pack()
+            torch.cuda.current_stream().wait_stream(self._side_streams[0])
+            self._pack_event = None
+
     def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin, out_bf16=None):
         """out_bf16: bf16 copy of the stage output, written by the last block's fc2 epilogue."""
         x = xin
@@ -575,6 +604,7 @@ class TulipEngine:
                      and nxt.H == sp.H and nxt.W == sp.W)
             self._block_fwd(P, sp, x, P[sp.prefix + ".out"], out_bf16 if k == len(specs) - 1 else None, ln1_done=ln1_done,
                             next_sp=nxt if chain else None)
+            self._issue_pack()                     # (no-op unless a weight-copy refresh is waiting for the chain's next kernel)
             ln1_done = chain
             x = P[sp.prefix + ".out"]
         return x
@@ -599,11 +629,17 @@ class TulipEngine:
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
-    def run_forward(self, P: Plan, with_loss: bool = True):
-        """TULIP.forward (tulip.py:702-737) on P.x_in / P.target -> P.pred, P.losses."""
+    def run_forward(self, P: Plan, with_loss: bool = True, pack_on_side: bool = False):
+        """TULIP.forward (tulip.py:702-737) on P.x_in / P.target -> P.pred, P.losses.
+        pack_on_side (Trainer): the fragment-major weight copies of the fused wide blocks are rewritten from the bf16
+        shadow beside the forward's first kernels (side stream, joined in front of the first wide block) instead of on
+        the chain behind AdamW."""
         m, W_ = self.model, self.params
         if W_.shadow_dirty:
             W_.refresh_shadow()
+        elif W_.pack_dirty and not pack_on_side:
+            W_.refresh_transposes()
+        self._pack_event, self._pack_issued = None, False
         self._no_save = not with_loss and self.infer_no_save
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
@@ -613,6 +649,9 @@ class TulipEngine:
                             m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
                             m.circular_padding, self.eps,
                             out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E)
+        if pack_on_side and W_.pk_active:
+            self._pack_event = torch.cuda.Event()
+            self._pack_event.record()
         # every encoder stage input is x_save[s]: its bf16 copy goes straight into the second half of the level's
         # concat buffer (tulip.py:715) from the kernel that produces it
         x = None
@@ -660,6 +699,7 @@ class TulipEngine:
             ops.expand_norm_fwd(P["tail.ey"], W_.p32(pre + ".norm.weight"), W_.p32(pre + ".norm.bias"), P["tail.emean"],
                                 P["tail.erstd"], B, H0, W0, r, E, self.eps, dotw=W_.p32("decoder_pred.weight"),
                                 pred=P.pred)
+        self._join_pack()                          # (a model without fused wide blocks never asked for the copies)
         if with_loss:
             ops.l1_loss_fwd(P.pred, P.target, P.partials, P.losses, P.pred.numel(), m.log_transform)
         P.generation += 1
@@ -753,6 +793,13 @@ class TulipEngine:
         else:
             fn()
 
+    def _side_first(self, fn):
+        """Like _side, but issued BEFORE the flush's fold launch (a kernel that produces slabs the folds read)."""
+        if self.overlap_wgrad:
+            self._pending.append(("p", fn))
+        else:
+            fn()
+
     def _fold(self, part, stride, out, n, rows, **kw):
         """Queue a fold of per-workgroup partial rows: out[i] += sum_r part[r*stride + i] (LayerNorm affine gradients,
         relative-position-bias gradients, ...).  Folds queued by one block leave in the same launch as the folds of
@@ -797,6 +844,8 @@ class TulipEngine:
         """Launch the queued side work on the current stream: weight gradients as grouped GEMMs (<= wgrad_group_max per launch), every
         fold in the launch that folds the slabs, other closures last."""
         pending = self._pending if pending is None else pending
+        for fn in [a for k, a in pending if k == "p"]:         # producers of slabs that this flush's fold launch consumes
+            fn()
         items = [a for k, a in pending if k == "w"]
         regions = list(self._carry) + [a for k, a in pending if k == "r"]
         self._carry = tuple(a for k, a in pending if k == "s")     # their dense sums are produced by THIS launch
@@ -1107,12 +1156,24 @@ class TulipEngine:
         gdw = G("decoder_pred.weight")
         if m.pixel_shuffle:
             tpart = P["tail.dwd_part"]
-            ops.tail_bwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
-                         W_.p32("decoder_pred.weight"), P.pred, P["tail.dz"], tpart, B, H0, W0, E, target=P.target,
-                         gscale_dev=gscale_dev, gscale=gscale)     # L1 backward (tulip.py:692-693) formed in-kernel
+            head_w, head_b = "ps_head.conv_expand.0.weight", "ps_head.conv_expand.0.bias"
+            targs = (P["tail.xn"], W_.p16(head_w), W_.p32(head_b), W_.p32("decoder_pred.weight"), P.pred)
+            tkw = dict(target=P.target, gscale_dev=gscale_dev, gscale=gscale)   # L1 backward (tulip.py:692-693) formed in-kernel
+            self._tail_fused = self.fuse_tail_bwd and ops.tail_fused_bwd_supported(E)
+            if self._tail_fused:
+                # d(expand pre-activation) -- 100 MB at batch 8 -- is never written: the chain's kernel goes straight to dxn,
+                # the side queue's kernel recomputes it channel-sliced for the expand conv's weight / bias gradient
+                ops.tail_bwd_dgrad(*targs, P["tail.dxn"], tpart, B, H0, W0, E, **tkw)
+                sp = ops.tail_wgrad_splits(B, H0, W0, E)
+                nw = 16 * E * E
+                slab = P.scratch("tail.wslab", sp * (nw + 16 * E))
+                self._side_first(lambda: ops.tail_wgrad(*targs, slab, slab + 4 * sp * nw, B, H0, W0, E, **tkw))
+                self._fold(slab, nw, G(head_w), nw, sp)
+                self._fold(slab + 4 * sp * nw, 16 * E, G(head_b), 16 * E, sp)
+            else:
+                ops.tail_bwd(*targs, P["tail.dz"], tpart, B, H0, W0, E, **tkw)
+                self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G(head_w), G(head_b))
             self._fold(tpart, 128, gdw, E, (M0 + 31) // 32)
-            head_w = "ps_head.conv_expand.0.weight"
-            self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G(head_w), G("ps_head.conv_expand.0.bias"))
         else:
             # FinalPatchExpanding backward: d(pred) (L1, tulip.py:692-693) -> decoder_pred / LayerNorm backward per fine
             # token -> tail.dz = d(Linear output) in the Linear's layout
@@ -1129,8 +1190,9 @@ class TulipEngine:
             self._fold(part + 8 * E, 3 * E, gdw, E, R)
             head_w = pre + ".expand.weight"
             self._wgrad(P["tail.dz"], 16 * E, P["tail.xn"], E, 16 * E, E, M0, G(head_w))
-        self._gemm(P["tail.dz"], W_.p16(head_w), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
-                 epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
+        if not (m.pixel_shuffle and self._tail_fused):
+            self._gemm(P["tail.dz"], W_.p16(head_w), M0, E, 16 * E, lda=16 * E, ldb=E, b_trans=True,
+                     epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
         self._ln_bwd(P, P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx, M0,

@@ -42,6 +42,8 @@ class GraphedForward:
             self.P.x_in.copy_(x.reshape(self.P.x_in.shape), non_blocking=True)
         if self.eng.params.shadow_dirty:
             self.eng.params.refresh_shadow()              # outside the graph: weights changed since capture
+        elif self.eng.params.pack_dirty:
+            self.eng.params.refresh_transposes()          # a Trainer stepped: its copies of the wide blocks' weights are due
         if self._graph is None:
             self._forward()                               # load kernels / size lazy buffers outside capture
             torch.cuda.synchronize()

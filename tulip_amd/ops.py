@@ -202,6 +202,26 @@ def tail_bwd(xn, We, be, wd, dpred, dz, dwd, B, H, W, E, target=None, gscale_dev
                                      _p(target), _p(gscale_dev), float(gscale), _stream()), "tulip_tail_bwd")
 
 
+def tail_fused_bwd_supported(E):
+    return bool(_lib.load().tulip_tail_fused_bwd_supported(int(E)))
+
+
+def tail_bwd_dgrad(xn, We, be, wd, dpred, dxn, dwd, B, H, W, E, target=None, gscale_dev=None, gscale=1.0):
+    """Head backward on the chain: dxn (bf16 [M][E]) and the decoder_pred partial rows; d(expand) is never written."""
+    check(_lib.load().tulip_tail_bwd_dgrad(_p(xn), _p(We), _p(be), _p(wd), _p(dpred), _p(dxn), _p(dwd), B, H, W, E,
+                                           _p(target), _p(gscale_dev), float(gscale), _stream()), "tulip_tail_bwd_dgrad")
+
+
+def tail_wgrad_splits(B, H, W, E):
+    return _lib.load().tulip_tail_wgrad_splits(B, H, W, E)
+
+
+def tail_wgrad(xn, We, be, wd, dpred, slabs_w, slabs_b, B, H, W, E, target=None, gscale_dev=None, gscale=1.0):
+    """Expand-conv weight / bias gradient of the head as token-split slabs, d(expand) recomputed channel-sliced."""
+    check(_lib.load().tulip_tail_wgrad(_p(xn), _p(We), _p(be), _p(wd), _p(dpred), _p(slabs_w), _p(slabs_b), B, H, W, E,
+                                       _p(target), _p(gscale_dev), float(gscale), _stream()), "tulip_tail_wgrad")
+
+
 def expand_norm_fwd(y, gamma, beta, mean, rstd, B, H, W, P, Cn, eps, out_bf16=None, ld=0, dotw=None, pred=None):
     """PatchExpanding / FinalPatchExpanding rearrange + LayerNorm (+ decoder_pred dot), see include/tulip_hip.h."""
     check(_lib.load().tulip_expand_norm_fwd(_p(y), _p(gamma), _p(beta), _p(out_bf16), ld, _p(dotw), _p(pred), _p(mean),

@@ -94,6 +94,9 @@ class Trainer:
         # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
         # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
+        # the fragment-major weight copies of the fused wide blocks (one ~25-us launch) are rewritten at the START of the
+        # next step, beside the forward's first kernels, instead of on the chain behind AdamW (TULIP_PACK_AT_START=0: old)
+        self.pack_at_step_start = os.environ.get("TULIP_PACK_AT_START", "1") != "0"
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
         # set before the first step (the choice is baked into the captured graphs)
         self.inject_drop_u: Optional[torch.Tensor] = None
@@ -132,7 +135,7 @@ class Trainer:
         eng, P = self.eng, self.P
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training, self.inject_drop_u)
-        eng.run_forward(P)
+        eng.run_forward(P, pack_on_side=self.pack_at_step_start)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None)
 
@@ -167,7 +170,8 @@ class Trainer:
     def _finish_buckets(self):
         if self.bucket_adamw:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
-            self.eng.params.refresh_transposes()
+            if not self.pack_at_step_start:
+                self.eng.params.refresh_transposes()
         else:
             self.bucketer.wait_all()
             self._adamw()
@@ -180,7 +184,8 @@ class Trainer:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
         ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=True)
-        W.refresh_transposes()
+        if not self.pack_at_step_start:
+            W.refresh_transposes()
 
     # ------------------------------------------------------------------ checkpoint (misc.save_model / load_model keep
     # {'model', 'optimizer', 'epoch', ...}: this is the 'optimizer' entry of the fused AdamW)
@@ -285,6 +290,12 @@ class Trainer:
         update = self.micro % self.accum_iter == 0
         if update:
             self._set_hyper()
+        if update and self.pack_at_step_start:
+            # after this step the bf16 shadow is new and the wide blocks' copies are not (this Trainer's next step rewrites
+            # them first thing; any other forward in between must, too)
+            mark_pack_dirty = True
+        else:
+            mark_pack_dirty = False
         if self.eng.params.shadow_dirty:
             # parameters were written from outside (load_state_dict / misc.load_model after construction, a foreign
             # optimizer): the bf16 GEMM operands are rebuilt here, outside the captured graphs
@@ -298,6 +309,7 @@ class Trainer:
                     self._adamw()
             else:
                 self._fwd_bwd(lambda tag: None, update=False)
+            self.eng.params.pack_dirty = self.eng.params.pack_dirty or mark_pack_dirty
             return self.P.losses
         if self._segments is None:
             # load every kernel once outside capture, without touching parameters, optimizer state, the gradients of an
@@ -326,6 +338,7 @@ class Trainer:
                     self._bucket_done(tag)
         if update and self.bucket_adamw:
             self._finish_buckets()
+        self.eng.params.pack_dirty = self.eng.params.pack_dirty or mark_pack_dirty
         return self.P.losses
 
 
