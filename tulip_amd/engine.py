@@ -724,6 +724,21 @@ class TulipEngine:
     wgrad_ctas = 0                                   # 0: WGRAD_BIG_CTAS
     WGRAD_DDP_CTAS = int(os.environ.get("TULIP_WGRAD_DDP_CTAS", "192"))
 
+    # Workgroups of a grouped large-tile launch as a function of the tiles it holds ("min_tiles:workgroups;..."): a stage
+    # with many tiles (C = 384: ~112) fills half the chip without any token split -- no slabs, nothing to fold -- and the
+    # step time is flat in the workgroup count (profiles/README.md), so the split-K traffic is what decides.  Default
+    # (round 3 sweep, same box, batch 8 / 64 ms per step): all 256: 2.2755 / 9.691; this map: 2.2784 / 9.717 with the slabs
+    # of a step at 70 MB instead of 220 MB; "100:112;20:28" (no split at C = 192 either): 2.360 / 10.16.
+    wgrad_ctas_map = tuple(sorted((tuple(int(v) for v in e.split(":")) for e in
+                                   os.environ.get("TULIP_WGRAD_CTAS_MAP", "100:112;20:128;5:128").split(";") if e), reverse=True))
+
+    def _group_ctas(self, group_tiles: int) -> int:
+        if not self.wgrad_ctas:                      # (a DDP run pins the count: RCCL's channels hold CUs)
+            for min_tiles, ctas in self.wgrad_ctas_map:
+                if group_tiles >= min_tiles:
+                    return ctas
+        return self.wgrad_ctas
+
     @classmethod
     def _splits(cls, Mout: int, Nout: int, K: int, group_tiles: int = 0, ctas: int = 0) -> int:
         if group_tiles:  # large tiles (192 x 192 / 384 x 96 / 96 x 384), `group_tiles` of them per split in this launch
@@ -867,7 +882,7 @@ class TulipEngine:
             group_tiles = sum(ops.wgrad_tiles(a[4], a[5]) for a in cand) if big else 0
             while items and len(grp) < gmax:
                 dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias = items[0]
-                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles, ctas=self.wgrad_ctas)
+                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles, ctas=self._group_ctas(group_tiles))
                 need = (Nw * Kw + Nw) * sp * 4 if sp > 1 else 0
                 if grp and used + need > ws_bytes:
                     break
