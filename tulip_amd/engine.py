@@ -861,6 +861,7 @@ class TulipEngine:
         pending = self._pending if pending is None else pending
         for fn in [a for k, a in pending if k == "p"]:         # producers of slabs that this flush's fold launch consumes
             fn()
+        full_chip = any(k == "c" for k, _ in pending)          # the backward's last stage: nothing left to run beside it
         items = [a for k, a in pending if k == "w"]
         regions = list(self._carry) + [a for k, a in pending if k == "r"]
         self._carry = tuple(a for k, a in pending if k == "s")     # their dense sums are produced by THIS launch
@@ -882,7 +883,7 @@ class TulipEngine:
             group_tiles = sum(ops.wgrad_tiles(a[4], a[5]) for a in cand) if big else 0
             while items and len(grp) < gmax:
                 dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias = items[0]
-                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles, ctas=self._group_ctas(group_tiles))
+                sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles, ctas=self.wgrad_ctas if full_chip else self._group_ctas(group_tiles))
                 need = (Nw * Kw + Nw) * sp * 4 if sp > 1 else 0
                 if grp and used + need > ws_bytes:
                     break
@@ -1273,6 +1274,10 @@ class TulipEngine:
                 self._ln_bwd(P, dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"], W_.p32(pre + ".norm.weight"),
                              None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, G(pre + ".norm.weight"), G(pre + ".norm.bias"),
                              pre, merge=True, H=Hp, W=Wp, cast=self._mlp_cast(P, self.enc_blocks[s - 1][-1]))
+            if s == 0:
+                # this stage's weight gradients are what the step waits for behind the chain's last kernels: one full round
+                # of the chip (the tile-count map trades duration for slab traffic, which only pays while the chain runs)
+                self._pending.append(("c", None))
             hook(f"enc{s}")
         kw = 8 if m.circular_padding else m.patch_size[1]
         # patch-embed parameter gradients: partial rows laid out like the flat gradient slice
