@@ -119,11 +119,11 @@ def _instep(family):
     return _stamped("instep_durations.json", family)
 
 
-def _mfma_counter(family):
-    """MFMA utilisation from counters (profiles/pmc_mfma.json, tools/mfma_summary.py: SQ_VALU_MFMA_BUSY_CYCLES over
-    GRBM_GUI_ACTIVE x 1024 SIMDs, its own --pmc pass)."""
+def _mfma_counter(family, t_launch):
+    """MFMA utilisation from counters: SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/pmc_mfma.json, tools/mfma_summary.py, its
+    own --pmc pass; busy cycles summed over the 1024 SIMDs) over 1024 x the family's launch duration x 2.4 GHz."""
     e = _stamped("pmc_mfma.json", family)
-    return round(e["mfma_util"], 4) if e else None
+    return round(e["mfma_busy_cycles_per_launch"] / (1024 * t_launch * 2.4e9), 4) if e else None
 
 
 def kernel_rooflines(trainer, reps=5):
@@ -254,7 +254,7 @@ def kernel_rooflines(trainer, reps=5):
              "frac_hbm_algorithmic": round(bpl / t_use / PEAK_HBM, 4),
              "traffic_over_algorithmic": round(traffic / bpl, 2) if traffic else None,
              "frac_hbm_of_traffic": round(traffic / t_use / PEAK_HBM, 4) if traffic else None,
-             "mfma_util_counter": _mfma_counter(fam),
+             "mfma_util_counter": _mfma_counter(fam, t_use),
              "isolated": {"mean_launch_us": round(t_iso * 1e6, 2), "launches": n,
                           "frac_hbm_algorithmic": round(bpl / t_iso / PEAK_HBM, 4), "frac_mfma": round(fpl / t_iso / PEAK_BF16, 4),
                           "timing": f"live, this run: mean of {reps} back-to-back launches per recorded call, HIP events"}}

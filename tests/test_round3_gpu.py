@@ -193,3 +193,54 @@ def test_graphed_forward_after_a_trainer_of_another_batch_size_sees_fresh_weight
         ref = m(lo8.to(DEV), hi8.to(DEV), mc_drop=True)       # autograd_forward refreshes every copy before it runs
     torch.cuda.synchronize()
     assert torch.equal(got, ref), (got - ref).abs().max().item()
+
+
+def test_torch_adamw_state_round_trip_and_continuation():
+    """a run of the reference's optimizer (torch.optim.AdamW over timm-style groups, main:282-283) continues
+    with the fused step -- Trainer.import_torch_optimizer -- and back (export_torch_optimizer): two steps with torch.optim.AdamW
+    through the module's own forward / backward, then one more step either way must land on the same parameters."""
+    from tulip_amd.trainer import Trainer
+    cfg = O.tiny_config(drop_path_rate=0.0)
+    sd = O.key_seeded_state_dict(cfg, seed=3)
+    lo, hi = O.synthetic_batch(cfg, 4, seed=77)
+    lo, hi = lo.to(DEV), hi.to(DEV)
+
+    def groups(m):
+        return [{"params": [p for p in m.parameters() if p.ndim <= 1], "weight_decay": 0.0},
+                {"params": [p for p in m.parameters() if p.ndim > 1], "weight_decay": 0.01}]
+
+    def torch_step(m, opt):
+        opt.zero_grad()
+        _, loss, _ = m(lo, hi)
+        loss.backward()
+        opt.step()
+
+    ma = build(cfg, sd, train=True)
+    oa = torch.optim.AdamW(groups(ma), lr=5e-4, betas=(0.9, 0.95))
+    for _ in range(2):
+        torch_step(ma, oa)
+    mb = build(cfg, {k: v.clone() for k, v in ma.state_dict().items()}, train=True)
+    ob = torch.optim.AdamW(groups(mb), lr=5e-4, betas=(0.9, 0.95))
+    ob.load_state_dict(oa.state_dict())              # what misc.load_model does with a reference checkpoint (misc.py:386-390)
+    tr = Trainer(mb, 4, lr=1.0, betas=(0.5, 0.5), weight_decay=0.3)          # every hyper-parameter must come from the import
+    tr.import_torch_optimizer(ob)
+    assert tr.t == 2 and tr.lr == 5e-4 and tuple(tr.betas) == (0.9, 0.95) and tr.wd == 0.01
+    tr.load_batch(lo, hi)
+    tr.step()
+    torch_step(ma, oa)                               # the uninterrupted reference-optimizer run
+    torch.cuda.synchronize()
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    worst = max((pa[n] - pb[n]).abs().max().item() for n in pa)
+    print(f"step 3 with the fused AdamW after import vs torch.optim.AdamW: max |d param| {worst:.3e} ({worst / 5e-4:.4f} lr)")
+    assert worst <= 0.1 * 5e-4           # the two forwards / backwards are the same kernels: only the AdamW arithmetic differs
+    # and back: the exported state is the imported one advanced by a step
+    oc = torch.optim.AdamW(groups(mb), lr=1.0)
+    tr.export_torch_optimizer(oc)
+    sa, sc = oa.state_dict(), oc.state_dict()
+    assert [g["params"] for g in sa["param_groups"]] == [g["params"] for g in sc["param_groups"]]
+    assert sc["param_groups"][0]["lr"] == 5e-4 and tuple(sc["param_groups"][0]["betas"]) == (0.9, 0.95)
+    for k in sa["state"]:
+        assert float(sc["state"][k]["step"]) == float(sa["state"][k]["step"]) == 3.0
+        for f in ("exp_avg", "exp_avg_sq"):
+            a, c = sa["state"][k][f], sc["state"][k][f]
+            assert (a - c).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12) + 1e-12, (k, f)

@@ -196,7 +196,10 @@ class Trainer:
                 "weight_decay": self.wd, "accum_iter": self.accum_iter,
                 "exp_avg": {n: cut(self.m, n) for n in W.names}, "exp_avg_sq": {n: cut(self.v, n) for n in W.names},
                 "grad": {n: cut(self.g, n) for n in W.names} if self.micro % self.accum_iter else None,
-                "drop_seed": int(self.eng._drop_seed), "drop_counter": int(self.eng._drop_counter.item())}
+                "drop_seed": int(self.eng._drop_seed), "drop_counter": int(self.eng._drop_counter.item()),
+                # the DropPath stream is seeded per rank (main_lidar_upsampling.py:155: args.seed + rank); a checkpoint is
+                # written by rank 0 and read by every rank, which re-derives its own seed from the saver's
+                "rank": dist.get_rank(self.process_group) if dist.is_initialized() else 0}
 
     def load_state_dict(self, sd: dict) -> None:
         W = self.eng.params
@@ -213,11 +216,65 @@ class Trainer:
                 put(self.g, n, sd["grad"][n])
         self.t, self.micro, self.lr = int(sd["step"]), int(sd["micro"]), float(sd["lr"])
         self.betas, self.eps, self.wd = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
-        if int(sd["drop_seed"]) != int(self.eng._drop_seed):
-            self.eng._drop_seed = int(sd["drop_seed"])
+        my_rank = dist.get_rank(self.process_group) if dist.is_initialized() else 0
+        seed = int(sd["drop_seed"]) - int(sd.get("rank", 0)) + my_rank      # ranks stay decorrelated after a resume
+        if seed != int(self.eng._drop_seed):
+            self.eng._drop_seed = seed
             self._segments = None          # the seed is a launch argument baked into the captured graphs: re-capture
         self.eng._drop_counter.fill_(int(sd["drop_counter"]))
         W.shadow_dirty = True          # the model's own load_state_dict normally precedes this; refresh either way
+
+    # ------------------------------------------------------------------ torch.optim.AdamW <-> fused AdamW state
+    def _param_names_by_ptr(self):
+        W = self.eng.params
+        return {W.base32 + 4 * W.offset[n]: n for n in W.names}
+
+    def import_torch_optimizer(self, optimizer: "torch.optim.Optimizer") -> None:
+        """Continue a run of the reference's optimizer (main_lidar_upsampling.py:283: torch.optim.AdamW over the module's
+        parameters; a reference checkpoint's 'optimizer' entry after `optimizer.load_state_dict`, misc.py:386-390) with the
+        fused step: exp_avg / exp_avg_sq / step of every parameter, lr, betas, eps and the weight decay of the decaying
+        group.  Parameters are matched by storage (the module's parameters are views of the flat buffer)."""
+        W, by_ptr = self.eng.params, self._param_names_by_ptr()
+        seen, steps, wds = set(), set(), set()
+        for grp in optimizer.param_groups:
+            for p in grp["params"]:
+                n = by_ptr.get(p.data_ptr())
+                if n is None:
+                    raise KeyError("optimizer holds a parameter that is not one of this model's (was the model moved?)")
+                st = optimizer.state.get(p, {})
+                sl = slice(W.offset[n], W.offset[n] + W.numel[n])
+                if st:
+                    self.m[sl].copy_(st["exp_avg"].reshape(-1).to(self.m.dtype))
+                    self.v[sl].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.dtype))
+                    steps.add(int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"]))
+                else:
+                    self.m[sl].zero_(); self.v[sl].zero_(); steps.add(0)
+                if p.ndim > 1:
+                    wds.add(float(grp["weight_decay"]))
+                elif float(grp["weight_decay"]) != 0.0:
+                    raise ValueError("the fused AdamW decays ndim > 1 parameters only (timm's grouping, main:282)")
+                seen.add(n)
+        if seen != set(W.names) or len(steps) != 1 or len(wds) > 1:
+            raise ValueError(f"cannot import: {len(W.names) - len(seen)} parameters missing, steps {sorted(steps)}, decays {sorted(wds)}")
+        g0 = optimizer.param_groups[0]
+        self.t, self.lr, self.betas, self.eps = steps.pop(), float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])
+        if wds:
+            self.wd = wds.pop()
+        self.g.zero_()
+        self.micro = 0
+        self.eng.params.shadow_dirty = True
+
+    def export_torch_optimizer(self, optimizer: "torch.optim.Optimizer") -> None:
+        """The reverse: write the fused optimizer's moments and step count into a torch.optim.AdamW built over the module's
+        parameters (so that `optimizer.state_dict()` is what misc.save_model stores, misc.py:339-345)."""
+        W, by_ptr = self.eng.params, self._param_names_by_ptr()
+        for grp in optimizer.param_groups:
+            grp["lr"], grp["betas"], grp["eps"] = self.lr, tuple(self.betas), self.eps
+            for p in grp["params"]:
+                n = by_ptr[p.data_ptr()]
+                sl = slice(W.offset[n], W.offset[n] + W.numel[n])
+                optimizer.state[p] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[sl].view(W.shape[n]).clone(),
+                                      "exp_avg_sq": self.v[sl].view(W.shape[n]).clone()}
 
     # ------------------------------------------------------------------ graph capture
     def _capture(self, update: bool):
