@@ -220,6 +220,24 @@ int tulip_tail_fused_bwd_supported(int E);
 int tulip_tail_bwd_dgrad(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
                          uint16_t* dxn, float* dwd_partials, int B, int H, int W, int E, const float* target,
                          const float* gscale_dev, float gscale, hipStream_t stream);
+/* tulip_tail_bwd_dgrad with norm_up's backward (autograd of tulip.py:720) in its epilogue: instead of dxn it writes what
+ * tulip_layernorm_bwd would -- dx[B*H*W][E] (fp32, overwritten), optionally dx_bf16 = bf16(dx * cast_rowscale[token /
+ * cast_rows_per_sample]) and ceil(B*H*W/32) partial rows ln_partials[row][2E] = [dgamma | dbeta] (fold with
+ * tulip_reduce_rows_multi).  x / mean / rstd / gamma: the LayerNorm's input rows, saved statistics and weight. */
+int tulip_tail_bwd_dgrad_ln(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
+                            float* dwd_partials, int B, int H, int W, int E, const float* target, const float* gscale_dev,
+                            float gscale, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            float* dx, uint16_t* dx_bf16, const float* cast_rowscale, int cast_rows_per_sample,
+                            float* ln_partials, hipStream_t stream);
+/* tulip_tail_fwd with norm_up (tulip.py:720: LayerNorm(E) of the fp32 rows x, eps) in front -- xn / mean / rstd are written
+ * for the backward -- and, when loss_partials != NULL, the partial sums of forward_loss (tulip.py:690-700) behind it:
+ * loss_partials[2*wg] = sum |pred - target|, [2*wg+1] = sum |expm1(pred) - expm1(target)| (log_transform) over the
+ * workgroup's 32 tokens, wg < ceil(B*H*W/32); tulip_l1_loss_final folds them into losses[2] (mean over n elements). */
+int tulip_tail_fwd_ln(const float* x, const float* gamma, const float* beta, float eps, uint16_t* xn, float* mean,
+                      float* rstd, const uint16_t* We, const float* be, const float* wd, float* pred, const float* target,
+                      float* loss_partials, int log_transform, int B, int H, int W, int E, hipStream_t stream);
+int tulip_l1_loss_final(const float* partials, float* losses, int nblocks, int64_t n, int log_transform,
+                        hipStream_t stream);
 int tulip_tail_wgrad_splits(int B, int H, int W, int E);
 int tulip_tail_wgrad(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
                      float* slabs_w, float* slabs_b, int B, int H, int W, int E, const float* target,

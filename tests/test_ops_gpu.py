@@ -502,6 +502,78 @@ def test_tail_bwd_without_the_expand_gradient_tensor(ops, B, H, W, E, l1):
     assert ((dzf @ We.float()) - dxn.float()).abs().max().item() <= 1e-2 * max(dxn.float().abs().max().item(), 1e-30)
 
 
+@pytest.mark.parametrize("B,H,W,E", [(2, 8, 64, 48), (1, 16, 256, 96), (1, 3, 24, 96)])
+@pytest.mark.parametrize("log_transform", [True, False])
+def test_tail_with_norm_up_and_loss_in_the_same_launches(ops, B, H, W, E, log_transform):
+    """tulip_tail_fwd_ln / tulip_tail_bwd_dgrad_ln: norm_up (tulip.py:720) in front of the fused head, forward_loss's partial
+    sums (tulip.py:690-700) behind it, and norm_up's backward in the epilogue of the head's data gradient -- against the
+    oracle's autograd of LayerNorm -> ps_head_and_pred -> forward_loss, and bit for bit against the separate launches for the
+    tensors both forms write."""
+    M = B * H * W
+    cfg = O.TulipConfig(img_size=(H, W * 4), target_img_size=(4 * H, 4 * W), embed_dim=E, log_transform=log_transform)
+    x = rnd(M, E, seed=11)
+    gam, bet = 1.0 + 0.1 * rnd(E, seed=12), 0.1 * rnd(E, seed=13)
+    We, be, wd = bf(rnd(16 * E, E, scale=0.1, seed=1)), rnd(16 * E, scale=0.1, seed=2), rnd(E, scale=0.2, seed=3)
+    target = 0.3 * rnd(B, 1, 4 * H, 4 * W, seed=8)
+    eps = 1e-6
+    xn, mean, rstd = torch.empty(M, E, dtype=torch.bfloat16, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    pred = torch.empty(B, 1, 4 * H, 4 * W, device=DEV)
+    R = (M + 31) // 32
+    parts, losses = torch.full((2 * R,), float("nan"), device=DEV), torch.empty(2, device=DEV)
+    ops.tail_fwd_ln(x, gam, bet, eps, xn, mean, rstd, We, be, wd, pred, B, H, W, E, target=target, loss_partials=parts,
+                    log_transform=log_transform)
+    ops.l1_loss_final(parts, losses, R, pred.numel(), log_transform)
+    # the separate launches
+    xn2, mean2, rstd2 = torch.empty_like(xn), torch.empty_like(mean), torch.empty_like(rstd)
+    pred2, parts2, losses2 = torch.empty_like(pred), torch.zeros(2048, device=DEV), torch.empty(2, device=DEV)
+    ops.layernorm_fwd(x, gam, bet, xn2, mean2, rstd2, M, E, eps)
+    ops.tail_fwd(xn2, We, be, wd, pred2, B, H, W, E)
+    ops.l1_loss_fwd(pred2, target, parts2, losses2, pred2.numel(), log_transform)
+    torch.cuda.synchronize()
+    close(mean, mean2, 1e-5, 1e-6, "mean"); close(rstd, rstd2, 1e-5, 1e-6, "rstd")
+    assert (xn.float() - xn2.float()).abs().max().item() <= 2 ** -7 * xn2.float().abs().max().item()     # 1-ulp bf16 flips at most
+    assert (xn != xn2).float().mean().item() <= 2e-3
+    close(losses, losses2, 2e-4, 1e-7, "losses vs separate launches")
+    # oracle
+    sd = {"ps_head.conv_expand.0.weight": We.float().reshape(16 * E, E, 1, 1).requires_grad_(True),
+          "ps_head.conv_expand.0.bias": be.clone().requires_grad_(True),
+          "decoder_pred.weight": wd.reshape(1, E, 1, 1).clone().requires_grad_(True)}
+    xr = x.clone().requires_grad_(True)
+    g_, b_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    pr = O._Prec(True)
+    xnr = pr.r(O.layer_norm(xr, g_, b_, eps)).reshape(B, H, W, E)
+    ref = O.ps_head_and_pred(pr, sd, cfg, xnr)
+    loss, pix = O.forward_loss(cfg, ref, target)
+    close(pred, ref, 2e-3, 2e-3, "pred")
+    assert abs(losses[0].item() - loss.item()) <= 1e-3 * abs(loss.item())
+    assert abs(losses[1].item() - pix.item()) <= 2e-3 * abs(pix.item())
+    (2.0 * loss).backward()
+    # backward: L1 gradient formed in-kernel (gscale 2), LayerNorm backward in the epilogue
+    dx, dxb = torch.full((M, E), float("nan"), device=DEV), torch.full((M, E), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dpart, lnp = torch.full((R, 128), float("nan"), device=DEV), torch.full((R, 2 * E), float("nan"), device=DEV)
+    rows_per_sample = H * W
+    scale = (0.5 + torch.arange(B, device=DEV, dtype=torch.float32))
+    ops.tail_bwd_dgrad_ln(xn, We, be, wd, pred, dpart, B, H, W, E, x, mean, rstd, gam, dx, lnp, dx_bf16=dxb,
+                          cast_rowscale=scale, cast_rows_per_sample=rows_per_sample, target=target, gscale=2.0)
+    dgb = torch.zeros(2 * E, device=DEV)
+    ops.reduce_rows_multi([ops.reduce_region(lnp, 2 * E, dgb, 2 * E, R)])
+    torch.cuda.synchronize()
+    for got, want, what in [(dx, xr.grad, "dx"), (dgb[:E], g_.grad, "dgamma"), (dgb[E:], b_.grad, "dbeta")]:
+        assert torch.isfinite(got).all(), what
+        rl2 = ((got - want).norm() / want.norm()).item()
+        assert rl2 <= 1.5e-2, (what, rl2)
+    want_b = (dx.reshape(B, H * W, E) * scale[:, None, None]).reshape(M, E)
+    assert (dxb.float() - want_b).abs().max().item() <= 2 ** -7 * want_b.abs().max().item() + 1e-12
+    # ... and against the two-launch form (bf16 dxn between them): same up to that rounding
+    dxn = torch.empty(M, E, dtype=torch.bfloat16, device=DEV)
+    dpart2, dx2 = torch.zeros_like(dpart), torch.empty_like(dx)
+    ops.tail_bwd_dgrad(xn, We, be, wd, pred, dxn, dpart2, B, H, W, E, target=target, gscale=2.0)
+    ops.layernorm_bwd(dxn, x, mean, rstd, gam, None, dx2, M, E)
+    torch.cuda.synchronize()
+    assert torch.equal(dpart, dpart2)
+    assert ((dx - dx2).norm() / dx2.norm()).item() <= 5e-3
+
+
 # ------------------------------------------------------------------ loss
 @pytest.mark.parametrize("log_transform", [True, False])
 def test_l1_loss(ops, log_transform):

@@ -244,3 +244,26 @@ def test_torch_adamw_state_round_trip_and_continuation():
         for f in ("exp_avg", "exp_avg_sq"):
             a, c = sa["state"][k][f], sc["state"][k][f]
             assert (a - c).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12) + 1e-12, (k, f)
+
+
+def test_training_is_bit_reproducible_at_the_bench_configuration():
+    """Two Trainers from the same seed, 60 graph-replayed steps of the bench's configuration each: parameters and every
+    loss bit-identical.  (Round 3: the head's weight-gradient kernel returned a slightly different slab about once in 200
+    launches inside the step -- an MFMA read a freshly packed bf16 operand too early, `mfma_operand_fence` in csrc/common.h;
+    every reduction in the step is ordered, so any run-to-run difference is a bug of that kind.)"""
+    import argparse
+    import bench
+    from tulip_amd.trainer import Trainer
+    a = argparse.Namespace(model="tulip_base", img=[16, 1024], target=[64, 1024], batch=8)
+    res = []
+    for _ in range(2):
+        m = bench.make_model(a).to(DEV).train()
+        tr = Trainer(m, 8)
+        lo, hi = bench.synthetic(a, 0, torch.device(DEV))
+        tr.load_batch(lo, hi)
+        ls = torch.stack([tr.step().clone() for _ in range(60)])
+        torch.cuda.synchronize()
+        res.append((tr.eng.params.flat.clone(), ls.cpu()))
+        del tr, m
+    assert torch.equal(res[0][1], res[1][1]), "losses differ between two identical runs"
+    assert torch.equal(res[0][0], res[1][0]), "parameters differ between two identical runs"

@@ -93,6 +93,9 @@ SIGNATURES = {
     "tulip_tail_bwd": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
     "tulip_tail_fused_bwd_supported": [I],
     "tulip_tail_bwd_dgrad": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
+    "tulip_tail_bwd_dgrad_ln": [P, P, P, P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, P, P, I, P, P],
+    "tulip_tail_fwd_ln": [P, P, P, F, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "tulip_l1_loss_final": [P, P, I, L, I, P],
     "tulip_tail_wgrad_splits": [I, I, I, I],
     "tulip_tail_wgrad": [P, P, P, P, P, P, P, I, I, I, I, P, P, F, P],
     "tulip_expand_norm_fwd": [P, P, P, P, I, P, P, P, P, I, I, I, I, I, F, P],

@@ -39,6 +39,19 @@ __device__ __forceinline__ void warm_touch16(const void* gptr, void* lds_scratch
                                      (__attribute__((address_space(3))) void*)lds_scratch, 16, 0, 0);
 }
 
+// A bf16 MFMA operand that was JUST packed by vector-ALU instructions (v_cvt_pk_bf16_f32 behind an fma): pin 8 wait states
+// between the pack and the MFMA that reads it.  Measured on gfx950 / ROCm 7.2 (tools/det_tail_instep.py): without them the
+// head's weight-gradient kernel returned, about once in 200 launches inside the training step (never in isolation: it takes
+// another wave's instructions in the SIMD's issue slots), one 16-channel block of a slab that differed in the 5th digit -- an
+// MFMA had read its B operand before the conversion's result had landed; no such hazard is known to the compiler.  The in/out
+// operand makes the nops a data dependence between the pack and its consumer, so they cannot be scheduled away.
+__device__ __forceinline__ bf16x8 mfma_operand_fence(bf16x8 v) {
+    typedef uint32_t u32x4_f __attribute__((ext_vector_type(4)));
+    u32x4_f t = __builtin_bit_cast(u32x4_f, v);
+    asm volatile("s_nop 7" : "+v"(t));
+    return __builtin_bit_cast(bf16x8, t);
+}
+
 // Two adjacent 16-column tiles of one output row in the MFMA accumulator layout -- lane (t, gq) holds 4 bf16 of tile A at
 // columns 4 gq and 4 bf16 of tile B at columns 16 + 4 gq -- leave as ONE 16-byte store per lane instead of two 8-byte
 // ones: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other, after which an

@@ -408,6 +408,15 @@ extern "C" int tulip_l1_loss_fwd(const float* pred, const float* target, float* 
     return TULIP_OK;
 }
 
+// second stage alone: the partial sums came out of another kernel (tulip_tail_fwd_ln: one [loss | pixel loss] pair per workgroup)
+extern "C" int tulip_l1_loss_final(const float* partials, float* losses, int nblocks, int64_t n, int log_transform,
+                                   hipStream_t stream) {
+    if (!partials || !losses || nblocks <= 0 || n <= 0) return TULIP_ERR_ARG;
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, stream, partials, losses, nblocks, 1.0 / (double)n, log_transform);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
 extern "C" int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscale_dev, float gscale,
                                  float* dpred, int64_t n, hipStream_t stream) {
     if (n <= 0) return TULIP_ERR_ARG;

@@ -104,6 +104,123 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const bf16_t* __restri
     }
 }
 
+// The same forward with norm_up (tulip.py:720) in front and the L1 / pixel loss partial sums (tulip.py:690-700) behind it, one
+// launch instead of four on the latency-bound chain: every wave normalises the workgroup's 32 token rows itself (lane
+// (li, gq) holds channels 32 ks + 8 gq .. + 7 of token li: exactly its MFMA B fragments, so the LayerNorm output never
+// leaves registers on the way to the expand conv); wave 0 also stores it (bf16) with the row statistics for the backward.
+struct TailNorm { const float* x; const float* gamma; const float* beta; float eps; bf16_t* xn; float* mean; float* rstd; };
+struct TailLoss { const float* target; float* partials; int log_transform; };
+template <int KS>
+__global__ __launch_bounds__(256, 2) void tail_fwd_ln_kernel(const TailNorm nrm, const bf16_t* __restrict__ We,
+                                                          const float* __restrict__ be, const float* __restrict__ wd,
+                                                          float* __restrict__ pred, TailGeom g, const TailLoss ls) {
+    __shared__ __attribute__((aligned(16))) float red[4][32][16];
+    __shared__ float lred[2][2];
+    const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4, wid = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 32;
+    bf16x8 xb[2][KS];
+    const float invE = 1.0f / (float)g.E;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        const int tok = m0 + mf * 16 + li;
+        const bool valid = tok < g.M;
+        float v[KS][8];
+        float sm = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 32 + gq * 8;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (valid && k < g.E) {
+                a = *(const float4*)(nrm.x + (size_t)tok * g.E + k);
+                b = *(const float4*)(nrm.x + (size_t)tok * g.E + k + 4);
+            }
+            v[ks][0] = a.x; v[ks][1] = a.y; v[ks][2] = a.z; v[ks][3] = a.w;
+            v[ks][4] = b.x; v[ks][5] = b.y; v[ks][6] = b.z; v[ks][7] = b.w;
+            sm += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+        }
+        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+        const float mu = sm * invE;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            if (ks * 32 + gq * 8 < g.E) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mu; q += d * d; }
+            }
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        const float rs = rsqrtf(q * invE + nrm.eps);
+        if (wid == 0 && gq == 0 && valid) { nrm.mean[tok] = mu; nrm.rstd[tok] = rs; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 32 + gq * 8;
+            bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid && k < g.E) {
+                const float4 g0 = *(const float4*)(nrm.gamma + k), g1 = *(const float4*)(nrm.gamma + k + 4);
+                const float4 b0 = *(const float4*)(nrm.beta + k), b1 = *(const float4*)(nrm.beta + k + 4);
+                const uint4 pk = make_uint4(
+                    pack_bf16x2((v[ks][0] - mu) * rs * g0.x + b0.x, (v[ks][1] - mu) * rs * g0.y + b0.y),
+                    pack_bf16x2((v[ks][2] - mu) * rs * g0.z + b0.z, (v[ks][3] - mu) * rs * g0.w + b0.w),
+                    pack_bf16x2((v[ks][4] - mu) * rs * g1.x + b1.x, (v[ks][5] - mu) * rs * g1.y + b1.y),
+                    pack_bf16x2((v[ks][6] - mu) * rs * g1.z + b1.z, (v[ks][7] - mu) * rs * g1.w + b1.w));
+                o = __builtin_bit_cast(bf16x8, pk);
+                if (wid == 0) *(uint4*)(nrm.xn + (size_t)tok * g.E + k) = pk;
+            }
+            xb[mf][ks] = o;
+        }
+    }
+    float pacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int cper = (g.E + 3) / 4, c0 = wid * cper, c1 = min(g.E, c0 + cper);
+    for (int c = c0; c < c1; ++c) {
+        f32x4 acc[2];
+        expand_channel<KS>(We, g, c, li, gq, xb, acc);
+        const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
+        const float wc = wd[c];
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[mf][r] + bb[r];
+                pacc[mf][r] += wc * (z > 0.f ? z : 0.01f * z);
+            }
+    }
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+        *(float4*)&red[wid][mf * 16 + li][gq * 4] = make_float4(pacc[mf][0], pacc[mf][1], pacc[mf][2], pacc[mf][3]);
+    __syncthreads();
+    float l0 = 0.f, l1 = 0.f;
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 2, i = threadIdx.x & 3;   // token, sub-row i (4 pixels j = 0..3)
+        const int tok = m0 + t;
+        if (tok < g.M) {
+            float4 o = *(const float4*)&red[0][t][i * 4];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = *(const float4*)&red[w][t][i * 4];
+                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            }
+            const size_t po = pred_off(g, tok, i);
+            *(float4*)(pred + po) = o;
+            if (ls.partials) {
+                const float4 q = *(const float4*)(ls.target + po);
+                l0 = (fabsf(o.x - q.x) + fabsf(o.y - q.y)) + (fabsf(o.z - q.z) + fabsf(o.w - q.w));
+                if (ls.log_transform)
+                    l1 = (fabsf(expm1f(o.x) - expm1f(q.x)) + fabsf(expm1f(o.y) - expm1f(q.y))) +
+                         (fabsf(expm1f(o.z) - expm1f(q.z)) + fabsf(expm1f(o.w) - expm1f(q.w)));
+            }
+        }
+    }
+    if (ls.partials) {                                          // uniform
+        l0 = group_sum<64>(l0); l1 = group_sum<64>(l1);
+        if (lane == 0 && wid < 2) { lred[0][wid] = l0; lred[1][wid] = l1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ls.partials[blockIdx.x * 2] = lred[0][0] + lred[0][1];
+            ls.partials[blockIdx.x * 2 + 1] = lred[1][0] + lred[1][1];
+        }
+    }
+}
+
 template <int KS>
 __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
                                                        const float* __restrict__ be, const float* __restrict__ wd,
@@ -228,17 +345,26 @@ __device__ __forceinline__ float4 pred_grad4(const float* __restrict__ dpred, co
     return d;
 }
 
+// norm_up's backward (autograd of tulip.py:720) in the epilogue of tail_bwd_dgrad_kernel: x = the LayerNorm's input rows,
+// dx / dx_bf16 / param_partials as tulip_layernorm_bwd writes them (one partial row [dgamma | dbeta] per workgroup)
+struct TailNormBwd {
+    const float* x; const float* mean; const float* rstd; const float* gamma;
+    float* dx; bf16_t* dx_bf16; const float* cast_rowscale; int cast_rows_per_sample; float* param_partials;
+};
 template <int KS, int NB>
 __global__ __launch_bounds__(256, 2) void tail_bwd_dgrad_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ We,
                                                              const float* __restrict__ be, const float* __restrict__ wd,
                                                              const float* __restrict__ dpred, bf16_t* __restrict__ dxn,
                                                              float* dwd, TailGeom g, const float* __restrict__ target,
-                                                             const float* __restrict__ gscale_dev, float gscale) {
+                                                             const float* __restrict__ gscale_dev, float gscale,
+                                                             const TailNormBwd nb) {
     constexpr int E = NB * 16, PITCH = tr_pitch(E), RP = E + 4;        // RP: fp32 row pitch of the cross-wave reduction
     constexpr int TILE = 32 * PITCH, RED = 32 * RP * 4;
+    constexpr int MAIN = 4 * (TILE > RED ? TILE : RED);
     __shared__ float lds_dwd[128];
-    // phase 1: four wave-private [32 output channels][E] tiles of We; phase 2 (overlaid): four [32 tokens][E] fp32 partial dxn
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * (TILE > RED ? TILE : RED)];
+    // phase 1: four wave-private [32 output channels][E] tiles of We; phase 2 (overlaid): four [32 tokens][E] fp32 partial dxn;
+    // behind them the [32 tokens][2E] LayerNorm affine-gradient terms of the fused norm_up backward
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 32 * 2 * E * 4];
     const int lane = threadIdx.x & 63, li = lane & 15, gq = lane >> 4, wid = threadIdx.x >> 6;
     if (threadIdx.x < 128) lds_dwd[threadIdx.x] = 0.f;
     __syncthreads();
@@ -300,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_dgrad_kernel(const bf16_t* __
             if (lane == 0) lds_dwd[c + cc] = part;                        // channel c belongs to this wave alone
         }
         // dxn^T[k][token] += We^T[k][oc] . dz[oc][token] over the pair's 32 output channels (k order: 4gq.., 16+4gq..)
-        const bf16x8 dzf[2] = {cat8_t(ob[0][0], ob[1][0]), cat8_t(ob[0][1], ob[1][1])};
+        const bf16x8 dzf[2] = {mfma_operand_fence(cat8_t(ob[0][0], ob[1][0])), mfma_operand_fence(cat8_t(ob[0][1], ob[1][1]))};
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const bf16x8 wt = cat8_t(trr_t(trp + 32 * n), trr_t(trp + 32 * n + 16 * PITCH));
@@ -315,16 +441,79 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_dgrad_kernel(const bf16_t* __
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) *(f32x4*)(red + (mf * 16 + li) * RP + 16 * n + 4 * gq) = dxa[n][mf];
     __syncthreads();
-    for (int id = threadIdx.x; id < 32 * (E / 4); id += 256) {
-        const int t = id / (E / 4), c4 = id - t * (E / 4);
-        const float* r0 = (const float*)smem + t * RP + c4 * 4;
-        float4 o = *(const float4*)r0;
+    if (nb.x == nullptr) {                                               // uniform: dxn itself is the output
+        for (int id = threadIdx.x; id < 32 * (E / 4); id += 256) {
+            const int t = id / (E / 4), c4 = id - t * (E / 4);
+            const float* r0 = (const float*)smem + t * RP + c4 * 4;
+            float4 o = *(const float4*)r0;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float4 v = *(const float4*)(r0 + w * (32 * RP));
-            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            for (int w = 1; w < 4; ++w) {
+                const float4 v = *(const float4*)(r0 + w * (32 * RP));
+                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            }
+            if (m0 + t < g.M) *(uint2*)(dxn + (size_t)(m0 + t) * E + c4 * 4) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
         }
-        if (m0 + t < g.M) *(uint2*)(dxn + (size_t)(m0 + t) * E + c4 * 4) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+    } else {
+        // LayerNorm backward of the 32 rows: 8 lanes per row, lane j owns the 4-channel pieces j, j + 8, ...
+        constexpr int NP = (E / 4 + 7) / 8;
+        const int t = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int tok = m0 + t;
+        const bool valid = tok < g.M;
+        const float mu = valid ? nb.mean[tok] : 0.f, rs = valid ? nb.rstd[tok] : 0.f;
+        float gy[NP][4], xh[NP][4];
+        float s1 = 0.f, s2 = 0.f;
+        float* pp = (float*)(smem + MAIN) + t * (2 * E);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c4 = j + 8 * p;
+            if (c4 < E / 4) {
+                const float* r0 = (const float*)smem + t * RP + c4 * 4;
+                float4 o = *(const float4*)r0;
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float4 v = *(const float4*)(r0 + w * (32 * RP));
+                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                }
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) xv = *(const float4*)(nb.x + (size_t)tok * E + c4 * 4);
+                const float4 ga = *(const float4*)(nb.gamma + c4 * 4);
+                const float dy[4] = {o.x, o.y, o.z, o.w}, xr[4] = {xv.x, xv.y, xv.z, xv.w}, gv[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[p][e] = (xr[e] - mu) * rs;
+                    pp[c4 * 4 + e] = dy[e] * xh[p][e];                    // d(gamma) term
+                    pp[E + c4 * 4 + e] = dy[e];                           // d(beta) term
+                    gy[p][e] = dy[e] * gv[e];
+                    s1 += gy[p][e];
+                    s2 += gy[p][e] * xh[p][e];
+                }
+            }
+        }
+        s1 = group_sum<8>(s1) * (1.0f / E);
+        s2 = group_sum<8>(s2) * (1.0f / E);
+        const float sc = (nb.dx_bf16 && nb.cast_rowscale && valid) ? nb.cast_rowscale[fast_div(tok, nb.cast_rows_per_sample)] : 1.0f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c4 = j + 8 * p;
+            if (c4 < E / 4 && valid) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = rs * (gy[p][e] - s1 - xh[p][e] * s2);
+                *(float4*)(nb.dx + (size_t)tok * E + c4 * 4) = make_float4(d[0], d[1], d[2], d[3]);
+                if (nb.dx_bf16)
+                    *(uint2*)(nb.dx_bf16 + (size_t)tok * E + c4 * 4) = make_uint2(pack_bf16x2(d[0] * sc, d[1] * sc), pack_bf16x2(d[2] * sc, d[3] * sc));
+            }
+        }
+        __syncthreads();
+        if (nb.param_partials) {
+            for (int c = threadIdx.x; c < 2 * E; c += 256) {
+                const float* col = (const float*)(smem + MAIN) + c;
+                float a = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) a += col[r * (2 * E)];
+                nb.param_partials[(size_t)blockIdx.x * (2 * E) + c] = a;
+            }
+        }
     }
     if (threadIdx.x < 128) dwd[(size_t)blockIdx.x * 128 + threadIdx.x] = threadIdx.x < g.E ? lds_dwd[threadIdx.x] : 0.f;
 }
@@ -482,7 +671,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && NC <= 2 ? 2 : 1)) void tail_
                     for (int r = 0; r < 4; ++r) { o[r] = leaky_grad_sel(z[r], dpl[mf][r], dql[mf][r]); bsum[cc] += o[r]; }
                     ob[mf] = pack4_t(o[0], o[1], o[2], o[3]);
                 }
-                const bf16x8 dzf = cat8_t(ob[0], ob[1]);                        // contraction = tokens 4gq.., 16+4gq..
+                const bf16x8 dzf = mfma_operand_fence(cat8_t(ob[0], ob[1]));    // contraction = tokens 4gq.., 16+4gq..
 #pragma unroll
                 for (int n = 0; n < NB; ++n) acc[cc][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xT[n], dzf, acc[cc][n], 0, 0, 0);
             }
@@ -554,16 +743,16 @@ extern "C" int tulip_tail_bwd(const uint16_t* xn, const uint16_t* We, const floa
 
 extern "C" int tulip_tail_fused_bwd_supported(int E) { return E > 0 && E % 16 == 0 && E <= 128; }
 
-extern "C" int tulip_tail_bwd_dgrad(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd,
-                                    const float* dpred, uint16_t* dxn, float* dwd, int B, int H, int W, int E,
-                                    const float* target, const float* gscale_dev, float gscale, hipStream_t stream) {
-    if (!tulip_tail_fused_bwd_supported(E) || !xn || !We || !be || !wd || !dpred || !dxn || !dwd) return TULIP_ERR_ARG;
+static int tail_bwd_dgrad_impl(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd, const float* dpred,
+                               uint16_t* dxn, float* dwd, int B, int H, int W, int E, const float* target,
+                               const float* gscale_dev, float gscale, const TailNormBwd& nb, hipStream_t stream) {
+    if (!tulip_tail_fused_bwd_supported(E) || !xn || !We || !be || !wd || !dpred || !dwd) return TULIP_ERR_ARG;
     TailGeom g{B * H * W, H, W, E};
     if (g.M <= 0) return TULIP_OK;
     const dim3 grid((g.M + 31) / 32), block(256);
 #define TULIP_TBD(KS, NB) \
     hipLaunchKernelGGL((tail_bwd_dgrad_kernel<KS, NB>), grid, block, 0, stream, (const bf16_t*)xn, (const bf16_t*)We, be, wd, dpred, \
-                       (bf16_t*)dxn, dwd, g, target, gscale_dev, gscale)
+                       (bf16_t*)dxn, dwd, g, target, gscale_dev, gscale, nb)
     switch (E / 16) {
         case 1: TULIP_TBD(1, 1); break;
         case 2: TULIP_TBD(1, 2); break;
@@ -579,7 +768,46 @@ extern "C" int tulip_tail_bwd_dgrad(const uint16_t* xn, const uint16_t* We, cons
     return TULIP_OK;
 }
 
-// token splits of tulip_tail_wgrad: about one workgroup per CU over (E/16 channel slices) x splits
+extern "C" int tulip_tail_bwd_dgrad(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd,
+                                    const float* dpred, uint16_t* dxn, float* dwd, int B, int H, int W, int E,
+                                    const float* target, const float* gscale_dev, float gscale, hipStream_t stream) {
+    if (!dxn) return TULIP_ERR_ARG;
+    const TailNormBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr};
+    return tail_bwd_dgrad_impl(xn, We, be, wd, dpred, dxn, dwd, B, H, W, E, target, gscale_dev, gscale, none, stream);
+}
+
+extern "C" int tulip_tail_bwd_dgrad_ln(const uint16_t* xn, const uint16_t* We, const float* be, const float* wd,
+                                       const float* dpred, float* dwd, int B, int H, int W, int E, const float* target,
+                                       const float* gscale_dev, float gscale, const float* x, const float* mean,
+                                       const float* rstd, const float* gamma, float* dx, uint16_t* dx_bf16,
+                                       const float* cast_rowscale, int cast_rows_per_sample, float* ln_partials,
+                                       hipStream_t stream) {
+    if (!x || !mean || !rstd || !gamma || !dx) return TULIP_ERR_ARG;
+    const TailNormBwd nb{x, mean, rstd, gamma, dx, (bf16_t*)dx_bf16, cast_rowscale,
+                         cast_rows_per_sample > 0 ? cast_rows_per_sample : 1, ln_partials};
+    return tail_bwd_dgrad_impl(xn, We, be, wd, dpred, nullptr, dwd, B, H, W, E, target, gscale_dev, gscale, nb, stream);
+}
+
+extern "C" int tulip_tail_fwd_ln(const float* x, const float* gamma, const float* beta, float eps, uint16_t* xn, float* mean,
+                                 float* rstd, const uint16_t* We, const float* be, const float* wd, float* pred,
+                                 const float* target, float* loss_partials, int log_transform, int B, int H, int W, int E,
+                                 hipStream_t stream) {
+    if (E <= 0 || (E & 7) || E > 128 || !x || !gamma || !beta || !xn || !mean || !rstd || !We || !be || !wd || !pred ||
+        (loss_partials && !target))
+        return TULIP_ERR_ARG;
+    TailGeom g{B * H * W, H, W, E};
+    if (g.M <= 0) return TULIP_OK;
+    const dim3 grid((g.M + 31) / 32), block(256);
+    const TailNorm nrm{x, gamma, beta, eps, (bf16_t*)xn, mean, rstd};
+    const TailLoss ls{target, loss_partials, log_transform};
+    const int ks = (E + 31) / 32;
+    if (ks <= 2) hipLaunchKernelGGL(tail_fwd_ln_kernel<2>, grid, block, 0, stream, nrm, (const bf16_t*)We, be, wd, pred, g, ls);
+    else if (ks == 3) hipLaunchKernelGGL(tail_fwd_ln_kernel<3>, grid, block, 0, stream, nrm, (const bf16_t*)We, be, wd, pred, g, ls);
+    else hipLaunchKernelGGL(tail_fwd_ln_kernel<4>, grid, block, 0, stream, nrm, (const bf16_t*)We, be, wd, pred, g, ls);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
 // channels per workgroup of tulip_tail_wgrad: 8 waves x 3 (E % 24 == 0; 256 registers per wave) or 4 waves x 4; about one
 // workgroup per CU
 static void tail_wgrad_plan(int M, int E, int* nslices, int* splits, int* steps_per_split) {

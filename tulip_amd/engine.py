@@ -218,7 +218,7 @@ class Plan:
         self.pred = self.f32("pred", B, m.in_chans, Hh, Wh)
         self.dpred = self.f32("dpred", B, m.in_chans, Hh, Wh)
         self.losses = self.f32("losses", 2)
-        self.partials = self.f32("partials", 2048)
+        self.partials = self.f32("partials", max(2048, 2 * ((B * H0 * W0 + 31) // 32)))   # loss partial sums (2 per block)
         self.gscale = self.f32("gscale", 1)
         self.gscale.fill_(1.0)
         nslots = max(1, eng.n_drop_slots)
@@ -491,6 +491,7 @@ class TulipEngine:
 
     fuse_splitk_ln = os.environ.get("TULIP_FUSE_SPLITK_LN", "1") != "0"
     fuse_tail_bwd = os.environ.get("TULIP_FUSE_TAIL_BWD", "1") != "0"      # head backward without the d(expand) tensor
+    fuse_tail_ln_bwd = os.environ.get("TULIP_FUSE_TAIL_LN_BWD", "1") != "0"   # ... and norm_up's backward in its epilogue
     _tail_fused = False
 
     def _unfused(self, sp: BlockSpec, B: int) -> bool:
@@ -629,7 +630,10 @@ class TulipEngine:
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
-    def run_forward(self, P: Plan, with_loss: bool = True, pack_on_side: bool = False):
+    fuse_tail_fwd = os.environ.get("TULIP_FUSE_TAIL_FWD", "1") != "0"      # norm_up + head + loss partials in one launch
+    _loss_final = None
+
+    def run_forward(self, P: Plan, with_loss: bool = True, pack_on_side: bool = False, defer_loss_final: bool = False):
         """TULIP.forward (tulip.py:702-737) on P.x_in / P.target -> P.pred, P.losses.
         pack_on_side (Trainer): the fragment-major weight copies of the fused wide blocks are rewritten from the bf16
         shadow beside the forward's first kernels (side stream, joined in front of the first wide block) instead of on
@@ -640,6 +644,7 @@ class TulipEngine:
         elif W_.pack_dirty and not pack_on_side:
             W_.refresh_transposes()
         self._pack_event, self._pack_issued = None, False
+        self._loss_final = None
         self._no_save = not with_loss and self.infer_no_save
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
@@ -684,14 +689,30 @@ class TulipEngine:
             if i < nl - 2:
                 self._unmerge_fwd(P, f"layers_up.{i}.upsample", s)
         M0 = B * H0 * W0
-        ops.layernorm_fwd(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), P["tail.xn"], P["tail.mean"],
-                          P["tail.rstd"], M0, E, self.eps)
-        if m.pixel_shuffle:
+        loss_done = False
+        if m.pixel_shuffle and self.fuse_tail_fwd:
+            # norm_up -> expand conv -> LeakyReLU -> PixelShuffle(4) -> decoder_pred (-> L1 partial sums) in ONE launch
+            ops.tail_fwd_ln(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), self.eps, P["tail.xn"], P["tail.mean"],
+                            P["tail.rstd"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
+                            W_.p32("decoder_pred.weight"), P.pred, B, H0, W0, E, target=P.target if with_loss else None,
+                            loss_partials=P.partials if with_loss else None, log_transform=m.log_transform)
+            if with_loss:
+                fin = lambda: ops.l1_loss_final(P.partials, P.losses, (M0 + 31) // 32, P.pred.numel(), m.log_transform)
+                if defer_loss_final:
+                    self._loss_final = fin            # run_backward issues it beside the chain (nothing on the GPU reads it)
+                else:
+                    fin()
+            loss_done = True
+        elif m.pixel_shuffle:
+            ops.layernorm_fwd(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), P["tail.xn"], P["tail.mean"],
+                              P["tail.rstd"], M0, E, self.eps)
             ops.tail_fwd(P["tail.xn"], W_.p16("ps_head.conv_expand.0.weight"), W_.p32("ps_head.conv_expand.0.bias"),
                          W_.p32("decoder_pred.weight"), P.pred, B, H0, W0, E)
         else:
             # FinalPatchExpanding (tulip.py:144-159) + decoder_pred (tulip.py:731): Linear E -> r^2 E, then one kernel
             # for rearrange + LayerNorm(E) + the 1x1 conv as a per-row dot product
+            ops.layernorm_fwd(x, W_.p32("norm_up.weight"), W_.p32("norm_up.bias"), P["tail.xn"], P["tail.mean"],
+                              P["tail.rstd"], M0, E, self.eps)
             r = m.upscale_factor
             pre = "final_patch_expanding"
             self._gemm(P["tail.xn"], W_.p16(pre + ".expand.weight"), M0, r * r * E, E, lda=E, ldb=E, epi=EPI_F32,
@@ -700,7 +721,7 @@ class TulipEngine:
                                 P["tail.erstd"], B, H0, W0, r, E, self.eps, dotw=W_.p32("decoder_pred.weight"),
                                 pred=P.pred)
         self._join_pack()                          # (a model without fused wide blocks never asked for the copies)
-        if with_loss:
+        if with_loss and not loss_done:
             ops.l1_loss_fwd(P.pred, P.target, P.partials, P.losses, P.pred.numel(), m.log_transform)
         P.generation += 1
         P.last_x = x
@@ -1140,6 +1161,9 @@ class TulipEngine:
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
+        if self._loss_final is not None:             # the loss read-out of run_forward(defer_loss_final=True): off the chain
+            self._side(self._loss_final)
+            self._loss_final = None
         gbase = gflat.data_ptr()
         G = lambda name: gbase + 4 * W_.offset[name]
         user_hook = bucket_hook or (lambda tag: None)
@@ -1179,7 +1203,21 @@ class TulipEngine:
             if self._tail_fused:
                 # d(expand pre-activation) -- 100 MB at batch 8 -- is never written: the chain's kernel goes straight to dxn,
                 # the side queue's kernel recomputes it channel-sliced for the expand conv's weight / bias gradient
-                ops.tail_bwd_dgrad(*targs, P["tail.dxn"], tpart, B, H0, W0, E, **tkw)
+                x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
+                dx0 = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
+                if self.fuse_tail_ln_bwd:
+                    # ... and on through norm_up's backward in the same launch (dx, the next GEMM's bf16 operand, one
+                    # [dgamma | dbeta] partial row per 32 tokens)
+                    cb, cs, ct = self._mlp_cast(P, (self.dec_blocks[-1] if nl > 1 else self.enc_blocks[0])[-1]) or (None, None, 1)
+                    R = (M0 + 31) // 32
+                    lnp = P.scratch("lnp.norm_up.fused", R * 2 * E)
+                    ops.tail_bwd_dgrad_ln(*targs, tpart, B, H0, W0, E, x_last, P["tail.mean"], P["tail.rstd"],
+                                          W_.p32("norm_up.weight"), dx0, lnp, dx_bf16=cb, cast_rowscale=cs,
+                                          cast_rows_per_sample=ct, **tkw)
+                    self._fold(lnp, 2 * E, G("norm_up.weight"), E, R)
+                    self._fold(lnp + 4 * E, 2 * E, G("norm_up.bias"), E, R)
+                else:
+                    ops.tail_bwd_dgrad(*targs, P["tail.dxn"], tpart, B, H0, W0, E, **tkw)
                 sp = ops.tail_wgrad_splits(B, H0, W0, E)
                 nw = 16 * E * E
                 slab = P.scratch("tail.wslab", sp * (nw + 16 * E))
@@ -1211,9 +1249,10 @@ class TulipEngine:
                      epi=EPI_BF16, out=P["tail.dxn"], ldo=E)
         x_last = P[self.dec_blocks[-1][-1].prefix + ".out"] if nl > 1 else P[self.enc_blocks[0][-1].prefix + ".out"]
         dx = P["dec0.dx"] if nl > 1 else P["enc0.dx"]
-        self._ln_bwd(P, P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx, M0,
-                     E, G("norm_up.weight"), G("norm_up.bias"), "norm_up",
-                     cast=self._mlp_cast(P, (self.dec_blocks[-1] if nl > 1 else self.enc_blocks[0])[-1]))
+        if not (m.pixel_shuffle and self._tail_fused and self.fuse_tail_ln_bwd):
+            self._ln_bwd(P, P["tail.dxn"], x_last, P["tail.mean"], P["tail.rstd"], W_.p32("norm_up.weight"), None, dx, M0,
+                         E, G("norm_up.weight"), G("norm_up.bias"), "norm_up",
+                         cast=self._mlp_cast(P, (self.dec_blocks[-1] if nl > 1 else self.enc_blocks[0])[-1]))
         hook("head")
         # ---- decoder, fine -> coarse
         for i in reversed(range(nl - 1)):

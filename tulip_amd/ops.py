@@ -212,6 +212,28 @@ def tail_bwd_dgrad(xn, We, be, wd, dpred, dxn, dwd, B, H, W, E, target=None, gsc
                                            _p(target), _p(gscale_dev), float(gscale), _stream()), "tulip_tail_bwd_dgrad")
 
 
+def tail_bwd_dgrad_ln(xn, We, be, wd, dpred, dwd, B, H, W, E, x, mean, rstd, gamma, dx, ln_partials, dx_bf16=None,
+                      cast_rowscale=None, cast_rows_per_sample=1, target=None, gscale_dev=None, gscale=1.0):
+    """tail_bwd_dgrad with norm_up's backward in the epilogue: dx / dx_bf16 / [dgamma | dbeta] partial rows (one per 32 tokens)."""
+    check(_lib.load().tulip_tail_bwd_dgrad_ln(_p(xn), _p(We), _p(be), _p(wd), _p(dpred), _p(dwd), B, H, W, E, _p(target),
+                                              _p(gscale_dev), float(gscale), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx),
+                                              _p(dx_bf16), _p(cast_rowscale), cast_rows_per_sample, _p(ln_partials),
+                                              _stream()), "tulip_tail_bwd_dgrad_ln")
+
+
+def tail_fwd_ln(x, gamma, beta, eps, xn, mean, rstd, We, be, wd, pred, B, H, W, E, target=None, loss_partials=None,
+                log_transform=False):
+    """norm_up + fused head (+ the L1 / pixel loss partial sums per 32 tokens) in one launch."""
+    check(_lib.load().tulip_tail_fwd_ln(_p(x), _p(gamma), _p(beta), float(eps), _p(xn), _p(mean), _p(rstd), _p(We), _p(be),
+                                        _p(wd), _p(pred), _p(target), _p(loss_partials), int(log_transform), B, H, W, E,
+                                        _stream()), "tulip_tail_fwd_ln")
+
+
+def l1_loss_final(partials, losses, nblocks, n, log_transform):
+    check(_lib.load().tulip_l1_loss_final(_p(partials), _p(losses), nblocks, n, int(log_transform), _stream()),
+          "tulip_l1_loss_final")
+
+
 def tail_wgrad_splits(B, H, W, E):
     return _lib.load().tulip_tail_wgrad_splits(B, H, W, E)
 

@@ -135,7 +135,7 @@ class Trainer:
         eng, P = self.eng, self.P
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training, self.inject_drop_u)
-        eng.run_forward(P, pack_on_side=self.pack_at_step_start)
+        eng.run_forward(P, pack_on_side=self.pack_at_step_start, defer_loss_final=True)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None)
 
