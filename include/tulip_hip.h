@@ -84,9 +84,17 @@ int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream
 typedef struct tulip_wgrad_item {
     const void* dY; const void* X; float* dW; float* db;
     int ldy; int ldx; int Nw; int Kw; int Mtok; int splits;
+    int overwrite;      /* 0: dW += ..., db += ... (autograd's accumulation); 1: dW = ..., db = ... (the caller guarantees this is the
+                           only contribution of the step: the gradient buffer then needs no clearing) */
+    int reserved_;
 } tulip_wgrad_item;
 int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
                       void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream);
+/* The fold regions tulip_wgrad_group(fold = 1) would hand to tulip_reduce_rows_multi for these items and this workspace (host
+ * code only): for a caller that launches with fold = 0 and folds later, in one launch with regions that become ready in
+ * between (the engine: the patch-embedding partial rows ride in the fold of the backward's last weight-gradient group).
+ * Returns the number of regions written to `out` (<= max), or a negative error. */
+int tulip_wgrad_group_regions(const tulip_wgrad_item* items, int n, void* workspace, tulip_reduce_region* out, int max);
 
 /* Workgroup tiles per token split the grouped launch uses for a [Nw][Kw] weight gradient (192 x 192 per workgroup where
  * both dimensions are multiples of 192, 384 x 96 / 96 x 384 for the 96-wide stage, else 64 x 96): what a caller sizes

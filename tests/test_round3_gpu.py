@@ -55,7 +55,10 @@ def test_kitti_b8_train_step_vs_oracle():
     torch.cuda.synchronize()
     assert tr._segments is not None and len(tr._segments[True]) == 1
     assert torch.equal(losses, loss_eager)
-    assert float(tr.g.abs().max()) == 0.0      # consumed and cleared by the fused AdamW
+    if tr.grad_overwrite:                      # the backward writes (does not add to) the buffer: it still holds the step's gradients,
+        assert torch.equal(tr.g, g_hip)        # bit for bit those of the eager pass
+    else:
+        assert float(tr.g.abs().max()) == 0.0  # consumed and cleared by the fused AdamW
     p1 = W.flat.clone()
     dropped = sum(int((torch.floor(1 - sp.rate + du[sp.prefix]) == 0).sum()) for sp in eng.blocks if sp.slot >= 0)
     assert dropped > 0                         # the draw really drops some (sample, branch) pairs

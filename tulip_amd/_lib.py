@@ -41,7 +41,7 @@ class ReduceRegion(ctypes.Structure):
 class WgradItem(ctypes.Structure):
     """tulip_wgrad_item (include/tulip_hip.h)."""
     _fields_ = [("dY", P), ("X", P), ("dW", P), ("db", P), ("ldy", I), ("ldx", I), ("Nw", I), ("Kw", I), ("Mtok", I),
-                ("splits", I)]
+                ("splits", I), ("overwrite", I), ("reserved_", I)]
 
 
 class PackItem(ctypes.Structure):
@@ -84,6 +84,7 @@ SIGNATURES = {
     "tulip_reduce_rows_multi": [P, I, P],
     "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
     "tulip_wgrad_tiles": [I, I],
+    "tulip_wgrad_group_regions": [P, I, P, P, I],
     "tulip_wgrad_set_mode": [I],
     "tulip_wgrad_set_profile": [P],
     "tulip_gemm_effective_splits": [I, I],

@@ -151,7 +151,10 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
             s += mine ? dense[ij] : 0.f;
             any |= mine;
         }
-        if (any) r.out[e * r.nh + h] += s;
+        if (any) {                                     // (every entry of a relative-position table has pairs)
+            if (r.overwrite) r.out[e * r.nh + h] = s;
+            else r.out[e * r.nh + h] += s;
+        }
         return;
     }
     if (rl == 0 && col < r.n4) {

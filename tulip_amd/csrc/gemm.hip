@@ -860,11 +860,11 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
             p.epi = TULIP_EPI_SPLIT_F32; p.accumulate = 0;
             p.out = ws + ws_used;
             p.out2 = it.db ? (void*)(ws + ws_used + nw * splits) : nullptr;
-            folds[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, 0, nullptr, 0, 0};
-            if (it.db) folds[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, 0, nullptr, 0, 0};
+            folds[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, it.overwrite, nullptr, 0, 0};
+            if (it.db) folds[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, it.overwrite, nullptr, 0, 0};
             ws_used += need;
         } else {
-            p.epi = TULIP_EPI_F32; p.accumulate = 1; p.out = it.dW; p.out2 = it.db;
+            p.epi = TULIP_EPI_F32; p.accumulate = it.overwrite ? 0 : 1; p.out = it.dW; p.out2 = it.db;
         }
         G.shape[G.n] = big ? wgrad_shape(it.Nw, it.Kw) : -1;
         wgrad_tile_grid(G.shape[G.n], it.Nw, it.Kw, &G.gx[G.n], &G.gy[G.n]);
@@ -892,6 +892,30 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
     if (!fold) return TULIP_OK;
     for (int i = 0; i < n_extra; ++i) folds[nf++] = extra[i];
     return nf ? tulip_reduce_rows_multi(folds, nf, stream) : TULIP_OK;
+}
+
+// The fold regions tulip_wgrad_group(..., fold = 1) would pass to tulip_reduce_rows_multi for these items and this workspace
+// (pure host code, same slab layout): for a caller that launches with fold = 0 and folds later in a launch of its own,
+// together with regions that only become ready in between.  Returns the number of regions written (<= max), or < 0.
+extern "C" int tulip_wgrad_group_regions(const tulip_wgrad_item* items, int n, void* workspace, tulip_reduce_region* out, int max) {
+    if (n < 0 || n > GROUP_MAX || (n && !items) || !out) return TULIP_ERR_ARG;
+    int nf = 0;
+    int64_t ws_used = 0;
+    float* ws = (float*)workspace;
+    for (int i = 0; i < n; ++i) {
+        const tulip_wgrad_item& it = items[i];
+        if (it.Nw <= 0 || it.Kw <= 0 || it.Mtok <= 0) continue;
+        int splits = it.splits < 1 ? 1 : it.splits;
+        const int kchunk = (((it.Mtok + splits - 1) / splits) + BK - 1) / BK * BK;
+        splits = (it.Mtok + kchunk - 1) / kchunk;
+        if (splits <= 1) continue;
+        const int64_t nw = (int64_t)it.Nw * it.Kw, need = (nw + (it.db ? it.Nw : 0)) * splits;
+        if (nf + 2 > max) return TULIP_ERR_ARG;
+        out[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, it.overwrite, nullptr, 0, 0};
+        if (it.db) out[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, it.overwrite, nullptr, 0, 0};
+        ws_used += need;
+    }
+    return nf;
 }
 
 extern "C" int tulip_gemm_set_touch(int on) { gemm_touch_on = on ? 1 : 0; return TULIP_OK; }

@@ -792,6 +792,8 @@ class TulipEngine:
     # (up to 12 linears) halve the launches, the slab traffic (1.36 -> 0.7 GB per step) and the fold launches: 2.46 -> 2.33 ms
     # at batch 8, 10.41 -> 10.24 ms at batch 64 (same box; per-block launches for the backward's last stage only: 2.36).
     flush_per_block = os.environ.get("TULIP_FLUSH_PER_BLOCK", "0") != "0"
+    flush_unfused_blocks = os.environ.get("TULIP_FLUSH_UNFUSED_BLOCKS", "0") != "0"
+    merge_embed_fold = os.environ.get("TULIP_MERGE_EMBED_FOLD", "0") != "0"      # measured neutral (2.245 vs 2.243 ms): off
     wgrad_group_max = int(os.environ.get("TULIP_WGRAD_GROUP_MAX", "12"))    # linears per grouped launch (<= 16)
     early_flush = frozenset()   # block prefixes with a mid-block side flush (set in bind())
     lag_bucket_join = os.environ.get("TULIP_LAG_BUCKET_JOIN", "1") != "0"
@@ -840,6 +842,7 @@ class TulipEngine:
         """Queue a fold of per-workgroup partial rows: out[i] += sum_r part[r*stride + i] (LayerNorm affine gradients,
         relative-position-bias gradients, ...).  Folds queued by one block leave in the same launch as the folds of
         its weight-gradient slabs."""
+        kw.setdefault("overwrite", self.grad_overwrite)
         r = ops.reduce_region(part, stride, out, n, rows, **kw)
         if self.overlap_wgrad:
             self._pending.append(("r", r))
@@ -855,8 +858,8 @@ class TulipEngine:
         pull a whole partial matrix through one CU."""
         dense = P.scratch("apd." + tag, nh * 256)
         self._fold(part, nh * 256, dense, nh * 256, rows, overwrite=True)
-        r = ops.reduce_region(dense, nh * 256, gtable, nh * 256, 1, scatter_index=self._rel32, scatter_nh=nh,
-                              scatter_len=256)
+        r = ops.reduce_region(dense, nh * 256, gtable, nh * 256, 1, overwrite=self.grad_overwrite, scatter_index=self._rel32,
+                              scatter_nh=nh, scatter_len=256)
         if self.overlap_wgrad and self.n_side == 1:
             self._pending.append(("s", r))
         elif self.overlap_wgrad:
@@ -887,6 +890,9 @@ class TulipEngine:
         regions = list(self._carry) + [a for k, a in pending if k == "r"]
         self._carry = tuple(a for k, a in pending if k == "s")     # their dense sums are produced by THIS launch
         fns = [a for k, a in pending if k == "f"]
+        # "e": an event the flush's FOLD launch has to wait for (not its weight-gradient launch) -- regions appended behind it
+        # became ready on the chain after the flush was forked (the patch-embedding partial rows: run_backward)
+        late = [a for k, a in pending if k == "e"]
         ws_bytes = (self.WS_ELEMS + (1 << 20)) * 4
         if not self.group_wgrad:
             for a in items:
@@ -909,11 +915,18 @@ class TulipEngine:
                 if grp and used + need > ws_bytes:
                     break
                 used += need
-                grp.append(ops.wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, sp))
+                grp.append(ops.wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, sp, overwrite=self.grad_overwrite))
                 items.pop(0)
             room = _lib.REDUCE_REGIONS_MAX - 2 * len(grp)
+            if late and not items and len(regions) <= room:
+                # one group, folded in ONE launch behind the late event together with everything else of this flush
+                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False)
+                regions = ops.wgrad_group_regions(grp, ws) + regions
+                break
             extra, regions = regions[:room], regions[room:]
             ops.wgrad_group(grp, extra, ws, ws_bytes)
+        for ev in late:
+            torch.cuda.current_stream().wait_event(ev)
         while regions:
             ops.reduce_rows_multi(regions[:_lib.REDUCE_REGIONS_MAX])
             regions = regions[_lib.REDUCE_REGIONS_MAX:]
@@ -1114,7 +1127,9 @@ class TulipEngine:
         if self._lagged_hook is not None:
             fn, self._lagged_hook = self._lagged_hook, None
             fn()                                    # bucket join + all-reduce of the previous group, one block late
-        if self.flush_per_block:
+        if self.flush_per_block or self.flush_unfused_blocks:
+            # (flush_unfused_blocks: the unfused blocks are the deep, few-token stages -- their chain is dozens of small
+            # GEMMs that leave most of the chip idle, the best place for their own weight gradients to run)
             self._flush_wgrads()
 
     def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G, have_dyb=False, next_cast=None):
@@ -1152,8 +1167,21 @@ class TulipEngine:
                  out=dx_out, ldo=C, out2=cb, ldo2=C if cb is not None else 0, rowscale=cs, rows_per_sample=ct)
         self._release_deferred()
 
+    # Gradients are WRITTEN, not accumulated (run_backward(overwrite=True), the Trainer with accum_iter == 1): every parameter has
+    # exactly one producer per backward (a weight-gradient item or a fold region), so the flat gradient buffer needs no clearing
+    # -- AdamW does not write 4 B per parameter of zeros, and the un-split weight gradients of the deep stages (66 MB) are stored
+    # instead of read-modify-written.  Not with the stand-alone LayerNorm parameter pass (C > 2048: tulip_large), which adds.
+    grad_overwrite = False
+
+    def overwrite_supported(self, B: int) -> bool:
+        m = self.model
+        E, nl = m.embed_dim, m.num_layers
+        widths = [E << s for s in range(nl)] + [4 * (E << s) for s in range(nl - 1)]
+        return bool(self.group_wgrad and self.overlap_wgrad
+                    and all(ops.layernorm_bwd_partial_rows(64, C) > 0 for C in widths))
+
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
-                     join_tags=None):
+                     join_tags=None, overwrite: bool = False):
         """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
         (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
         each parameter group has been *launched* (DDP overlap)."""
@@ -1161,6 +1189,7 @@ class TulipEngine:
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
+        self.grad_overwrite = bool(overwrite)
         if self._loss_final is not None:             # the loss read-out of run_forward(defer_loss_final=True): off the chain
             self._side(self._loss_final)
             self._loss_final = None
@@ -1330,7 +1359,14 @@ class TulipEngine:
                             m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
                             self.eps, partial_stride=P.embed_stride)
         gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
-        self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
+        if self.merge_embed_fold and self._deferred is not None and self.overlap_wgrad:
+            # the last stage's side work was forked in front of patch_embed_bwd and is not enqueued yet: its fold launch waits
+            # for the kernel above and takes the patch-embedding partial rows along (one launch less behind the chain's end)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._deferred[3].extend([("e", ev), ("r", ops.reduce_region(ep, P.embed_stride, gpe, P.embed_stride, nbe))])
+        else:
+            self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge

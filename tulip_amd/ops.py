@@ -95,8 +95,8 @@ def reduce_region(part, stride, out, n, rows, overwrite=False, scatter_index=Non
                              scatter_len)
 
 
-def wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, dW, db=None, splits=1):
-    return _lib.WgradItem(_p(dY), _p(X), _p(dW), _p(db), ldy, ldx, Nw, Kw, Mtok, splits)
+def wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, dW, db=None, splits=1, overwrite=False):
+    return _lib.WgradItem(_p(dY), _p(X), _p(dW), _p(db), ldy, ldx, Nw, Kw, Mtok, splits, int(overwrite), 0)
 
 
 def reduce_rows_multi(regions):
@@ -127,6 +127,15 @@ def wgrad_group(items, extra, workspace, workspace_bytes, fold=True):
     ea = (_lib.ReduceRegion * max(len(extra), 1))(*extra)
     check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, int(fold),
                                         _stream()), "tulip_wgrad_group")
+
+
+def wgrad_group_regions(items, workspace):
+    """The fold regions of a grouped launch issued with fold=False (tulip_wgrad_group_regions)."""
+    ia = (_lib.WgradItem * max(len(items), 1))(*items)
+    out = (_lib.ReduceRegion * _lib.REDUCE_REGIONS_MAX)()
+    n = _lib.load().tulip_wgrad_group_regions(ia, len(items), _p(workspace), out, _lib.REDUCE_REGIONS_MAX)
+    check(min(n, 0), "tulip_wgrad_group_regions")
+    return [out[i] for i in range(n)]
 
 
 def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False, B=0, H=0, W=0):

@@ -97,6 +97,10 @@ class Trainer:
         # the fragment-major weight copies of the fused wide blocks (one ~25-us launch) are rewritten at the START of the
         # next step, beside the forward's first kernels, instead of on the chain behind AdamW (TULIP_PACK_AT_START=0: old)
         self.pack_at_step_start = os.environ.get("TULIP_PACK_AT_START", "1") != "0"
+        # without gradient accumulation the backward WRITES every gradient (one producer per parameter and step) instead of adding
+        # to a buffer AdamW has to clear: TulipEngine.grad_overwrite (TULIP_GRAD_OVERWRITE=0: accumulate + clear, as with accum_iter > 1)
+        self.grad_overwrite = (self.accum_iter == 1 and os.environ.get("TULIP_GRAD_OVERWRITE", "1") != "0"
+                               and self.eng.overwrite_supported(batch_size))
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
         # set before the first step (the choice is baked into the captured graphs)
         self.inject_drop_u: Optional[torch.Tensor] = None
@@ -137,13 +141,14 @@ class Trainer:
         eng.draw_drop_scales(P, self.model.training, self.inject_drop_u)
         eng.run_forward(P, pack_on_side=self.pack_at_step_start, defer_loss_final=True)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
-                         join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None)
+                         join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None,
+                         overwrite=self.grad_overwrite)
 
     def _adamw_range(self, lo: int, hi: int):
         W = self.eng.params
         ops.adamw(W.base32 + 4 * lo, self.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
                   self.v.data_ptr() + 4 * lo, W.base16 + 2 * lo, hi - lo, self.hyper,
-                  W.decay_mask.data_ptr() + lo // 64, zero_grad=True)
+                  W.decay_mask.data_ptr() + lo // 64, zero_grad=not self.grad_overwrite)
 
     def _cast_bucket_down(self, tag):
         """grad_dtype bf16: the bucket's gradients -> the bf16 exchange buffer (captured at the end of the bucket's graph
@@ -183,7 +188,7 @@ class Trainer:
         if self.track_grad_norm:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
-        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=True)
+        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=not self.grad_overwrite)
         if not self.pack_at_step_start:
             W.refresh_transposes()
 
