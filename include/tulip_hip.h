@@ -86,10 +86,21 @@ typedef struct tulip_wgrad_item {
     int ldy; int ldx; int Nw; int Kw; int Mtok; int splits;
     int overwrite;      /* 0: dW += ..., db += ... (autograd's accumulation); 1: dW = ..., db = ... (the caller guarantees this is the
                            only contribution of the step: the gradient buffer then needs no clearing) */
-    int reserved_;
+    int reserved_;      /* tulip_wgrad_group_adamw: 1 = apply the optimizer step in the write-out (see there); else 0 */
 } tulip_wgrad_item;
 int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
                       void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream);
+/* tulip_wgrad_group that also takes the optimizer step of the items marked reserved_ = 1 (and overwrite = 1, large tiles, no
+ * token split: the workgroup holds the complete gradient tile) in its write-out -- torch.optim.AdamW.step (main_lidar_upsampling.py:283)
+ * on fp32 master weights + bf16 shadow, same arithmetic as tulip_adamw, decoupled decay on -- instead of storing the gradient:
+ * param / exp_avg / exp_avg_sq / param_bf16 are flat buffers laid out like `grad` (an element is addressed by its gradient's
+ * offset from `grad`), hyper as in tulip_adamw.  The caller's end-of-step tulip_adamw must skip those tensors (mask bit 1).
+ * adam == NULL: exactly tulip_wgrad_group. */
+typedef struct tulip_adamw_ref {
+    const float* hyper; const float* grad; float* param; float* exp_avg; float* exp_avg_sq; uint16_t* param_bf16;
+} tulip_adamw_ref;
+int tulip_wgrad_group_adamw(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
+                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, hipStream_t stream);
 /* The fold regions tulip_wgrad_group(fold = 1) would hand to tulip_reduce_rows_multi for these items and this workspace (host
  * code only): for a caller that launches with fold = 0 and folds later, in one launch with regions that become ready in
  * between (the engine: the patch-embedding partial rows ride in the fold of the backward's last weight-gradient group).
@@ -282,8 +293,9 @@ int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscal
 
 /* Fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, main_lidar_upsampling.py:283):
  * hyper (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale}.
- * decay_mask64[i/64] != 0 selects weight decay for elements of 64-float block i/64 (timm's grouping,
- * main:282: decay only for ndim>1 parameters); NULL = decay everywhere.  Also refreshes the bf16 shadow.
+ * decay_mask64[i/64] bit 0 selects weight decay for elements of 64-float block i/64 (timm's grouping,
+ * main:282: decay only for ndim>1 parameters), bit 1 SKIPS the block (its step was taken elsewhere:
+ * tulip_wgrad_group_adamw); NULL = decay everywhere, skip nothing.  Also refreshes the bf16 shadow.
  * zero_grad != 0: g is cleared after it has been consumed (optimizer.zero_grad(), engine_upsampling.py:97). */
 int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
                 const uint8_t* decay_mask64, int zero_grad, hipStream_t stream);

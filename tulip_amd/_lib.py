@@ -44,6 +44,11 @@ class WgradItem(ctypes.Structure):
                 ("splits", I), ("overwrite", I), ("reserved_", I)]
 
 
+class AdamwRef(ctypes.Structure):
+    """tulip_adamw_ref (include/tulip_hip.h)."""
+    _fields_ = [(n, P) for n in ("hyper", "grad", "param", "exp_avg", "exp_avg_sq", "param_bf16")]
+
+
 class PackItem(ctypes.Structure):
     """tulip_pack_item (include/tulip_hip.h)."""
     _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I), ("transpose", I)]
@@ -85,6 +90,7 @@ SIGNATURES = {
     "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
     "tulip_wgrad_tiles": [I, I],
     "tulip_wgrad_group_regions": [P, I, P, P, I],
+    "tulip_wgrad_group_adamw": [P, I, P, I, P, L, I, P, P],
     "tulip_wgrad_set_mode": [I],
     "tulip_wgrad_set_profile": [P],
     "tulip_gemm_effective_splits": [I, I],

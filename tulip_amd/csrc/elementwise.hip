@@ -224,26 +224,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
                                                     const uint8_t* __restrict__ mask64, int zero_grad) {
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
-    const float bc1 = hyper[5], bc2 = hyper[6], gs = hyper[7];
-    const float decay_on = 1.0f - lr * wd;
-    const float step = lr / bc1;
-    const float rbc2 = rsqrtf(bc2);
+    const AdamwCoef cd = adamw_coef(hyper, true), cn = adamw_coef(hyper, false);
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float decay = (!mask64 || mask64[i >> 4]) ? decay_on : 1.0f;
+        const unsigned mk = mask64 ? mask64[i >> 4] : 1u;
+        if (mk & 2u) continue;                       // this block's step was taken in a weight-gradient write-out
         float4 pp = *(float4*)(p + i * 4);
         const float4 gg = *(const float4*)(g + i * 4);
         float4 mm = *(float4*)(m + i * 4), vv = *(float4*)(v + i * 4);
-        float* P = (float*)&pp; const float* G = (const float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gr = G[k] * gs;
-            M[k] = b1 * M[k] + (1.0f - b1) * gr;
-            V[k] = b2 * V[k] + (1.0f - b2) * gr * gr;
-            const float denom = sqrtf(V[k]) * rbc2 + eps;
-            P[k] = P[k] * decay - step * (M[k] / denom);
-        }
+        adamw_step4(pp, mm, vv, gg, (mk & 1u) ? cd : cn);
         *(float4*)(p + i * 4) = pp; *(float4*)(m + i * 4) = mm; *(float4*)(v + i * 4) = vv;
         if (zero_grad) *(float4*)(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pb) *(uint2*)(pb + i * 4) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));

@@ -418,7 +418,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             const int m = m0 + wm * (BM / 2) + i * 16 + li;
             if (m >= p.M) continue;
             if (p.epi == TULIP_EPI_SPLIT_F32) rs[(size_t)bz * p.M + m] = rsum[i][0];
-            else if (p.accumulate) rs[m] += rsum[i][0];
+            else if (p.accumulate & 1) rs[m] += rsum[i][0];
             else rs[m] = rsum[i][0];
         }
     }
@@ -458,13 +458,16 @@ __global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_group_kernel(co
 // fragments in registers (one wave per SIMD), 24 transpose reads for 36 MFMAs, and a third of the operand traffic.
 // GM x GN = 2 x 2 (192 x 192: every linear of stages 1-3), 4 x 1 (384 x 96) and 1 x 4 (96 x 384) for the C = 96 stage.
 // Each k-step's operands are [32 tokens][96 columns] sub-tiles in the k-slow LDS layout of Stage<96, true> (pitch 288 B).
+// AdamW in the write-out of an un-split weight gradient (tulip_wgrad_group_adamw): the flat fp32 gradient / parameter / moment
+// buffers share one layout, so an element's parameter, moments and bf16 shadow sit at the gradient's own offset from g0
+struct AdamRef { const float* hyper; const float* g0; float* p0; float* m0; float* v0; bf16_t* pb0; };
 constexpr int WG_SUB = 32 * T_PITCH;          // bytes of one sub-tile
 constexpr int WG_STG_PITCH = 96 * 4 + 16;     // fp32 write-out staging row
 constexpr int WG_LDS_BYTES = 2 * 5 * WG_SUB;  // double-buffered 4 x 1 stage (the 2 x 2 stage is 4 sub-tiles)
 
 template <int GM, int GN, int RING>
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, const int by, const int bz,
-                                           unsigned char* __restrict__ smem) {
+                                           unsigned char* __restrict__ smem, const AdamRef& ad) {
     static_assert(GM * GN == 4, "four compute waves");
     constexpr int SUBS = GM + GN;
     constexpr int STAGE = SUBS * WG_SUB;
@@ -647,11 +650,20 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
             if (m < p.M && n < p.N) {
                 float4 v = *(const float4*)(wst + rl * WG_STG_PITCH + c4 * 16);
                 float* o = obase + (size_t)m * p.ldo + n;
-                if (!split && p.accumulate) {
+                if (!split && (p.accumulate & 1)) {
                     const float4 q = *(const float4*)o;
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
-                *(float4*)o = v;
+                if (!split && (p.accumulate & 2)) {
+                    // the optimizer step of these four elements right here (adamw_step4, common.h: the same operations as
+                    // adamw_kernel; weights always decay): the gradient is never stored, the end-of-step AdamW skips the tensor
+                    const size_t idx = (size_t)(o - ad.g0);
+                    float4 pp = *(const float4*)(ad.p0 + idx), mm = *(const float4*)(ad.m0 + idx), vv = *(const float4*)(ad.v0 + idx);
+                    adamw_step4(pp, mm, vv, v, adamw_coef(ad.hyper, true));
+                    *(float4*)(ad.p0 + idx) = pp; *(float4*)(ad.m0 + idx) = mm; *(float4*)(ad.v0 + idx) = vv;
+                    *(uint2*)(ad.pb0 + idx) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
+                } else
+                    *(float4*)o = v;
             }
         }
     }
@@ -664,7 +676,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
             const int m = m0 + wm * 96 + li * 16 + g * 4 + e;
             if (m >= p.M) continue;
             if (split) rs[(size_t)bz * p.M + m] = rsum[e];
-            else if (p.accumulate) rs[m] += rsum[e];
+            else if (p.accumulate & 1) rs[m] += rsum[e];
             else rs[m] = rsum[e];
         }
     }
@@ -675,6 +687,7 @@ struct WgradGroup {
     int first[GROUP_MAX + 1];
     int gx[GROUP_MAX], gy[GROUP_MAX], shape[GROUP_MAX];
     int n;
+    AdamRef adam;
 };
 __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgradGroup G) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS_BYTES];
@@ -692,9 +705,9 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgradGroup G) {
     const int by = b / G.gx[i], bx = b - by * G.gx[i];
     const GemmArgs p = G.g[i];
     switch (G.shape[i]) {
-        case 0: wgrad_tile<2, 2, 4>(p, bx, by, bz, smem); break;
-        case 1: wgrad_tile<4, 1, 4>(p, bx, by, bz, smem); break;
-        default: wgrad_tile<1, 4, 4>(p, bx, by, bz, smem); break;
+        case 0: wgrad_tile<2, 2, 4>(p, bx, by, bz, smem, G.adam); break;
+        case 1: wgrad_tile<4, 1, 4>(p, bx, by, bz, smem, G.adam); break;
+        default: wgrad_tile<1, 4, 4>(p, bx, by, bz, smem, G.adam); break;
     }
 }
 
@@ -823,8 +836,24 @@ extern "C" int tulip_wgrad_tiles(int Nw, int Kw) {
     return gx * gy;
 }
 
+static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
+                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, hipStream_t stream);
+
 extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
                                  void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream) {
+    return wgrad_group_impl(items, n, extra, n_extra, workspace, workspace_bytes, fold, nullptr, stream);
+}
+
+extern "C" int tulip_wgrad_group_adamw(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
+                                       void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam,
+                                       hipStream_t stream) {
+    if (adam && (!adam->hyper || !adam->grad || !adam->param || !adam->exp_avg || !adam->exp_avg_sq || !adam->param_bf16))
+        return TULIP_ERR_ARG;
+    return wgrad_group_impl(items, n, extra, n_extra, workspace, workspace_bytes, fold, adam, stream);
+}
+
+static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
+                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, hipStream_t stream) {
     if (n < 0 || n > GROUP_MAX || n_extra < 0 || n + n + n_extra > TULIP_REDUCE_REGIONS_MAX || (n && !items) ||
         (n_extra && !extra))
         return TULIP_ERR_ARG;
@@ -865,6 +894,8 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
             ws_used += need;
         } else {
             p.epi = TULIP_EPI_F32; p.accumulate = it.overwrite ? 0 : 1; p.out = it.dW; p.out2 = it.db;
+            // reserved_ = 1: apply AdamW to this (un-split, large-tile, written-not-accumulated) weight gradient in the write-out
+            if (it.reserved_ == 1 && adam && big && it.overwrite) p.accumulate |= 2;
         }
         G.shape[G.n] = big ? wgrad_shape(it.Nw, it.Kw) : -1;
         wgrad_tile_grid(G.shape[G.n], it.Nw, it.Kw, &G.gx[G.n], &G.gy[G.n]);
@@ -875,6 +906,8 @@ extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tul
     if (G.n > 0) {
         const int blocks = G.first[G.n];
         if (big) {
+            G.adam = adam ? AdamRef{adam->hyper, adam->grad, adam->param, adam->exp_avg, adam->exp_avg_sq, (bf16_t*)adam->param_bf16}
+                          : AdamRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < G.n; ++i) G.g[i].aux = g_wgrad_prof;
             hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(512), 0, stream, G);
         } else {

@@ -900,7 +900,7 @@ class TulipEngine:
             items = []
         from . import _lib
         while items:
-            grp, used = [], 0
+            grp, used, any_adam = [], 0, False
             gmax = self.wgrad_group_max
             cand = items[:gmax]
             # (the large-tile kernel also needs whole 32-token k-steps: same test as tulip_wgrad_group, csrc/gemm.hip)
@@ -915,16 +915,23 @@ class TulipEngine:
                 if grp and used + need > ws_bytes:
                     break
                 used += need
-                grp.append(ops.wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, sp, overwrite=self.grad_overwrite))
+                # an un-split large-tile item holds its complete gradient tile in the write-out: the optimizer step can be taken there
+                elig = big and sp == 1 and self.grad_overwrite
+                if elig and self.adam_probe is not None:
+                    self.adam_probe.add(gout)
+                step_here = elig and self.adam_apply and gout in self.adam_fused
+                any_adam = any_adam or step_here
+                grp.append(ops.wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, sp, overwrite=self.grad_overwrite,
+                                          adamw=step_here))
                 items.pop(0)
             room = _lib.REDUCE_REGIONS_MAX - 2 * len(grp)
             if late and not items and len(regions) <= room:
                 # one group, folded in ONE launch behind the late event together with everything else of this flush
-                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False)
+                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False, adam=self.adam_ctx if any_adam else None)
                 regions = ops.wgrad_group_regions(grp, ws) + regions
                 break
             extra, regions = regions[:room], regions[room:]
-            ops.wgrad_group(grp, extra, ws, ws_bytes)
+            ops.wgrad_group(grp, extra, ws, ws_bytes, adam=self.adam_ctx if any_adam else None)
         for ev in late:
             torch.cuda.current_stream().wait_event(ev)
         while regions:
@@ -1172,6 +1179,13 @@ class TulipEngine:
     # -- AdamW does not write 4 B per parameter of zeros, and the un-split weight gradients of the deep stages (66 MB) are stored
     # instead of read-modify-written.  Not with the stand-alone LayerNorm parameter pass (C > 2048: tulip_large), which adds.
     grad_overwrite = False
+    # The optimizer step of un-split weight gradients in their write-out (Trainer.fuse_adamw): adam_ctx = ops.adamw_ref of the
+    # Trainer's flat buffers, adam_fused = the gradient addresses it applies to, adam_apply = this backward is an optimizer
+    # step; adam_probe (a set) collects the eligible addresses during the Trainer's eager warm-up pass.
+    adam_ctx = None
+    adam_fused = frozenset()
+    adam_apply = False
+    adam_probe = None
 
     def overwrite_supported(self, B: int) -> bool:
         m = self.model
@@ -1181,7 +1195,7 @@ class TulipEngine:
                     and all(ops.layernorm_bwd_partial_rows(64, C) > 0 for C in widths))
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
-                     join_tags=None, overwrite: bool = False):
+                     join_tags=None, overwrite: bool = False, apply_adamw: bool = False):
         """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
         (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
         each parameter group has been *launched* (DDP overlap)."""
@@ -1190,6 +1204,7 @@ class TulipEngine:
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
         self.grad_overwrite = bool(overwrite)
+        self.adam_apply = bool(apply_adamw and overwrite and self.adam_ctx is not None)
         if self._loss_final is not None:             # the loss read-out of run_forward(defer_loss_final=True): off the chain
             self._side(self._loss_final)
             self._loss_final = None

@@ -95,8 +95,13 @@ def reduce_region(part, stride, out, n, rows, overwrite=False, scatter_index=Non
                              scatter_len)
 
 
-def wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, dW, db=None, splits=1, overwrite=False):
-    return _lib.WgradItem(_p(dY), _p(X), _p(dW), _p(db), ldy, ldx, Nw, Kw, Mtok, splits, int(overwrite), 0)
+def wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, dW, db=None, splits=1, overwrite=False, adamw=False):
+    return _lib.WgradItem(_p(dY), _p(X), _p(dW), _p(db), ldy, ldx, Nw, Kw, Mtok, splits, int(overwrite), int(adamw))
+
+
+def adamw_ref(hyper, grad, param, exp_avg, exp_avg_sq, param_bf16):
+    """tulip_adamw_ref: the flat buffers tulip_wgrad_group_adamw steps in (all laid out like `grad`)."""
+    return _lib.AdamwRef(_p(hyper), _p(grad), _p(param), _p(exp_avg), _p(exp_avg_sq), _p(param_bf16))
 
 
 def reduce_rows_multi(regions):
@@ -121,12 +126,17 @@ def wgrad_set_profile(stamps):
     _lib.load().tulip_wgrad_set_profile(_p(stamps))
 
 
-def wgrad_group(items, extra, workspace, workspace_bytes, fold=True):
-    """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions."""
+def wgrad_group(items, extra, workspace, workspace_bytes, fold=True, adam=None):
+    """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions.
+    adam (ops.adamw_ref): items built with adamw=True take their optimizer step in the write-out (tulip_wgrad_group_adamw)."""
     ia = (_lib.WgradItem * max(len(items), 1))(*items)
     ea = (_lib.ReduceRegion * max(len(extra), 1))(*extra)
-    check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, int(fold),
-                                        _stream()), "tulip_wgrad_group")
+    if adam is None:
+        check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, int(fold),
+                                            _stream()), "tulip_wgrad_group")
+    else:
+        check(_lib.load().tulip_wgrad_group_adamw(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, int(fold),
+                                                  ctypes.byref(adam), _stream()), "tulip_wgrad_group_adamw")
 
 
 def wgrad_group_regions(items, workspace):

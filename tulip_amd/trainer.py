@@ -101,6 +101,15 @@ class Trainer:
         # to a buffer AdamW has to clear: TulipEngine.grad_overwrite (TULIP_GRAD_OVERWRITE=0: accumulate + clear, as with accum_iter > 1)
         self.grad_overwrite = (self.accum_iter == 1 and os.environ.get("TULIP_GRAD_OVERWRITE", "1") != "0"
                                and self.eng.overwrite_supported(batch_size))
+        # ... and where a weight-gradient workgroup holds a tensor's COMPLETE gradient tile (no token split: the deep stages, 90 %
+        # of the parameters), the optimizer step is taken right there, in the write-out, beside the backward instead of behind it
+        # (TULIP_FUSE_ADAMW=0: one AdamW launch over everything at the end of the step).  Captured steps on one GPU only: a
+        # gradient all-reduce, the gradient-norm read-out and accumulation need the gradients themselves.
+        self.fuse_adamw = (self.grad_overwrite and use_graph and not self.segmented and not track_grad_norm
+                           and os.environ.get("TULIP_FUSE_ADAMW", "1") != "0")
+        self._adam_mask = None
+        self.fused_adamw_params = 0
+        self._fuse_adamw_skip = tuple(x for x in os.environ.get("TULIP_FUSE_ADAMW_SKIP", "").split(",") if x)   # dev: name prefixes
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
         # set before the first step (the choice is baked into the captured graphs)
         self.inject_drop_u: Optional[torch.Tensor] = None
@@ -135,14 +144,14 @@ class Trainer:
             self._hyper_events[k] = torch.cuda.Event()
         self._hyper_events[k].record()
 
-    def _fwd_bwd(self, hook, update: bool = True):
+    def _fwd_bwd(self, hook, update: bool = True, apply_adamw: bool = False):
         eng, P = self.eng, self.P
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training, self.inject_drop_u)
         eng.run_forward(P, pack_on_side=self.pack_at_step_start, defer_loss_final=True)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None,
-                         overwrite=self.grad_overwrite)
+                         overwrite=self.grad_overwrite, apply_adamw=apply_adamw)
 
     def _adamw_range(self, lo: int, hi: int):
         W = self.eng.params
@@ -188,7 +197,8 @@ class Trainer:
         if self.track_grad_norm:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
-        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, W.decay_mask, zero_grad=not self.grad_overwrite)
+        mask = self._adam_mask if self._adam_mask is not None else W.decay_mask       # (bit 1: stepped in a weight-gradient write-out)
+        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, mask, zero_grad=not self.grad_overwrite)
         if not self.pack_at_step_start:
             W.refresh_transposes()
 
@@ -228,6 +238,25 @@ class Trainer:
             self._segments = None          # the seed is a launch argument baked into the captured graphs: re-capture
         self.eng._drop_counter.fill_(int(sd["drop_counter"]))
         W.shadow_dirty = True          # the model's own load_state_dict normally precedes this; refresh either way
+
+    def _plan_fused_adamw(self, eligible):
+        """Which tensors take their optimizer step in a weight-gradient write-out: the un-split large-tile items the warm-up
+        pass saw, except weights the backward reads again AFTER their gradient is complete (the skip Linears: the x_save half
+        of their input gradient is formed when the encoder stage is reached, see FlatParams._completion_order)."""
+        W = self.eng.params
+        gbase = self.g.data_ptr()
+        fused, mask = set(), W.decay_mask.clone()
+        for n in W.names:
+            ptr = gbase + 4 * W.offset[n]
+            if (ptr in eligible and not n.startswith("skip_connection_layers.") and len(W.shape[n]) > 1
+                    and not any(n.startswith(x) for x in self._fuse_adamw_skip)):
+                fused.add(ptr)
+                mask[W.offset[n] // 64:(W.offset[n] + W.numel[n] + 63) // 64] |= 2
+        if fused:
+            self.eng.adam_fused = frozenset(fused)
+            self.eng.adam_ctx = ops.adamw_ref(self.hyper, self.g, W.flat, self.m, self.v, W.shadow)
+            self._adam_mask = mask
+            self.fused_adamw_params = sum(W.numel[n] for n in W.names if gbase + 4 * W.offset[n] in fused)
 
     # ------------------------------------------------------------------ torch.optim.AdamW <-> fused AdamW state
     def _param_names_by_ptr(self):
@@ -303,7 +332,7 @@ class Trainer:
                     cur = torch.cuda.CUDAGraph()
                     cur.capture_begin(capture_error_mode="thread_local")
 
-            self._fwd_bwd(hook, update)
+            self._fwd_bwd(hook, update, apply_adamw=update and self._adam_mask is not None)
             if not update:
                 cur.capture_end()
                 segs.append((cur, None))
@@ -377,7 +406,12 @@ class Trainer:
             # load every kernel once outside capture, without touching parameters, optimizer state, the gradients of an
             # open accumulation window or the DropPath stream (the pass below accumulates into g and draws once)
             keep_g, keep_c = self.g.clone(), self.eng._drop_counter.clone()
+            if self.fuse_adamw:
+                self.eng.adam_probe = set()
             self._fwd_bwd(lambda tag: None)
+            if self.fuse_adamw:
+                self._plan_fused_adamw(self.eng.adam_probe)
+                self.eng.adam_probe = None
             scratch = torch.zeros(64, dtype=torch.float32, device=self.device)
             ops.adamw(scratch, scratch.clone(), scratch.clone(), scratch.clone(), None, 64, self.hyper, None)
             ops.grad_norm(scratch, 64, self._norm_part, self.grad_norm)
