@@ -157,7 +157,7 @@ def kernel_rooflines(trainer, reps=5):
         rec.append(("gemm", name, lambda: real["gemm"](A, B, M, N, K, **kw), f, by, by))
         real["gemm"](A, B, M, N, K, **kw)
 
-    def wgrad_group(items, extra, ws, ws_bytes, fold=True):
+    def wgrad_group(items, extra, ws, ws_bytes, fold=True, adam=None):
         items = list(items)
         f = by = slab = 0.0
         tiles, deep = 0, True
@@ -168,6 +168,10 @@ def kernel_rooflines(trainer, reps=5):
             deep = deep and kchunk >= 256
             f += 2.0 * it.Nw * it.Kw * it.Mtok
             by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw + 4.0 * it.Nw      # operands once, fp32 dW + db once
+            if it.dW in trainer.eng.adam_fused:
+                # in the step this item's write-out takes the AdamW step (Trainer.fuse_adamw): parameter + two moments read and
+                # written, bf16 shadow written, the gradient itself never stored (26 B instead of 4 B per element)
+                by += 22.0 * it.Nw * it.Kw
             slab += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * (it.Nw * it.Kw + it.Nw) * eff      # what the launch writes: slabs
         ksub = 4 if (tiles <= 400 and deep) else 1
         big = all(ops.wgrad_tiles(it.Nw, it.Kw) != -(-it.Nw // 64) * -(-it.Kw // 96) and it.Mtok % 32 == 0 for it in items)
@@ -175,7 +179,7 @@ def kernel_rooflines(trainer, reps=5):
         rec.append(("wgrad", "wgrad_group_kernel (192x192 / 384x96 / 96x384 tiles)" if big
                     else f"gemm_group_kernel<64, true, true, {ksub}>",
                     lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False), f, by, slab))
-        real["wgrad_group"](items, extra, ws, ws_bytes, fold)
+        real["wgrad_group"](items, extra, ws, ws_bytes, fold, adam)
 
     def block(name, fam, bwd, C_of):
         def f(*a, **kw):

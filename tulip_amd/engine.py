@@ -400,6 +400,9 @@ class TulipEngine:
             if sp.slot >= 0:
                 rates[sp.slot] = rates[sp.slot + 1] = 1.0 - sp.rate
         self._keep = rates.to(device)
+        # fused blocks behind which the queued side work is flushed at once instead of at the end of their stage (dev knob:
+        # TULIP_FLUSH_AFTER = comma-separated block prefixes)
+        self.flush_after = frozenset(x for x in os.environ.get("TULIP_FLUSH_AFTER", "").split(",") if x)
         nearly = int(os.environ.get("TULIP_EARLY_FLUSH_BLOCKS", "1"))
         # backward order ends with encoder stage 0, block 1 then block 0
         self.early_flush = frozenset(sp.prefix for sp in self.enc_blocks[0][:nearly])
@@ -1098,7 +1101,7 @@ class TulipEngine:
             if self._lagged_hook is not None:
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
-            if self.flush_per_block:
+            if self.flush_per_block or sp.prefix in self.flush_after:
                 self._flush_wgrads()
             return
         # ---- MLP branch (tulip.py:346-351)
