@@ -278,25 +278,28 @@ def test_training_is_bit_reproducible_at_the_bench_configuration():
     assert torch.equal(res[0][0], res[1][0]), "parameters differ between two identical runs"
 
 
-def test_optimizer_step_in_the_weight_gradient_write_out_is_the_same_step():
+@pytest.mark.parametrize("model,img,target,batch", [("tulip_base", (16, 1024), (64, 1024), 8), ("tulip_large", (16, 2048), (64, 2048), 2)])
+def test_optimizer_step_in_the_weight_gradient_write_out_is_the_same_step(model, img, target, batch):
     """Trainer.fuse_adamw: tensors whose weight-gradient workgroups hold the complete gradient tile (no token split: ~90 % of
     tulip_base's parameters at the bench configuration) take their AdamW step in that kernel's write-out instead of in the
     launch at the end of the step.  Same operations (adamw_step4, csrc/common.h), so parameters, moments, the bf16 shadow
-    and every loss must equal the unfused run bit for bit -- which also proves that no fused tensor is read by the backward
-    after it has been stepped."""
+    and every loss must equal the run with gradients accumulated, cleared and stepped at the end (grad_overwrite and
+    fuse_adamw off) bit for bit -- which also proves that no fused tensor is read by the backward after it has been stepped,
+    and that every gradient element has exactly one producer.  tulip_large: the backup window, C = 1536 and the stand-alone
+    LayerNorm parameter pass (C > 2048), whose two ranges the overwrite mode has to clear itself."""
     import argparse
     import bench
     from tulip_amd.trainer import Trainer
-    a = argparse.Namespace(model="tulip_base", img=[16, 1024], target=[64, 1024], batch=8)
+    a = argparse.Namespace(model=model, img=list(img), target=list(target), batch=batch)
     res = []
     for fuse in (True, False):
         m = bench.make_model(a).to(DEV).train()
-        tr = Trainer(m, 8)
+        tr = Trainer(m, batch)
         assert tr.fuse_adamw and tr.grad_overwrite
-        tr.fuse_adamw = fuse
+        tr.fuse_adamw = tr.grad_overwrite = fuse
         lo, hi = bench.synthetic(a, 0, torch.device(DEV))
         tr.load_batch(lo, hi)
-        ls = torch.stack([tr.step().clone() for _ in range(12)])
+        ls = torch.stack([tr.step().clone() for _ in range(8)])
         torch.cuda.synchronize()
         W = tr.eng.params
         assert (tr.fused_adamw_params > 0.8 * sum(W.numel[n] for n in W.names)) == fuse

@@ -1034,6 +1034,10 @@ class TulipEngine:
         cb, cs, ct = cast if cast is not None else (None, None, 1)
         nrows = ops.layernorm_bwd_partial_rows(rows, C)
         if nrows == 0:  # C > 2048 (tulip_large's deepest PatchMerging norm): stand-alone parameter pass
+            if self.grad_overwrite:      # that pass ADDS: the two ranges are cleared here instead of by AdamW
+                g0 = self._gflat.data_ptr()
+                for ptr in (gw, gb):
+                    self._gflat[(ptr - g0) // 4:(ptr - g0) // 4 + C].zero_()
             ops.layernorm_bwd_params(dy, x, mean, rstd, gw, gb, rows, C, merge=merge, B=P.B, H=H, W=W)
             ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, rows, C, merge=merge, B=P.B, H=H, W=W,
                               dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct)
@@ -1180,7 +1184,7 @@ class TulipEngine:
     # Gradients are WRITTEN, not accumulated (run_backward(overwrite=True), the Trainer with accum_iter == 1): every parameter has
     # exactly one producer per backward (a weight-gradient item or a fold region), so the flat gradient buffer needs no clearing
     # -- AdamW does not write 4 B per parameter of zeros, and the un-split weight gradients of the deep stages (66 MB) are stored
-    # instead of read-modify-written.  Not with the stand-alone LayerNorm parameter pass (C > 2048: tulip_large), which adds.
+    # instead of read-modify-written.  (The stand-alone LayerNorm parameter pass for C > 2048 adds: its two ranges are cleared first.)
     grad_overwrite = False
     # The optimizer step of un-split weight gradients in their write-out (Trainer.fuse_adamw): adam_ctx = ops.adamw_ref of the
     # Trainer's flat buffers, adam_fused = the gradient addresses it applies to, adam_apply = this backward is an optimizer
@@ -1191,11 +1195,7 @@ class TulipEngine:
     adam_probe = None
 
     def overwrite_supported(self, B: int) -> bool:
-        m = self.model
-        E, nl = m.embed_dim, m.num_layers
-        widths = [E << s for s in range(nl)] + [4 * (E << s) for s in range(nl - 1)]
-        return bool(self.group_wgrad and self.overlap_wgrad
-                    and all(ops.layernorm_bwd_partial_rows(64, C) > 0 for C in widths))
+        return bool(self.group_wgrad and self.overlap_wgrad)
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
                      join_tags=None, overwrite: bool = False, apply_adamw: bool = False):
@@ -1207,6 +1207,7 @@ class TulipEngine:
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
         self.grad_overwrite = bool(overwrite)
+        self._gflat = gflat
         self.adam_apply = bool(apply_adamw and overwrite and self.adam_ctx is not None)
         if self._loss_final is not None:             # the loss read-out of run_forward(defer_loss_final=True): off the chain
             self._side(self._loss_final)
