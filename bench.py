@@ -63,12 +63,14 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
     eff = ops.gemm_effective_splits(K, splits)
     kchunk = -(-(-(-K // eff)) // 32) * 32
     gn = -(-N // 96)
-    if -(-M // 128) * gn * eff < 2048 or M <= 64:
+    t128, t256 = -(-M // 128) * gn * eff, -(-M // 256) * gn * eff
+    bm = 64 if (t128 < 512 or M <= 64) else 128
+    if t256 >= 512 and gn >= 32:
+        bm = 256
+    ksub = 1
+    if bm == 64:
         grid = gn * -(-M // 64) * eff
         ksub = 4 if (grid <= 400 and kchunk >= 256) else 1
-        bm = 64
-    else:
-        bm, ksub = 128, 1
     t = lambda f: "true" if f else "false"
     return f"gemm_kernel<{bm}, {t(a_trans)}, {t(b_trans)}, {ksub}>"
 

@@ -56,7 +56,7 @@ struct GemmArgs {
 int gemm_touch_on = 1;
 
 // launch heuristics (compile-time; mirrored by bench.py's kernel-name bookkeeping)
-#define TULIP_GEMM_BIG_TILES 2048   // 128-row tiles only for launches with at least this many of them
+#define TULIP_GEMM_MID_TILES 512    // taller tiles only while the launch still has this many of them (two rounds of the chip)
 #define TULIP_GEMM_KSUB_GRID 400    // 128-deep k stages for grids up to this many workgroups
 #ifndef TULIP_WGRAD_RING
 #define TULIP_WGRAD_RING 3
@@ -386,15 +386,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // row) instead of 8-B pieces scattered over 16 rows per instruction -- the MFMA-layout stores were the
     // bottleneck of every output-heavy GEMM here.  64 rows per pass (the fp32 tile is 25 KiB).
     constexpr int NPASS = BM / 64;
+    constexpr int PPW = NPASS > 1 ? NPASS / 2 : 1;      // passes per wave row: a pass holds 64 rows = 4 fragments of ONE wave row
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        if (NPASS == 1 || wm == ps) {
+        if (NPASS == 1) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int rl = (NPASS == 1 ? wm * (BM / 2) : 0) + i * 16 + li;
+                const int rl = wm * (BM / 2) + i * 16 + li;
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     *(f32x4*)(smem + rl * STG_PITCH + (wn * 48 + j * 16 + g * 4) * 4) = acc[i][j];
+            }
+        } else if (wm == ps / PPW) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int rl = ii * 16 + li;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *(f32x4*)(smem + rl * STG_PITCH + (wn * 48 + j * 16 + g * 4) * 4) = acc[(ps % PPW) * 4 + ii][j];
             }
         }
         __syncthreads();
@@ -738,14 +747,23 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
     // 64-row tiles unless the launch already has thousands of 128-row tiles: at B=8 every GEMM of this model
     // is latency-bound per workgroup, and twice as many half-size workgroups in flight measured 4 % faster
     // end to end
-    const bool small = ((p.M + 127) / 128) * gn * splits < TULIP_GEMM_BIG_TILES;
-    if (small || p.M <= 64) {
+    // Tile height by the tiles the launch would have (tools/gemm_big.py, isolated, TFLOP/s at 64 / 128 / 256 rows): 4096x2304x768
+    // 355 / 492 / 453, 4096x3072x768 441 / 461 / 529, 2048x6144x1536 519 / 555 / 704, 8192x2304x768 461 / 580 / 536, the N = 768
+    // data gradients (K = 2304..6144) 287-312 / 261-297 / same: taller tiles only while at least two rounds of the chip remain,
+    // 256 rows only for wide outputs (>= 32 column tiles).  Every GEMM of the batch-8 step stays on 64 rows.
+    const int t128 = ((p.M + 127) / 128) * gn * splits, t256 = ((p.M + 255) / 256) * gn * splits;
+    int bm = (t128 < TULIP_GEMM_MID_TILES || p.M <= 64) ? 64 : 128;
+    if (t256 >= TULIP_GEMM_MID_TILES && gn >= 32) bm = 256;
+    if (bm == 64) {
         dim3 grid(gn, (p.M + 63) / 64, splits);
         // 128-deep k stages (80-150 KB LDS, 1-2 workgroups/CU) pay while the grid is at most ~1.5 waves of the chip
         if ((int)(grid.x * grid.y * grid.z) <= TULIP_GEMM_KSUB_GRID && p.kchunk >= 256)
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 4>), grid, dim3(256), 0, stream, p);
         else
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
+    } else if (bm == 256) {
+        dim3 grid(gn, (p.M + 255) / 256, splits);
+        hipLaunchKernelGGL((gemm_kernel<256, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
     } else {
         dim3 grid(gn, (p.M + 127) / 128, splits);
         hipLaunchKernelGGL((gemm_kernel<128, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
@@ -951,4 +969,7 @@ extern "C" int tulip_wgrad_group_regions(const tulip_wgrad_item* items, int n, v
     return nf;
 }
 
-extern "C" int tulip_gemm_set_touch(int on) { gemm_touch_on = on ? 1 : 0; return TULIP_OK; }
+extern "C" int tulip_gemm_set_touch(int on) {
+    gemm_touch_on = on ? 1 : 0;
+    return TULIP_OK;
+}
