@@ -210,9 +210,12 @@ def kernel_rooflines(trainer, reps=5):
         for n in patched:
             setattr(ops, n, real[n])
     W = trainer.eng.params
+    # the end-of-step AdamW launch as the step issues it: tensors stepped in a weight-gradient write-out are masked out
+    amask = trainer._adam_mask if trainer._adam_mask is not None else W.decay_mask
+    n_adam = W.total - trainer.fused_adamw_params
     rec.append(("adamw", "adamw_kernel",
-                lambda: ops.adamw(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, W.total, trainer.hyper, W.decay_mask,
-                                  zero_grad=True), 0.0, 30.0 * W.total, 30.0 * W.total))
+                lambda: ops.adamw(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, W.total, trainer.hyper, amask,
+                                  zero_grad=not trainer.grad_overwrite), 0.0, 30.0 * n_adam, 30.0 * n_adam))
     fams, detail = {}, {}
     for fam, name, call, fl, by, by2 in rec:
         call()
@@ -234,7 +237,8 @@ def kernel_rooflines(trainer, reps=5):
         "gemm": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv forward and data gradient outside the fused blocks)",
         "swin96_fwd": "swin96_fwd_kernel (whole C=96 Swin block, forward)", "swin96_bwd": "swin96_bwd_kernel",
         "swinw_fwd": "swinw_fwd_kernel<C,G> (whole C=192/384 Swin block, forward)", "swinw_bwd": "swinw_bwd_kernel<C,G>",
-        "adamw": "adamw_kernel (fp32 master + moments + bf16 shadow, 30 B / parameter)"}
+        "adamw": "adamw_kernel (fp32 master + moments + bf16 shadow, 30 B / parameter; only the tensors whose step was not taken in "
+                 "a weight-gradient write-out)"}
     out = []
     for fam, (n, t, fl, by, by2) in fams.items():
         ai = fl / by
