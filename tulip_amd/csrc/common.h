@@ -62,11 +62,12 @@ __device__ __forceinline__ void adamw_step4(float4& pp, float4& mm, float4& vv, 
 }
 
 // A bf16 MFMA operand that was JUST packed by vector-ALU instructions (v_cvt_pk_bf16_f32 behind an fma): pin 8 wait states
-// between the pack and the MFMA that reads it.  Measured on gfx950 / ROCm 7.2 (tools/det_tail_instep.py): without them the
-// head's weight-gradient kernel returned, about once in 200 launches inside the training step (never in isolation: it takes
-// another wave's instructions in the SIMD's issue slots), one 16-channel block of a slab that differed in the 5th digit -- an
-// MFMA had read its B operand before the conversion's result had landed; no such hazard is known to the compiler.  The in/out
-// operand makes the nops a data dependence between the pack and its consumer, so they cannot be scheduled away.
+// between the pack and the MFMAs that read it.  Measured on gfx950 / ROCm 7.2 (tools/det_tail_instep.py): without them the
+// head's weight-gradient kernel returned, about once in 200 launches INSIDE the training step (never in isolation), one
+// 16-channel block of a slab that differed in the 5th digit.  The cause is not pinned down further (other kernels have the
+// same pack -> MFMA distance and are reproducible); this fence, or a compare/select form of the arithmetic in front of the
+// pack, each made 800 repeats bit-identical.  The in/out operand makes the nops a data dependence between the pack and its
+// consumer, so they cannot be scheduled away.
 __device__ __forceinline__ bf16x8 mfma_operand_fence(bf16x8 v) {
     typedef uint32_t u32x4_f __attribute__((ext_vector_type(4)));
     u32x4_f t = __builtin_bit_cast(u32x4_f, v);

@@ -644,6 +644,8 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     unsigned char* wst = smem + wid * (32 * WG_STG_PITCH);
     const bool split = p.epi == TULIP_EPI_SPLIT_F32;
     float* obase = (float*)p.out + (split ? (size_t)bz * p.M * p.ldo : 0);
+    const bool step_here = !split && (p.accumulate & 2);               // (uniform) AdamW in the write-out, see AdamRef
+    const AdamwCoef cf = step_here ? adamw_coef(ad.hyper, true) : AdamwCoef{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < 3; ++ps) {
 #pragma unroll
@@ -651,6 +653,39 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 *(f32x4*)(wst + (ii * 16 + li) * WG_STG_PITCH + (j * 16 + g * 4) * 4) = acc[ps * 2 + ii][j];
+        if (step_here) {
+            // the optimizer step of this tile right here (adamw_step4, common.h: the same operations as adamw_kernel; weights
+            // always decay): the gradient is never stored, the end-of-step AdamW skips the tensor.  Parameter and moments of FOUR
+            // pieces are fetched before the first is stepped -- twelve loads in flight per lane instead of three: one piece at a
+            // time the write-out was a chain of 36 memory latencies per wave (the deep stage's group 243 us in the step).
+#pragma unroll
+            for (int it0 = 0; it0 < 12; it0 += 4) {
+                float4 pp[4], mm[4], vv[4];
+                size_t idx[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = lane + (it0 + u) * 64;
+                    const int rl = c / 24, c4 = c - rl * 24;
+                    const int m = m0 + wm * 96 + ps * 32 + rl, n = n0 + wn * 96 + c4 * 4;
+                    ok[u] = m < p.M && n < p.N;
+                    idx[u] = ok[u] ? (size_t)((obase + (size_t)m * p.ldo + n) - ad.g0) : 0;
+                    pp[u] = *(const float4*)(ad.p0 + idx[u]); mm[u] = *(const float4*)(ad.m0 + idx[u]); vv[u] = *(const float4*)(ad.v0 + idx[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = lane + (it0 + u) * 64;
+                    const int rl = c / 24, c4 = c - rl * 24;
+                    if (ok[u]) {
+                        const float4 v = *(const float4*)(wst + rl * WG_STG_PITCH + c4 * 16);
+                        adamw_step4(pp[u], mm[u], vv[u], v, cf);
+                        *(float4*)(ad.p0 + idx[u]) = pp[u]; *(float4*)(ad.m0 + idx[u]) = mm[u]; *(float4*)(ad.v0 + idx[u]) = vv[u];
+                        *(uint2*)(ad.pb0 + idx[u]) = make_uint2(pack_bf16x2(pp[u].x, pp[u].y), pack_bf16x2(pp[u].z, pp[u].w));
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 12; ++it) {
             const int c = lane + it * 64;
@@ -663,16 +698,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
                     const float4 q = *(const float4*)o;
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
-                if (!split && (p.accumulate & 2)) {
-                    // the optimizer step of these four elements right here (adamw_step4, common.h: the same operations as
-                    // adamw_kernel; weights always decay): the gradient is never stored, the end-of-step AdamW skips the tensor
-                    const size_t idx = (size_t)(o - ad.g0);
-                    float4 pp = *(const float4*)(ad.p0 + idx), mm = *(const float4*)(ad.m0 + idx), vv = *(const float4*)(ad.v0 + idx);
-                    adamw_step4(pp, mm, vv, v, adamw_coef(ad.hyper, true));
-                    *(float4*)(ad.p0 + idx) = pp; *(float4*)(ad.m0 + idx) = mm; *(float4*)(ad.v0 + idx) = vv;
-                    *(uint2*)(ad.pb0 + idx) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
-                } else
-                    *(float4*)o = v;
+                *(float4*)o = v;
             }
         }
     }
