@@ -42,7 +42,7 @@ def no_side(eng):
 def no_folds(eng):
     from tulip_amd import ops
     real = ops.wgrad_group
-    ops.wgrad_group = lambda items, extra, ws, ws_bytes, fold=True: real(items, [], ws, ws_bytes, fold=False)
+    ops.wgrad_group = lambda items, extra, ws, ws_bytes, fold=True, adam=None: real(items, [], ws, ws_bytes, fold=False, adam=adam)
     ops.reduce_rows_multi = lambda *a, **k: None
 
 
