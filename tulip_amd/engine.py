@@ -1389,6 +1389,59 @@ class TulipEngine:
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge
+    # The reference's calling convention -- model(lo, hi) under autocast, loss.backward(), a foreign optimizer
+    # (engine_upsampling.py:77-80, misc.py:295) -- issues the same ~115 launches per direction from Python through ctypes:
+    # ~3 ms of host time per step against 2 ms of GPU work.  The two launch sequences are fixed per (batch size, train / eval),
+    # so the module path replays them from HIP graphs as well: first call eager (loads kernels, sizes lazy buffers), second call
+    # captures, later calls replay.  TULIP_GRAPH_MODULE=0: eager launches every time.
+    graph_module = os.environ.get("TULIP_GRAPH_MODULE", "1") != "0"
+
+    def _module_sequence(self, P: Plan, key, fn):
+        graphs = P.__dict__.setdefault("_module_graphs", {})
+        ent = graphs.get(key)
+        if not self.graph_module or ent is None:
+            fn()
+            graphs[key] = "warm"
+            return
+        if ent == "warm":
+            cur = torch.cuda.current_stream()
+            cap = torch.cuda.Stream(device=self.device)
+            cap.wait_stream(cur)
+            with torch.cuda.stream(cap):
+                ent = torch.cuda.CUDAGraph()
+                ent.capture_begin(capture_error_mode="thread_local")
+                fn()
+                ent.capture_end()
+            cur.wait_stream(cap)
+            graphs[key] = ent
+        ent.replay()
+
+    def _module_forward(self, P: Plan):
+        train = bool(self.model.training)
+
+        def seq():
+            self.params.shadow_dirty = True      # a foreign optimizer may have written the parameters: the cast + pack are part
+            self.draw_drop_scales(P, train)      # of the sequence (and of its graph)
+            self.run_forward(P)
+        self._module_sequence(P, ("fwd", train, self.attn_fp8), seq)
+        P.generation += 1
+
+    def _module_backward(self, P: Plan, dloss):
+        W_ = self.params
+        if not hasattr(P, "_mod_gflat"):
+            P._mod_gflat = torch.zeros(W_.total, dtype=torch.float32, device=self.device)
+            P._mod_gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        if dloss is None:
+            P._mod_gscale.fill_(1.0)
+        else:
+            P._mod_gscale.copy_(dloss.detach().reshape(1))
+        over = self.overwrite_supported(P.B)      # every gradient element has one producer: nothing to clear between calls
+        if not over:
+            P._mod_gflat.zero_()
+        self._module_sequence(P, ("bwd", self.attn_fp8),
+                              lambda: self.run_backward(P, P._mod_gflat, gscale_dev=P._mod_gscale, gscale=1.0, overwrite=over))
+        return P._mod_gflat.clone()               # (autograd may keep the returned tensors as .grad: never the static buffer)
+
     def autograd_forward(self, x, target, mc_drop: bool):
         self.bind(x.device)
         self.params.shadow_dirty = True  # parameters may have been updated by a foreign optimizer
@@ -1400,9 +1453,9 @@ class TulipEngine:
             self.run_forward(P, with_loss=False)
             return P.pred.clone()
         P.target.copy_(target.reshape(P.target.shape).float())
-        self.draw_drop_scales(P, self.model.training)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
         if not need_grad:
+            self.draw_drop_scales(P, self.model.training)
             self.run_forward(P)
             return P.pred.clone(), P.losses[0].clone(), P.losses[1].clone()
         params = [p for _, p in sorted(self.model.named_parameters(), key=lambda kv: self.params.offset[kv[0]])]
@@ -1414,7 +1467,7 @@ class _TulipFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: TulipEngine, P: Plan, *params):
-        eng.run_forward(P)
+        eng._module_forward(P)
         ctx.eng, ctx.P, ctx.gen = eng, P, P.generation
         pred, pixel = P.pred.clone(), P.losses[1].clone()
         # only total_loss carries a gradient (the reference back-propagates total_loss alone, misc.py:295); anything
@@ -1429,8 +1482,6 @@ class _TulipFn(torch.autograd.Function):
             raise RuntimeError("tulip_amd: backward() must follow its own forward() (activation workspaces are "
                                "reused by the next forward of the same batch size)")
         W_ = eng.params
-        gflat = torch.zeros(W_.total, dtype=torch.float32, device=eng.device)
-        g = dloss.detach().float().reshape(1).contiguous() if dloss is not None else None
-        eng.run_backward(P, gflat, gscale_dev=g, gscale=1.0)
+        gflat = eng._module_backward(P, dloss)
         grads = tuple(gflat[W_.offset[n]:W_.offset[n] + W_.numel[n]].view(W_.shape[n]) for n in W_.names)
         return (None, None) + grads
