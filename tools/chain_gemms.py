@@ -32,10 +32,16 @@ torch.cuda.synchronize()
 rows = collections.OrderedDict()
 for M, N, K, kw, call in rec:
     call()
+    torch.cuda.synchronize()
+    # the launches are replayed from a HIP graph like the step's: eager ctypes launches are host-bound at ~10 us each
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(a.reps):
+            call()
+    gr.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(a.reps):
-        call()
+    gr.replay()
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.reps
     key = (M, N, K, bool(kw.get("a_trans")), bool(kw.get("b_trans")), kw.get("epi", 0), kw.get("splits", 1))

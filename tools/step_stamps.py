@@ -35,8 +35,16 @@ def run_forward(self, *a, **kw):
     return real_fwd(self, *a, **kw)
 E.run_forward = run_forward
 wrap(E, "run_backward", before="chain backward begins", after="chain backward issued (side joined)")
+wrap(E, "_block_fwd", after=lambda s, a, kw: f"chain end of block fwd {a[1].prefix}")
 wrap(E, "_block_bwd", after=lambda s, a, kw: f"chain end of block bwd {a[1].prefix}")
-wrap(E, "_issue_pending", before="side  group begins", after="side  group ends")
+def _grp(self, a, kw):
+    pend = self._pending if (len(a) < 2 or a[1] is None) and kw.get("pending") is None else (kw.get("pending") or a[1])
+    w = [x for k, x in pend if k == "w"]
+    kinds = "".join(k for k, _ in pend if k != "w")
+    contents.append(" ".join(f"{x[4]}x{x[5]}/{x[6]}" for x in w) + (" +" + kinds if kinds else ""))
+    return "side  group begins"
+contents = []
+wrap(E, "_issue_pending", before=_grp, after="side  group ends")
 wrap(Trainer, "_adamw", before="chain adamw begins", after="chain adamw ends")
 
 m = bench.make_model(a).to(dev).train()
@@ -49,4 +57,5 @@ ev = sorted(((v[i], tag, k) for (tag, k), i in slots.items() if v[i]), key=lambd
 t0 = ev[0][0]
 print(f"{len(ev)} stamps; 10-ns ticks since the first one; every stamp is a 1-thread launch of its own (~3-5 us each)")
 for t, tag, k in ev:
-    print(f"  +{(t - t0) / 100.0:9.1f} us  {tag}" + (f" #{k}" if tag.startswith("side") else ""))
+    print(f"  +{(t - t0) / 100.0:9.1f} us  {tag}" + (f" #{k}" if tag.startswith("side") else "")
+          + (f"   [{contents[len(contents) - seen['side  group begins'] + k]}]" if tag == "side  group begins" else ""))

@@ -61,6 +61,9 @@ int gemm_touch_on = 1;
 #ifndef TULIP_WGRAD_RING
 #define TULIP_WGRAD_RING 3
 #endif
+#ifndef TULIP_GEMM_DEEP_RING
+#define TULIP_GEMM_DEEP_RING 2      // register ring of the 128-deep k stages
+#endif
 // f(integral_constant<0>) ... f(integral_constant<N-1>), unrolled at compile time
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -295,7 +298,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     // while the older one is written to LDS.
     // (a deeper ring for the weight-gradient form, K = thousands of tokens per workgroup, measured no faster: 4 stages
     // 31.7 us, 6 stages 32.3 us vs 31.3 us per grouped launch, and costs occupancy)
-    constexpr int RING = (KSUB == 1) ? ((A_T && B_T) ? TULIP_WGRAD_RING : 3) : 2;
+    constexpr int RING = (KSUB == 1) ? ((A_T && B_T) ? TULIP_WGRAD_RING : 3) : TULIP_GEMM_DEEP_RING;
     SA sa[RING];
     SB sb[RING];
     auto issue = [&](auto R, int t) {

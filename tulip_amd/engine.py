@@ -172,12 +172,15 @@ class FlatParams:
         self.packed_t = torch.zeros(max(off, ALIGN) if with_transposes else ALIGN, dtype=torch.bfloat16, device=self.device)
         self._pk_entries, self._pk_joined = {}, {}
         for width, names in names_by_width.items():
-            ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
-                   for n in names]
-            if with_transposes:
-                ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
-                        for n in names]
-            self._pk_entries[width] = ent
+            # part 0: the encoder's blocks (read first in a forward), part 1: the decoder's ("layers_up."), see refresh_transposes
+            for part in (0, 1):
+                sel = [n for n in names if n.startswith("layers_up.") == bool(part)]
+                ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
+                       for n in sel]
+                if with_transposes:
+                    ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
+                            for n in sel]
+                self._pk_entries[(width, part)] = ent
         self.pk_active = set()
 
     def p16p(self, name: str) -> int:
@@ -186,17 +189,21 @@ class FlatParams:
     def p16t(self, name: str) -> int:
         return self.packed_t.data_ptr() + 2 * self.pk_offset[name]
 
-    def refresh_transposes(self):
-        """One launch for the copies of every active width (up to TULIP_PACK_MAX matrices per launch)."""
-        key = tuple(sorted(getattr(self, "pk_active", ())))
-        if not key:
+    def refresh_transposes(self, part: Optional[int] = None):
+        """One launch for the copies of every active width (up to TULIP_PACK_MAX matrices per launch).  part = 0 / 1: only the
+        encoder's / the decoder's blocks (the Trainer's forward rewrites the two halves at different points, _issue_pack)."""
+        widths = tuple(sorted(getattr(self, "pk_active", ())))
+        if not widths:
             return
+        key = (widths, part)
         if key not in self._pk_joined:
-            self._pk_joined[key] = ops.pack_items([e for width in key for e in self._pk_entries[width]])
+            parts = (0, 1) if part is None else (part,)
+            self._pk_joined[key] = ops.pack_items([e for width in widths for q in parts for e in self._pk_entries[(width, q)]])
         items, n = self._pk_joined[key]
         if n:
             ops.pack_bf16_multi(items, n)
-        self.pack_dirty = False
+        if part is None or part == 1:
+            self.pack_dirty = False
 
 
 class Plan:
@@ -531,7 +538,7 @@ class TulipEngine:
         if wide or (self.fuse_block96 and self._fusable96(sp)):
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
             if wide:
-                self._join_pack()                  # the fragment-major weight copies being rewritten beside the forward's head
+                self._join_pack(p)                 # the fragment-major weight copies being rewritten beside the forward
             launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
             wf = W_.p16p if wide else W_.p16           # the wide kernel streams fragment-major copies of the weights
             # forward without a backward behind it (run_forward(with_loss=False): eval / MC-dropout inference): the kernels'
@@ -578,25 +585,40 @@ class TulipEngine:
                  bias=W_.p32(p + ".mlp.fc2.bias"), out=xout, aux=P[p + ".x1"], ldaux=C,
                  rowscale=self._ds(P, sp, 1), rows_per_sample=tok, out2=out_bf16, ldo2=C if out_bf16 is not None else 0)
 
-    _pack_event = None      # run_forward(pack_on_side=True): fork point of the weight-copy refresh
-    _pack_issued = False
+    # run_forward(pack_on_side=True): the weight-copy refresh in two halves, [fork event, issued, joined] each.  Half 0 (the
+    # encoder's wide blocks) is forked behind the forward's first kernel and joined in front of the first wide block; half 1
+    # (the decoder's) is forked in front of the LAST encoder stage -- the few-token stage whose small GEMMs leave most of the
+    # chip idle -- and joined in front of the first decoder block that streams a copy: beside the 96-wide blocks at the head
+    # of the forward the whole refresh cost those blocks ~15 us each (tools/step_stamps.py).  TULIP_SPLIT_PACK=0: one piece.
+    split_pack = os.environ.get("TULIP_SPLIT_PACK", "1") != "0"
+    _packs = None
+
+    def _fork_pack(self, part):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._packs[part] = [ev, False, False]
 
     def _issue_pack(self):
-        """The refresh of the fused wide blocks' fragment-major weight copies (FlatParams.refresh_transposes) on the side
-        stream, forked behind the forward's first kernel and enqueued only after the chain's next one (the graph executor
-        keeps a node's first-created successor on the node's queue, see defer_side)."""
-        if self._pack_event is not None and not self._pack_issued:
-            st = self._side_streams[0]
-            st.wait_event(self._pack_event)
-            with torch.cuda.stream(st):
-                self.params.refresh_transposes()
-            self._pack_issued = True
+        """Enqueue the forked halves on the side stream -- called after the chain's next kernel (the graph executor keeps a
+        node's first-created successor on the node's queue, see defer_side)."""
+        for part, pk in (self._packs or {}).items():
+            if not pk[1]:
+                st = self._side_streams[0]
+                st.wait_event(pk[0])
+                with torch.cuda.stream(st):
+                    self.params.refresh_transposes(part)
+                pk[1] = True
 
-    def _join_pack(self):
-        if self._pack_event is not None:
-            self._issue_pack()
-            torch.cuda.current_stream().wait_stream(self._side_streams[0])
-            self._pack_event = None
+    def _join_pack(self, prefix: Optional[str] = None):
+        """The chain waits for the halves a block with this prefix reads (None: for everything forked so far)."""
+        if not self._packs:
+            return
+        self._issue_pack()
+        need = [q for q in self._packs if prefix is None or q is None or q == int(prefix.startswith("layers_up."))]
+        if any(not self._packs[q][2] for q in need):
+            torch.cuda.current_stream().wait_stream(self._side_streams[0])     # (one side stream: waits for all issued halves)
+            for pk in self._packs.values():
+                pk[2] = pk[2] or pk[1]
 
     def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin, out_bf16=None):
         """out_bf16: bf16 copy of the stage output, written by the last block's fc2 epilogue."""
@@ -646,7 +668,7 @@ class TulipEngine:
             W_.refresh_shadow()
         elif W_.pack_dirty and not pack_on_side:
             W_.refresh_transposes()
-        self._pack_event, self._pack_issued = None, False
+        self._packs = {}
         self._loss_final = None
         self._no_save = not with_loss and self.infer_no_save
         B, E, nl = P.B, m.embed_dim, m.num_layers
@@ -657,13 +679,15 @@ class TulipEngine:
                             m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
                             m.circular_padding, self.eps,
                             out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E)
+        two_packs = pack_on_side and W_.pk_active and self.split_pack and nl > 2
         if pack_on_side and W_.pk_active:
-            self._pack_event = torch.cuda.Event()
-            self._pack_event.record()
+            self._fork_pack(0 if two_packs else None)
         # every encoder stage input is x_save[s]: its bf16 copy goes straight into the second half of the level's
         # concat buffer (tulip.py:715) from the kernel that produces it
         x = None
         for s in range(nl):
+            if two_packs and s == nl - 1:
+                self._fork_pack(1)
             x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"],
                                 out_bf16=P[f"lvl{s}.xb"] if (s == nl - 1 and nl > 1) else None)
             if s < nl - 1:  # PatchMerging (tulip.py:101-106)
