@@ -170,7 +170,7 @@ def kernel_rooflines(trainer, reps=5):
             deep = deep and kchunk >= 256
             f += 2.0 * it.Nw * it.Kw * it.Mtok
             by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw + 4.0 * it.Nw      # operands once, fp32 dW + db once
-            if it.dW in trainer.eng.adam_fused:
+            if it.dW in trainer.eng.adam_fused and eff == 1:     # (a token-split item's step is taken by the fold of its slabs)
                 # in the step this item's write-out takes the AdamW step (Trainer.fuse_adamw): parameter + two moments read and
                 # written, bf16 shadow written, the gradient itself never stored (26 B instead of 4 B per element)
                 by += 22.0 * it.Nw * it.Kw
@@ -213,9 +213,16 @@ def kernel_rooflines(trainer, reps=5):
     # the end-of-step AdamW launch as the step issues it: tensors stepped in a weight-gradient write-out are masked out
     amask = trainer._adam_mask if trainer._adam_mask is not None else W.decay_mask
     n_adam = W.total - trainer.fused_adamw_params
-    rec.append(("adamw", "adamw_kernel",
-                lambda: ops.adamw(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, W.total, trainer.hyper, amask,
-                                  zero_grad=not trainer.grad_overwrite), 0.0, 30.0 * n_adam, 30.0 * n_adam))
+    blk = getattr(trainer, "_adam_blocks", None)
+    if blk is not None:       # the few 64-element blocks left for the end of the step, by index (Trainer._adamw)
+        n_adam = blk.numel() * 64
+        rec.append(("adamw", "adamw_kernel_blocks",
+                    lambda: ops.adamw_blocks(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, blk, blk.numel(), trainer.hyper,
+                                             amask, zero_grad=not trainer.grad_overwrite), 0.0, 30.0 * n_adam, 30.0 * n_adam))
+    else:
+        rec.append(("adamw", "adamw_kernel",
+                    lambda: ops.adamw(W.flat, trainer.g, trainer.m, trainer.v, W.shadow, W.total, trainer.hyper, amask,
+                                      zero_grad=not trainer.grad_overwrite), 0.0, 30.0 * n_adam, 30.0 * n_adam))
     fams, detail = {}, {}
     for fam, name, call, fl, by, by2 in rec:
         call()

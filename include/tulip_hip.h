@@ -69,6 +69,7 @@ typedef struct tulip_reduce_region {
     int64_t stride; int64_t n;
     int rows; int overwrite;
     const int32_t* scatter_index; int scatter_nh; int scatter_len;
+    int adamw;      /* 1: tulip_reduce_rows_multi_adamw takes the optimizer step of out[0..n) instead of storing the sum */
 } tulip_reduce_region;
 int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream);
 
@@ -98,9 +99,16 @@ int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_r
  * adam == NULL: exactly tulip_wgrad_group. */
 typedef struct tulip_adamw_ref {
     const float* hyper; const float* grad; float* param; float* exp_avg; float* exp_avg_sq; uint16_t* param_bf16;
+    const uint8_t* decay_mask64;    /* tulip_adamw's mask (bit 0 = weight decay applies to these 64 elements); NULL: everywhere */
 } tulip_adamw_ref;
 int tulip_wgrad_group_adamw(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
                             void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, hipStream_t stream);
+/* tulip_reduce_rows_multi whose regions marked adamw = 1 (overwrite = 1, no scatter: the sum is the complete gradient of
+ * out[0..n), a range of `adam->grad`) take the optimizer step in place of storing the sum -- same arithmetic as tulip_adamw,
+ * decay per 64 elements from adam->decay_mask64; the caller's end-of-step tulip_adamw must skip those ranges (mask bit 1).
+ * tulip_wgrad_group_adamw marks the fold regions of its token-split items with reserved_ = 1 this way (weight and bias).
+ * adam == NULL: exactly tulip_reduce_rows_multi (a marked region is then an argument error). */
+int tulip_reduce_rows_multi_adamw(const tulip_reduce_region* regions, int n, const tulip_adamw_ref* adam, hipStream_t stream);
 /* The fold regions tulip_wgrad_group(fold = 1) would hand to tulip_reduce_rows_multi for these items and this workspace (host
  * code only): for a caller that launches with fold = 0 and folds later, in one launch with regions that become ready in
  * between (the engine: the patch-embedding partial rows ride in the fold of the backward's last weight-gradient group).
@@ -299,6 +307,11 @@ int tulip_l1_loss_bwd(const float* pred, const float* target, const float* gscal
  * zero_grad != 0: g is cleared after it has been consumed (optimizer.zero_grad(), engine_upsampling.py:97). */
 int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* hyper,
                 const uint8_t* decay_mask64, int zero_grad, hipStream_t stream);
+/* The same step for the 64-float blocks blocks[0..nblocks) only (device int32 block indices; decay_mask64 is indexed by block,
+ * bit 1 is ignored): the end-of-step launch when most tensors were stepped where their gradient was completed
+ * (tulip_wgrad_group_adamw, tulip_reduce_rows_multi_adamw) -- nothing is scanned. */
+int tulip_adamw_blocks(float* p, float* g, float* m, float* v, uint16_t* p_bf16, const int32_t* blocks, int nblocks,
+                       const float* hyper, const uint8_t* decay_mask64, int zero_grad, hipStream_t stream);
 
 /* DropPath multipliers of one step (tulip.py:25-29; timm drop_path: keep a sample's residual branch with
  * probability keep, scale kept branches by 1/keep): scale[slot*B+b] = floor(keep[slot] + u)/keep[slot] with

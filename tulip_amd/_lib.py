@@ -35,7 +35,7 @@ class Swin96BwdDesc(ctypes.Structure):
 class ReduceRegion(ctypes.Structure):
     """tulip_reduce_region (include/tulip_hip.h)."""
     _fields_ = [("partials", P), ("out", P), ("stride", L), ("n", L), ("rows", I), ("overwrite", I),
-                ("scatter_index", P), ("scatter_nh", I), ("scatter_len", I)]
+                ("scatter_index", P), ("scatter_nh", I), ("scatter_len", I), ("adamw", I)]
 
 
 class WgradItem(ctypes.Structure):
@@ -46,7 +46,7 @@ class WgradItem(ctypes.Structure):
 
 class AdamwRef(ctypes.Structure):
     """tulip_adamw_ref (include/tulip_hip.h)."""
-    _fields_ = [(n, P) for n in ("hyper", "grad", "param", "exp_avg", "exp_avg_sq", "param_bf16")]
+    _fields_ = [(n, P) for n in ("hyper", "grad", "param", "exp_avg", "exp_avg_sq", "param_bf16", "decay_mask64")]
 
 
 class PackItem(ctypes.Structure):
@@ -87,6 +87,7 @@ SIGNATURES = {
     "tulip_reduce_splits": [P, P, L, I, P],
     "tulip_reduce_rows2": [P, L, P, L, P, L, P, L, I, P],
     "tulip_reduce_rows_multi": [P, I, P],
+    "tulip_reduce_rows_multi_adamw": [P, I, P, P],
     "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
     "tulip_wgrad_tiles": [I, I],
     "tulip_wgrad_group_regions": [P, I, P, P, I],
@@ -111,6 +112,7 @@ SIGNATURES = {
     "tulip_l1_loss_fwd": [P, P, P, P, L, I, P],
     "tulip_l1_loss_bwd": [P, P, P, F, P, L, P],
     "tulip_adamw": [P, P, P, P, P, L, P, P, I, P],
+    "tulip_adamw_blocks": [P, P, P, P, P, P, I, P, P, I, P],
     "tulip_drop_path_scales": [P, P, P, I, I, ctypes.c_uint64, P, P],
     "tulip_grad_norm": [P, L, P, P, F, P, P],
     "tulip_kitti_range_map": [P, L, I, I, F, F, F, F, F, P, P, P],

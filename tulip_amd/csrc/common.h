@@ -61,6 +61,10 @@ __device__ __forceinline__ void adamw_step4(float4& pp, float4& mm, float4& vv, 
     }
 }
 
+// The flat optimizer buffers of a step taken outside adamw_kernel (tulip_adamw_ref): an element is addressed by the offset of its
+// gradient from g0; mask64 (optional): one byte per 64 elements, bit 0 = decoupled weight decay applies (NULL: everywhere).
+struct AdamRef { const float* hyper; const float* g0; float* p0; float* m0; float* v0; bf16_t* pb0; const uint8_t* mask64; };
+
 // A bf16 MFMA operand that was JUST packed by vector-ALU instructions (v_cvt_pk_bf16_f32 behind an fma): pin 8 wait states
 // between the pack and the MFMAs that read it.  Measured on gfx950 / ROCm 7.2 (tools/det_tail_instep.py): without them the
 // head's weight-gradient kernel returned, about once in 200 launches INSIDE the training step (never in isolation), one

@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(ReduceRegion r0, Reduc
 struct MultiRegion {
     const float* part; float* out; const int* scatter;
     int64_t stride, n4;
-    int first_block, rows, overwrite, rl, nh, LL;
+    int first_block, rows, overwrite, rl, nh, LL, adam;
 };
-struct MultiRegions { MultiRegion r[TULIP_REDUCE_REGIONS_MAX]; int n; };
+// ad: the optimizer buffers for the regions with adam = 1 -- their sums are complete gradients (overwrite regions: the one
+// producer of these tensors in this backward), so the AdamW step (adamw_step4, common.h: the arithmetic of adamw_kernel) is
+// taken right here and the gradient is never stored; the end-of-step AdamW skips the tensors (mask bit 1)
+struct MultiRegions { MultiRegion r[TULIP_REDUCE_REGIONS_MAX]; int n; AdamRef ad; };
 __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegions R) {
     __shared__ float4 red[256];
     int i = 0;
@@ -168,7 +171,17 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
         } else {
             float4 o = r.overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(r.out + col * 4);
             o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-            *(float4*)(r.out + col * 4) = o;
+            if (r.adam) {                               // block-uniform
+                const AdamRef& ad = R.ad;
+                const size_t idx = (size_t)((r.out + col * 4) - ad.g0);
+                const bool decay = ad.mask64 ? (ad.mask64[idx >> 6] & 1u) != 0 : true;
+                float4 pp = *(const float4*)(ad.p0 + idx), mm = *(const float4*)(ad.m0 + idx), vv = *(const float4*)(ad.v0 + idx);
+                adamw_step4(pp, mm, vv, o, adamw_coef(ad.hyper, decay));
+                *(float4*)(ad.p0 + idx) = pp; *(float4*)(ad.m0 + idx) = mm; *(float4*)(ad.v0 + idx) = vv;
+                *(uint2*)(ad.pb0 + idx) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
+            } else {
+                *(float4*)(r.out + col * 4) = o;
+            }
         }
     }
 }
@@ -229,6 +242,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const unsigned mk = mask64 ? mask64[i >> 4] : 1u;
         if (mk & 2u) continue;                       // this block's step was taken in a weight-gradient write-out
+        float4 pp = *(float4*)(p + i * 4);
+        const float4 gg = *(const float4*)(g + i * 4);
+        float4 mm = *(float4*)(m + i * 4), vv = *(float4*)(v + i * 4);
+        adamw_step4(pp, mm, vv, gg, (mk & 1u) ? cd : cn);
+        *(float4*)(p + i * 4) = pp; *(float4*)(m + i * 4) = mm; *(float4*)(v + i * 4) = vv;
+        if (zero_grad) *(float4*)(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pb) *(uint2*)(pb + i * 4) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
+    }
+}
+
+// the same step over an explicit list of 64-element blocks (the few tensors left for the end of the step once everything else was
+// stepped where its gradient was completed): 16 lanes per block, nothing scanned
+__global__ __launch_bounds__(256) void adamw_kernel_blocks(float* __restrict__ p, float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           bf16_t* __restrict__ pb, const int32_t* __restrict__ blocks,
+                                                           int nblocks, const float* __restrict__ hyper,
+                                                           const uint8_t* __restrict__ mask64, int zero_grad) {
+    const AdamwCoef cd = adamw_coef(hyper, true), cn = adamw_coef(hyper, false);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < (int64_t)nblocks * 16; q += (int64_t)gridDim.x * 256) {
+        const int blk = blocks[q >> 4];
+        const int64_t i = (int64_t)blk * 16 + (q & 15);
+        const unsigned mk = mask64 ? mask64[blk] : 1u;
         float4 pp = *(float4*)(p + i * 4);
         const float4 gg = *(const float4*)(g + i * 4);
         float4 mm = *(float4*)(m + i * 4), vv = *(float4*)(v + i * 4);
@@ -356,8 +391,18 @@ extern "C" int tulip_reduce_rows2(const float* part0, int64_t stride0, float* ou
 }
 
 extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream) {
+    return tulip_reduce_rows_multi_adamw(regions, n, nullptr, stream);
+}
+
+extern "C" int tulip_reduce_rows_multi_adamw(const tulip_reduce_region* regions, int n, const tulip_adamw_ref* adam,
+                                             hipStream_t stream) {
     if (n < 0 || n > TULIP_REDUCE_REGIONS_MAX || (n && !regions)) return TULIP_ERR_ARG;
+    if (adam && (!adam->hyper || !adam->grad || !adam->param || !adam->exp_avg || !adam->exp_avg_sq || !adam->param_bf16))
+        return TULIP_ERR_ARG;
     MultiRegions R;
+    R.ad = adam ? AdamRef{adam->hyper, adam->grad, adam->param, adam->exp_avg, adam->exp_avg_sq, (bf16_t*)adam->param_bf16,
+                          adam->decay_mask64}
+                : AdamRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     R.n = 0;
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -369,6 +414,9 @@ extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n
         MultiRegion& r = R.r[R.n++];
         r.part = g.partials; r.out = g.out; r.scatter = g.scatter_index; r.stride = g.stride; r.n4 = g.n / 4;
         r.rows = g.rows; r.overwrite = g.overwrite; r.nh = g.scatter_nh; r.LL = g.scatter_len;
+        // the step is taken only where the sum IS the gradient: an overwrite region without a scatter, optimizer buffers given
+        if (g.adamw && (!adam || !g.overwrite || g.scatter_index)) return TULIP_ERR_ARG;
+        r.adam = g.adamw ? 1 : 0;
         // one thread per float4 column when there are few rows; otherwise spread the rows over 2..16 row lanes until
         // the region has enough workgroups to hide the strided loads (32-row slabs of a 37k-column weight gradient
         // took 50-80 us with one thread per column)
@@ -424,6 +472,16 @@ extern "C" int tulip_adamw(float* p, float* g, float* m, float* v, uint16_t* p_b
     if (n & 3) return TULIP_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, hyper,
                        decay_mask64, zero_grad);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
+
+extern "C" int tulip_adamw_blocks(float* p, float* g, float* m, float* v, uint16_t* p_bf16, const int32_t* blocks, int nblocks,
+                                  const float* hyper, const uint8_t* decay_mask64, int zero_grad, hipStream_t stream) {
+    if (nblocks <= 0) return TULIP_OK;
+    if (!p || !g || !m || !v || !blocks || !hyper) return TULIP_ERR_ARG;
+    hipLaunchKernelGGL(adamw_kernel_blocks, dim3(grid_for((int64_t)nblocks * 16)), dim3(256), 0, stream, p, g, m, v,
+                       (bf16_t*)p_bf16, blocks, nblocks, hyper, decay_mask64, zero_grad);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

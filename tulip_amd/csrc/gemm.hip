@@ -472,7 +472,6 @@ __global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_group_kernel(co
 // Each k-step's operands are [32 tokens][96 columns] sub-tiles in the k-slow LDS layout of Stage<96, true> (pitch 288 B).
 // AdamW in the write-out of an un-split weight gradient (tulip_wgrad_group_adamw): the flat fp32 gradient / parameter / moment
 // buffers share one layout, so an element's parameter, moments and bf16 shadow sit at the gradient's own offset from g0
-struct AdamRef { const float* hyper; const float* g0; float* p0; float* m0; float* v0; bf16_t* pb0; };
 constexpr int WG_SUB = 32 * T_PITCH;          // bytes of one sub-tile
 constexpr int WG_STG_PITCH = 96 * 4 + 16;     // fp32 write-out staging row
 constexpr int WG_LDS_BYTES = 2 * 5 * WG_SUB;  // double-buffered 4 x 1 stage (the 2 x 2 stage is 4 sub-tiles)
@@ -856,7 +855,8 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     return TULIP_OK;
 }
 
-extern "C" int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream_t stream);
+extern "C" int tulip_reduce_rows_multi_adamw(const tulip_reduce_region* regions, int n, const tulip_adamw_ref* adam,
+                                             hipStream_t stream);
 
 // tile shape of the large-tile weight-gradient kernel for a [Nw][Kw] gradient: 0 = 192 x 192, 1 = 384 x 96, 2 = 96 x 384,
 // -1 = none (the 64 x 96 tile of gemm_group_kernel)
@@ -936,8 +936,10 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
             p.epi = TULIP_EPI_SPLIT_F32; p.accumulate = 0;
             p.out = ws + ws_used;
             p.out2 = it.db ? (void*)(ws + ws_used + nw * splits) : nullptr;
-            folds[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, it.overwrite, nullptr, 0, 0};
-            if (it.db) folds[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, it.overwrite, nullptr, 0, 0};
+            // reserved_ = 1 on a token-split item: the fold of its slabs takes the optimizer step (weight and bias)
+            const int st = (it.reserved_ == 1 && adam && it.overwrite) ? 1 : 0;
+            folds[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, it.overwrite, nullptr, 0, 0, st};
+            if (it.db) folds[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, it.overwrite, nullptr, 0, 0, st};
             ws_used += need;
         } else {
             p.epi = TULIP_EPI_F32; p.accumulate = it.overwrite ? 0 : 1; p.out = it.dW; p.out2 = it.db;
@@ -953,8 +955,9 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
     if (G.n > 0) {
         const int blocks = G.first[G.n];
         if (big) {
-            G.adam = adam ? AdamRef{adam->hyper, adam->grad, adam->param, adam->exp_avg, adam->exp_avg_sq, (bf16_t*)adam->param_bf16}
-                          : AdamRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            G.adam = adam ? AdamRef{adam->hyper, adam->grad, adam->param, adam->exp_avg, adam->exp_avg_sq, (bf16_t*)adam->param_bf16,
+                                    adam->decay_mask64}
+                          : AdamRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < G.n; ++i) G.g[i].aux = g_wgrad_prof;
             hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(512), 0, stream, G);
         } else {
@@ -971,7 +974,7 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
     }
     if (!fold) return TULIP_OK;
     for (int i = 0; i < n_extra; ++i) folds[nf++] = extra[i];
-    return nf ? tulip_reduce_rows_multi(folds, nf, stream) : TULIP_OK;
+    return nf ? tulip_reduce_rows_multi_adamw(folds, nf, adam, stream) : TULIP_OK;
 }
 
 // The fold regions tulip_wgrad_group(..., fold = 1) would pass to tulip_reduce_rows_multi for these items and this workspace
@@ -991,8 +994,9 @@ extern "C" int tulip_wgrad_group_regions(const tulip_wgrad_item* items, int n, v
         if (splits <= 1) continue;
         const int64_t nw = (int64_t)it.Nw * it.Kw, need = (nw + (it.db ? it.Nw : 0)) * splits;
         if (nf + 2 > max) return TULIP_ERR_ARG;
-        out[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, it.overwrite, nullptr, 0, 0};
-        if (it.db) out[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, it.overwrite, nullptr, 0, 0};
+        const int st = (it.reserved_ == 1 && it.overwrite) ? 1 : 0;     // (folded with tulip_reduce_rows_multi_adamw)
+        out[nf++] = tulip_reduce_region{ws + ws_used, it.dW, nw, nw, splits, it.overwrite, nullptr, 0, 0, st};
+        if (it.db) out[nf++] = tulip_reduce_region{ws + ws_used + nw * splits, it.db, it.Nw, it.Nw, splits, it.overwrite, nullptr, 0, 0, st};
         ws_used += need;
     }
     return nf;

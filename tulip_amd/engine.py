@@ -870,11 +870,23 @@ class TulipEngine:
         relative-position-bias gradients, ...).  Folds queued by one block leave in the same launch as the folds of
         its weight-gradient slabs."""
         kw.setdefault("overwrite", self.grad_overwrite)
+        if kw["overwrite"] and self.fuse_adamw_folds and self._in_gflat(out):
+            # the fold produces the complete gradient of a parameter range: the optimizer step can be taken in it (Trainer.fuse_adamw)
+            if self.adam_probe is not None:
+                self.adam_probe[out] = max(n, self.adam_probe.get(out, 0))
+            kw["adamw"] = self.adam_apply and out in self.adam_fused
         r = ops.reduce_region(part, stride, out, n, rows, **kw)
         if self.overlap_wgrad:
             self._pending.append(("r", r))
         else:
-            ops.reduce_rows_multi([r])
+            ops.reduce_rows_multi([r], adam=self._adam_arg())
+
+    def _in_gflat(self, ptr) -> bool:
+        g = self._gflat
+        return g is not None and isinstance(ptr, int) and g.data_ptr() <= ptr < g.data_ptr() + 4 * g.numel()
+
+    def _adam_arg(self):
+        return self.adam_ctx if self.adam_apply else None
 
     def _fold_bias_table(self, P: Plan, tag: str, part, rows: int, nh: int, gtable):
         """Relative-position-bias gradient of one block: partial rows [rows][nh*256] (dense (head, query, key) sums per
@@ -901,7 +913,7 @@ class TulipEngine:
         if self._carry:
             carry, self._carry = list(self._carry), ()
             with torch.cuda.stream(self._side_streams[0]):
-                ops.reduce_rows_multi(carry)
+                ops.reduce_rows_multi(carry, adam=self._adam_arg())
             self._side_dirty = True
 
     group_wgrad = os.environ.get("TULIP_GROUP_WGRAD", "1") != "0"
@@ -942,11 +954,15 @@ class TulipEngine:
                 if grp and used + need > ws_bytes:
                     break
                 used += need
-                # an un-split large-tile item holds its complete gradient tile in the write-out: the optimizer step can be taken there
-                elig = big and sp == 1 and self.grad_overwrite
+                # an un-split large-tile item holds its complete gradient tile in the write-out: the optimizer step can be taken
+                # there (weight only); a token-split item's step is taken by the fold of its slabs (weight and bias)
+                elig = self.grad_overwrite and ((sp > 1 and self.fuse_adamw_folds) or (sp == 1 and big))
                 if elig and self.adam_probe is not None:
-                    self.adam_probe.add(gout)
-                step_here = elig and self.adam_apply and gout in self.adam_fused
+                    self.adam_probe[gout] = Nw * Kw
+                    if sp > 1 and gbias is not None:
+                        self.adam_probe[gbias] = Nw
+                step_here = (elig and self.adam_apply and gout in self.adam_fused
+                             and (sp == 1 or gbias is None or gbias in self.adam_fused))
                 any_adam = any_adam or step_here
                 grp.append(ops.wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, sp, overwrite=self.grad_overwrite,
                                           adamw=step_here))
@@ -954,15 +970,15 @@ class TulipEngine:
             room = _lib.REDUCE_REGIONS_MAX - 2 * len(grp)
             if late and not items and len(regions) <= room:
                 # one group, folded in ONE launch behind the late event together with everything else of this flush
-                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False, adam=self.adam_ctx if any_adam else None)
+                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False, adam=self._adam_arg())
                 regions = ops.wgrad_group_regions(grp, ws) + regions
                 break
             extra, regions = regions[:room], regions[room:]
-            ops.wgrad_group(grp, extra, ws, ws_bytes, adam=self.adam_ctx if any_adam else None)
+            ops.wgrad_group(grp, extra, ws, ws_bytes, adam=self._adam_arg())
         for ev in late:
             torch.cuda.current_stream().wait_event(ev)
         while regions:
-            ops.reduce_rows_multi(regions[:_lib.REDUCE_REGIONS_MAX])
+            ops.reduce_rows_multi(regions[:_lib.REDUCE_REGIONS_MAX], adam=self._adam_arg())
             regions = regions[_lib.REDUCE_REGIONS_MAX:]
         for fn in fns:
             fn()
@@ -1212,11 +1228,13 @@ class TulipEngine:
     grad_overwrite = False
     # The optimizer step of un-split weight gradients in their write-out (Trainer.fuse_adamw): adam_ctx = ops.adamw_ref of the
     # Trainer's flat buffers, adam_fused = the gradient addresses it applies to, adam_apply = this backward is an optimizer
-    # step; adam_probe (a set) collects the eligible addresses during the Trainer's eager warm-up pass.
+    # step; adam_probe (a dict: gradient address -> elements) collects the eligible ranges during the Trainer's eager warm-up pass.
     adam_ctx = None
     adam_fused = frozenset()
     adam_apply = False
     adam_probe = None
+    _gflat = None
+    fuse_adamw_folds = os.environ.get("TULIP_FUSE_ADAMW_FOLDS", "1") != "0"      # (0: only the un-split write-outs step)
 
     def overwrite_supported(self, B: int) -> bool:
         return bool(self.group_wgrad and self.overlap_wgrad)

@@ -89,26 +89,32 @@ def reduce_rows2(part0, stride0, out0, n0, part1, stride1, out1, n1, nrows):
                                          _stream()), "tulip_reduce_rows2")
 
 
-def reduce_region(part, stride, out, n, rows, overwrite=False, scatter_index=None, scatter_nh=0, scatter_len=0):
-    """One tulip_reduce_region: out[i] (+)= sum_s part[s*stride + i]; see include/tulip_hip.h."""
+def reduce_region(part, stride, out, n, rows, overwrite=False, scatter_index=None, scatter_nh=0, scatter_len=0, adamw=False):
+    """One tulip_reduce_region: out[i] (+)= sum_s part[s*stride + i]; see include/tulip_hip.h.  adamw: the fold takes the
+    optimizer step of out[0..n) instead of storing the sum (reduce_rows_multi(..., adam=adamw_ref(...)))."""
     return _lib.ReduceRegion(_p(part), _p(out), stride, n, rows, int(overwrite), _p(scatter_index), scatter_nh,
-                             scatter_len)
+                             scatter_len, int(adamw))
 
 
 def wgrad_item(dY, ldy, X, ldx, Nw, Kw, Mtok, dW, db=None, splits=1, overwrite=False, adamw=False):
     return _lib.WgradItem(_p(dY), _p(X), _p(dW), _p(db), ldy, ldx, Nw, Kw, Mtok, splits, int(overwrite), int(adamw))
 
 
-def adamw_ref(hyper, grad, param, exp_avg, exp_avg_sq, param_bf16):
-    """tulip_adamw_ref: the flat buffers tulip_wgrad_group_adamw steps in (all laid out like `grad`)."""
-    return _lib.AdamwRef(_p(hyper), _p(grad), _p(param), _p(exp_avg), _p(exp_avg_sq), _p(param_bf16))
+def adamw_ref(hyper, grad, param, exp_avg, exp_avg_sq, param_bf16, decay_mask64=None):
+    """tulip_adamw_ref: the flat buffers tulip_wgrad_group_adamw / tulip_reduce_rows_multi_adamw step in (all laid out like
+    `grad`); decay_mask64: tulip_adamw's mask (bit 0: weight decay for these 64 elements; None: everywhere)."""
+    return _lib.AdamwRef(_p(hyper), _p(grad), _p(param), _p(exp_avg), _p(exp_avg_sq), _p(param_bf16), _p(decay_mask64))
 
 
-def reduce_rows_multi(regions):
+def reduce_rows_multi(regions, adam=None):
     if len(regions) > _lib.REDUCE_REGIONS_MAX:
         raise ValueError("too many regions for one launch")
     arr = (_lib.ReduceRegion * max(len(regions), 1))(*regions)
-    check(_lib.load().tulip_reduce_rows_multi(arr, len(regions), _stream()), "tulip_reduce_rows_multi")
+    if adam is None:
+        check(_lib.load().tulip_reduce_rows_multi(arr, len(regions), _stream()), "tulip_reduce_rows_multi")
+    else:
+        check(_lib.load().tulip_reduce_rows_multi_adamw(arr, len(regions), ctypes.byref(adam), _stream()),
+              "tulip_reduce_rows_multi_adamw")
 
 
 def wgrad_tiles(Nw, Kw):
@@ -293,6 +299,12 @@ def l1_loss_bwd(pred, target, gscale_dev, gscale, dpred, n):
 def adamw(p, g, m, v, p_bf16, n, hyper, decay_mask64=None, zero_grad=False):
     check(_lib.load().tulip_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _p(decay_mask64),
                                   int(zero_grad), _stream()), "tulip_adamw")
+
+
+def adamw_blocks(p, g, m, v, p_bf16, blocks, nblocks, hyper, decay_mask64=None, zero_grad=False):
+    """tulip_adamw over the listed 64-float blocks only (blocks: int32 device tensor of block indices)."""
+    check(_lib.load().tulip_adamw_blocks(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(blocks), nblocks, _p(hyper),
+                                         _p(decay_mask64), int(zero_grad), _stream()), "tulip_adamw_blocks")
 
 
 def grad_norm(g, n, partials, out, scale_dev=None, scale=1.0):

@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 from . import ops
 from .ddp import GradBucketer
+from .engine import ALIGN
 
 
 def cosine_lr(epoch_float: float, lr: float, min_lr: float, warmup_epochs: float, epochs: float) -> float:
@@ -108,6 +109,7 @@ class Trainer:
         self.fuse_adamw = (self.grad_overwrite and use_graph and not self.segmented and not track_grad_norm
                            and os.environ.get("TULIP_FUSE_ADAMW", "1") != "0")
         self._adam_mask = None
+        self._adam_blocks = None
         self.fused_adamw_params = 0
         self._fuse_adamw_skip = tuple(x for x in os.environ.get("TULIP_FUSE_ADAMW_SKIP", "").split(",") if x)   # dev: name prefixes
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
@@ -197,8 +199,13 @@ class Trainer:
         if self.track_grad_norm:
             # g holds the SUM over ranks here; hyper[7] = 1/world turns it into DDP's mean
             ops.grad_norm(self.g, W.total, self._norm_part, self.grad_norm, scale_dev=self.hyper[7:8])
-        mask = self._adam_mask if self._adam_mask is not None else W.decay_mask       # (bit 1: stepped in a weight-gradient write-out)
-        ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, mask, zero_grad=not self.grad_overwrite)
+        mask = self._adam_mask if self._adam_mask is not None else W.decay_mask       # (bit 1: stepped beside the backward)
+        if self._adam_blocks is not None:
+            # most tensors were stepped where their gradient was completed: the few blocks left, by index (nothing scanned)
+            ops.adamw_blocks(W.flat, self.g, self.m, self.v, W.shadow, self._adam_blocks, self._adam_blocks.numel(), self.hyper,
+                             mask, zero_grad=not self.grad_overwrite)
+        else:
+            ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, mask, zero_grad=not self.grad_overwrite)
         if not self.pack_at_step_start:
             W.refresh_transposes()
 
@@ -240,23 +247,37 @@ class Trainer:
         W.shadow_dirty = True          # the model's own load_state_dict normally precedes this; refresh either way
 
     def _plan_fused_adamw(self, eligible):
-        """Which tensors take their optimizer step in a weight-gradient write-out: the un-split large-tile items the warm-up
-        pass saw, except weights the backward reads again AFTER their gradient is complete (the skip Linears: the x_save half
-        of their input gradient is formed when the encoder stage is reached, see FlatParams._completion_order)."""
+        """Which tensors take their optimizer step where their gradient is completed, beside the backward, instead of in the
+        AdamW launch at the end of the step: `eligible` = {gradient address: elements} of the producers the warm-up pass saw --
+        un-split large-tile weight-gradient items (step in the write-out), token-split items and partial-row folds (step in
+        the fold launch).  Left out: weights the backward reads again AFTER their gradient is complete (the skip Linears: the
+        x_save half of their input gradient is formed when the encoder stage is reached, see FlatParams._completion_order),
+        and ranges that do not cover whole tensors."""
         W = self.eng.params
         gbase = self.g.data_ptr()
-        fused, mask = set(), W.decay_mask.clone()
-        for n in W.names:
-            ptr = gbase + 4 * W.offset[n]
-            if (ptr in eligible and not n.startswith("skip_connection_layers.") and len(W.shape[n]) > 1
-                    and not any(n.startswith(x) for x in self._fuse_adamw_skip)):
-                fused.add(ptr)
-                mask[W.offset[n] // 64:(W.offset[n] + W.numel[n] + 63) // 64] |= 2
+        by_off = {W.offset[n]: n for n in W.names}
+        fused, mask, count = set(), W.decay_mask.clone(), 0
+        for ptr, cnt in eligible.items():
+            a = (ptr - gbase) // 4
+            names, o = [], a
+            while o < a + cnt and o in by_off:             # the tensors the range covers, in flat order
+                names.append(by_off[o])
+                o = (o + W.numel[by_off[o]] + ALIGN - 1) // ALIGN * ALIGN
+            whole = bool(names) and W.offset[names[-1]] + W.numel[names[-1]] <= a + cnt <= o
+            if (not whole or any(n.startswith("skip_connection_layers.") for n in names)
+                    or any(n.startswith(x) for n in names for x in self._fuse_adamw_skip)):
+                continue
+            fused.add(ptr)
+            mask[a // 64:(a + cnt + 63) // 64] |= 2
+            count += sum(W.numel[n] for n in names)
         if fused:
             self.eng.adam_fused = frozenset(fused)
-            self.eng.adam_ctx = ops.adamw_ref(self.hyper, self.g, W.flat, self.m, self.v, W.shadow)
             self._adam_mask = mask
-            self.fused_adamw_params = sum(W.numel[n] for n in W.names if gbase + 4 * W.offset[n] in fused)
+            self.eng.adam_ctx = ops.adamw_ref(self.hyper, self.g, W.flat, self.m, self.v, W.shadow, decay_mask64=mask)
+            self.fused_adamw_params = count
+            left = torch.nonzero((mask[:(W.total + 63) // 64] & 2) == 0).flatten().to(torch.int32)
+            if 0 < left.numel() * 64 <= W.total // 4:       # (a long list gains nothing over the scan)
+                self._adam_blocks = left.contiguous()
 
     # ------------------------------------------------------------------ torch.optim.AdamW <-> fused AdamW state
     def _param_names_by_ptr(self):
@@ -407,7 +428,7 @@ class Trainer:
             # open accumulation window or the DropPath stream (the pass below accumulates into g and draws once)
             keep_g, keep_c = self.g.clone(), self.eng._drop_counter.clone()
             if self.fuse_adamw:
-                self.eng.adam_probe = set()
+                self.eng.adam_probe = {}
             self._fwd_bwd(lambda tag: None)
             if self.fuse_adamw:
                 self._plan_fused_adamw(self.eng.adam_probe)
