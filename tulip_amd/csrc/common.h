@@ -61,6 +61,24 @@ __device__ __forceinline__ void adamw_step4(float4& pp, float4& mm, float4& vv, 
     }
 }
 
+// Sum of the `nslab` split-K partial slabs of one float4, in slab order (the order every fold of these slabs uses: same bits).
+// Four loads are issued before the first add -- a loop of load / add pairs with a run-time trip count is a chain of nslab
+// memory latencies, and the kernels that fold (3-4 slabs, a few rows per workgroup) are nothing but that chain.
+__device__ __forceinline__ float4 fold_slabs4(const float* __restrict__ p, size_t stride, int nslab) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto group = [&](int s0) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(p + (size_t)min(s0 + u, nslab - 1) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < nslab) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    };
+    group(0);
+    for (int s0 = 4; s0 < nslab; s0 += 4) group(s0);
+    return a;
+}
+
 // The flat optimizer buffers of a step taken outside adamw_kernel (tulip_adamw_ref): an element is addressed by the offset of its
 // gradient from g0; mask64 (optional): one byte per 64 elements, bit 0 = decoupled weight decay applies (NULL: everywhere).
 struct AdamRef { const float* hyper; const float* g0; float* p0; float* m0; float* v0; bf16_t* pb0; const uint8_t* mask64; };

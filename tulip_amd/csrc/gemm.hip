@@ -756,13 +756,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, 
     const int total = p.M * n8;                 // (the launcher only folds outputs of < 2^31 8-column chunks)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int m = fast_div(i, n8), n = (i - m * n8) * 8;
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        for (int sidx = 0; sidx < splits; ++sidx) {
-            const float* src = slabs + ((size_t)sidx * p.M + m) * p.N + n;
-            const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
-            lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w;
-            hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
-        }
+        const float* src = slabs + (size_t)m * p.N + n;
+        const float4 lo = fold_slabs4(src, (size_t)p.M * p.N, splits), hi = fold_slabs4(src + 4, (size_t)p.M * p.N, splits);
         epilogue8(p, m, n, lo, hi, 0);
     }
 }

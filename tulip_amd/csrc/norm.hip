@@ -111,11 +111,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 const float4 xv = *(const float4*)(x + src_off(g, row, c * 4));
                 uint2 d;
                 if (slabs) {
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int sidx = 0; sidx < nslab; ++sidx) {
-                        const float4 v = *(const float4*)(slabs + ((size_t)sidx * rows + row) * g.C + c * 4);
-                        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-                    }
+                    const float4 a = fold_slabs4(slabs + (size_t)row * g.C + c * 4, (size_t)rows * g.C, nslab);
                     d = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
                 } else {
                     d = *(const uint2*)(dy + (size_t)row * g.C + c * 4);
@@ -644,11 +640,7 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + i * 64) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sidx = 0; sidx < nslab; ++sidx) {
-            const float4 t = *(const float4*)(slabs + ((size_t)sidx * M + row) * N + c);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-        }
+        float4 a = fold_slabs4(slabs + (size_t)row * N + c, (size_t)M * N, nslab);
         if (bias) {
             const float4 b = *(const float4*)(bias + c);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
