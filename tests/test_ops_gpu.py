@@ -609,6 +609,48 @@ def test_adamw_matches_torch(ops):
         assert torch.equal(qb, bf(q))
 
 
+def test_adamw_in_the_fold_and_by_block_index_equal_the_full_launch(ops):
+    """tulip_reduce_rows_multi_adamw (the optimizer step taken by the fold that completes a gradient) and tulip_adamw_blocks (the
+    step over listed 64-element blocks) against fold-then-tulip_adamw over everything: same bits in parameters, moments and
+    bf16 shadow; decay per 64 elements from the mask; un-marked regions are stored as before; a marked region without
+    optimizer buffers / without overwrite is an argument error."""
+    n, rows = 64 * 37, 5
+    torch.manual_seed(3)
+    part = torch.randn(rows, n, device=DEV)
+    part2 = torch.randn(rows, 256, device=DEV)
+    mask = (torch.arange(n // 64, device=DEV) % 3 != 0).to(torch.uint8)          # bit 0: decay for two blocks in three
+    hyper = torch.tensor([5e-4, 0.9, 0.95, 1e-8, 0.01, 1 - 0.9 ** 3, 1 - 0.95 ** 3, 1.0], device=DEV)
+    p0, m0, v0 = rnd(n), rnd(n, seed=5) * 0.01, rnd(n, seed=6).abs() * 0.01
+
+    def fresh():
+        return p0.clone(), m0.clone(), v0.clone(), torch.zeros(n, dtype=torch.bfloat16, device=DEV), torch.zeros(n, device=DEV)
+
+    # reference: fold into g, one AdamW launch over everything
+    p, m, v, pb, g = fresh()
+    ops.reduce_rows_multi([ops.reduce_region(part, n, g, n, rows, overwrite=True)])
+    assert torch.allclose(g, part.sum(0), rtol=1e-5, atol=1e-5)
+    ops.adamw(p, g, m, v, pb, n, hyper, mask)
+    # (a) the fold takes the step for the first 64*20 elements, a second region is stored; the rest by block index
+    q, mq, vq, qb, gq = fresh()
+    other = torch.zeros(256, device=DEV)
+    ref = ops.adamw_ref(hyper, gq, q, mq, vq, qb, decay_mask64=mask)
+    cut = 64 * 20
+    ops.reduce_rows_multi([ops.reduce_region(part, n, gq, cut, rows, overwrite=True, adamw=True),
+                           ops.reduce_region(part.data_ptr() + 4 * cut, n, gq.data_ptr() + 4 * cut, n - cut, rows, overwrite=True),
+                           ops.reduce_region(part2, 256, other, 256, rows, overwrite=True)], adam=ref)
+    assert float(gq[:cut].abs().max()) == 0.0                  # the stepped range's gradient is never stored
+    assert torch.equal(gq[cut:], g[cut:]) and torch.equal(other, part2.sum(0))
+    blocks = torch.arange(cut // 64, n // 64, dtype=torch.int32, device=DEV)
+    ops.adamw_blocks(q, gq, mq, vq, qb, blocks, blocks.numel(), hyper, mask)
+    for a, b, what in ((q, p, "param"), (mq, m, "exp_avg"), (vq, v, "exp_avg_sq"), (qb, pb, "bf16 shadow")):
+        assert torch.equal(a, b), what
+    # (b) argument errors
+    with pytest.raises(RuntimeError):
+        ops.reduce_rows_multi([ops.reduce_region(part, n, gq, cut, rows, overwrite=True, adamw=True)])
+    with pytest.raises(RuntimeError):
+        ops.reduce_rows_multi([ops.reduce_region(part, n, gq, cut, rows, overwrite=False, adamw=True)], adam=ref)
+
+
 @pytest.mark.parametrize("n", [64, 1003, 27_150_337])
 def test_grad_norm(ops, n):
     """tulip_grad_norm vs float64 torch (misc.py:317-329); deterministic across calls."""
