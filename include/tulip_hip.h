@@ -185,6 +185,16 @@ int tulip_layernorm_bwd_params(const uint16_t* dy, const float* x, const float* 
 int tulip_patch_embed_fwd(const float* img, const float* w, const float* b, const float* gamma, const float* beta,
                           float* out, int B, int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular,
                           float eps, uint16_t* out_bf16, int ld_bf16, hipStream_t stream);
+/* The same launch also drawing the step's DropPath multipliers (tulip_drop_path_scales below: same generator, same counter
+ * update) in its first workgroup -- nothing in this launch reads them, every later kernel of the step is ordered behind it -- so a
+ * training step does not begin with a launch of its own for a few hundred numbers.  draw == NULL: exactly tulip_patch_embed_fwd.
+ * Shapes the row kernel does not cover issue the draw as its own launch first. */
+typedef struct tulip_drop_draw {
+    const float* keep; float* scale; float* u_out; int nslots; int B; uint64_t seed; uint64_t* counter;
+} tulip_drop_draw;
+int tulip_patch_embed_fwd_draw(const float* img, const float* w, const float* b, const float* gamma, const float* beta,
+                               float* out, int B, int Cin, int Hin, int Win, int E, int p0, int p1, int kw, int circular,
+                               float eps, uint16_t* out_bf16, int ld_bf16, const tulip_drop_draw* draw, hipStream_t stream);
 /* parameter gradients of the above (the input image needs no gradient).  partial_stride > 0: dw/db/dgamma/
  * dbeta point into row 0 of a [tulip_patch_embed_bwd_blocks(ntok)][partial_stride] partial buffer (plain
  * stores; fold with tulip_reduce_rows2); partial_stride == 0: accumulate atomically into the gradients. */

@@ -49,6 +49,11 @@ class AdamwRef(ctypes.Structure):
     _fields_ = [(n, P) for n in ("hyper", "grad", "param", "exp_avg", "exp_avg_sq", "param_bf16", "decay_mask64")]
 
 
+class DropDraw(ctypes.Structure):
+    """tulip_drop_draw (include/tulip_hip.h)."""
+    _fields_ = [("keep", P), ("scale", P), ("u_out", P), ("nslots", I), ("B", I), ("seed", ctypes.c_uint64), ("counter", P)]
+
+
 class PackItem(ctypes.Structure):
     """tulip_pack_item (include/tulip_hip.h)."""
     _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I), ("transpose", I)]
@@ -78,6 +83,7 @@ SIGNATURES = {
     "tulip_layernorm_bwd_partial_rows": [I, I],
     "tulip_layernorm_bwd_params": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "tulip_patch_embed_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P, I, P],
+    "tulip_patch_embed_fwd_draw": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P, I, P, P],
     "tulip_patch_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "tulip_patch_embed_bwd_blocks": [I],
     "tulip_window_attn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],

@@ -61,6 +61,29 @@ __device__ __forceinline__ void adamw_step4(float4& pp, float4& mm, float4& vv, 
     }
 }
 
+// DropPath draws of one step by ONE 256-thread workgroup (tulip_drop_path_scales; also the first workgroup of the patch-embedding
+// forward, tulip_patch_embed_fwd_draw, so that a training step does not start with a launch of its own for 224 numbers):
+// scale[i] = floor(keep[slot] + u) / keep[slot], u ~ U[0,1) from a counter-based generator keyed by (seed, *counter, i).
+struct DropDraw { const float* keep; float* scale; float* u_out; int nslots, B; unsigned long long seed; unsigned long long* counter; };
+__device__ __forceinline__ uint64_t drop_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void drop_draw_block(const DropDraw& d) {
+    const unsigned long long c = *d.counter;
+    const int n = d.nslots * d.B;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint64_t r = drop_mix64(drop_mix64(d.seed + 0x9E3779B97F4A7C15ull * (c + 1)) ^ (0xD1B54A32D192ED03ull * (uint64_t)(i + 1)));
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+        const float k = d.keep[i / d.B];
+        d.scale[i] = floorf(k + u) / k;
+        if (d.u_out) d.u_out[i] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *d.counter = c + 1;
+}
+
 // Sum of the `nslab` split-K partial slabs of one float4, in slab order (the order every fold of these slabs uses: same bits).
 // Four loads are issued before the first add -- a loop of load / add pairs with a run-time trip count is a chain of nslab
 // memory latencies, and the kernels that fold (3-4 slabs, a few rows per workgroup) are nothing but that chain.

@@ -277,27 +277,7 @@ __global__ __launch_bounds__(256) void adamw_kernel_blocks(float* __restrict__ p
 // ---------------------------------------------------------------- DropPath draws (tulip.py:25-29, timm drop_path)
 // scale[slot][b] = floor(keep[slot] + u) / keep[slot], u ~ U[0,1) from a counter-based generator keyed by
 // (seed, step counter, index): one launch per step, graph-replayable (the counter lives in device memory).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__global__ __launch_bounds__(256) void drop_scales_kernel(const float* __restrict__ keep, float* __restrict__ scale,
-                                                          float* __restrict__ u_out, int nslots, int B,
-                                                          unsigned long long seed,
-                                                          unsigned long long* __restrict__ counter) {
-    const unsigned long long c = *counter;
-    const int n = nslots * B;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const uint64_t r = mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (c + 1)) ^ (0xD1B54A32D192ED03ull * (uint64_t)(i + 1)));
-        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
-        const float k = keep[i / B];
-        scale[i] = floorf(k + u) / k;
-        if (u_out) u_out[i] = u;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *counter = c + 1;
-}
+__global__ __launch_bounds__(256) void drop_scales_kernel(const DropDraw d) { drop_draw_block(d); }
 
 // ---------------------------------------------------------------- gradient L2 norm (misc.py:317-329)
 // fixed block -> partial mapping and a fixed fold order: the read-out is run-to-run deterministic
@@ -489,8 +469,8 @@ extern "C" int tulip_adamw_blocks(float* p, float* g, float* m, float* v, uint16
 extern "C" int tulip_drop_path_scales(const float* keep, float* scale, float* u_out, int nslots, int B,
                                       uint64_t seed, uint64_t* counter, hipStream_t stream) {
     if (!keep || !scale || !counter || nslots <= 0 || B <= 0) return TULIP_ERR_ARG;
-    hipLaunchKernelGGL(drop_scales_kernel, dim3(1), dim3(256), 0, stream, keep, scale, u_out, nslots, B,
-                       (unsigned long long)seed, (unsigned long long*)counter);
+    hipLaunchKernelGGL(drop_scales_kernel, dim3(1), dim3(256), 0, stream,
+                       DropDraw{keep, scale, u_out, nslots, B, (unsigned long long)seed, (unsigned long long*)counter});
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

@@ -335,8 +335,9 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_row_kernel(const float* _
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* __restrict__ out,
                                                                   bf16_t* __restrict__ out16, int ld16, EmbedGeom g,
-                                                                  float eps) {
+                                                                  float eps, const DropDraw dd) {
     constexpr int UNR = 4;
+    if (dd.keep && blockIdx.x == 0) drop_draw_block(dd);         // (block-uniform) the step's DropPath draws: nobody in this launch reads them
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int ntok = g.B * g.Ho * g.Wo;
@@ -787,19 +788,38 @@ extern "C" int tulip_patch_embed_fwd(const float* img, const float* w, const flo
                                      const float* beta, float* out, int B, int Cin, int Hin, int Win, int E, int p0,
                                      int p1, int kw, int circular, float eps, uint16_t* out_bf16, int ld_bf16,
                                      hipStream_t stream) {
+    return tulip_patch_embed_fwd_draw(img, w, b, gamma, beta, out, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps, out_bf16, ld_bf16,
+                                      nullptr, stream);
+}
+
+extern "C" int tulip_patch_embed_fwd_draw(const float* img, const float* w, const float* b, const float* gamma,
+                                          const float* beta, float* out, int B, int Cin, int Hin, int Win, int E, int p0,
+                                          int p1, int kw, int circular, float eps, uint16_t* out_bf16, int ld_bf16,
+                                          const tulip_drop_draw* draw, hipStream_t stream) {
     EmbedGeom g;
     if (!embed_geom(g, B, Cin, Hin, Win, E, p0, p1, kw, circular)) return TULIP_ERR_ARG;
+    if (draw && (!draw->keep || !draw->scale || !draw->counter || draw->nslots <= 0 || draw->B <= 0)) return TULIP_ERR_ARG;
     const int ntok = g.B * g.Ho * g.Wo;
+    const bool row = g.Cin == 1 && g.p0 == 1 && g.taps == g.kw && (g.kw == 8 || g.kw == 4) && E <= 128 && ntok > 0;
+    DropDraw dd{nullptr, nullptr, nullptr, 0, 0, 0ull, nullptr};
+    if (draw && row) {
+        dd = DropDraw{draw->keep, draw->scale, draw->u_out, draw->nslots, draw->B, (unsigned long long)draw->seed,
+                      (unsigned long long*)draw->counter};
+    } else if (draw) {           // the generic kernels: the draw keeps its own launch
+        const int rc = tulip_drop_path_scales(draw->keep, draw->scale, draw->u_out, draw->nslots, draw->B, draw->seed, draw->counter,
+                                              stream);
+        if (rc != TULIP_OK) return rc;
+    }
     if (ntok <= 0) return TULIP_OK;
     const int grid = std::min((ntok + 3) / 4, 256 * 8);
-    if (g.Cin == 1 && g.p0 == 1 && g.taps == g.kw && (g.kw == 8 || g.kw == 4) && E <= 128) {
+    if (row) {
         const int grid4 = std::min((ntok + 15) / 16, 256 * 2);   // 8 waves per CU, each amortises its weight loads
         if (g.kw == 8)
             hipLaunchKernelGGL(patch_embed_fwd_row_kernel<8>, dim3(grid4), dim3(256), 0, stream, img, w, b, gamma, beta,
-                               out, (bf16_t*)out_bf16, ld_bf16, g, eps);
+                               out, (bf16_t*)out_bf16, ld_bf16, g, eps, dd);
         else
             hipLaunchKernelGGL(patch_embed_fwd_row_kernel<4>, dim3(grid4), dim3(256), 0, stream, img, w, b, gamma, beta,
-                               out, (bf16_t*)out_bf16, ld_bf16, g, eps);
+                               out, (bf16_t*)out_bf16, ld_bf16, g, eps, dd);
         TULIP_CHECK_LAUNCH();
         return TULIP_OK;
     }

@@ -440,17 +440,25 @@ class TulipEngine:
     # ------------------------------------------------------------------ forward
     def draw_drop_scales(self, P: Plan, train: bool, drop_u: Optional[torch.Tensor] = None):
         """DropPath multipliers floor(keep+u)/keep per (block branch, sample) (tulip.py:25-29)."""
+        self._pending_draw = None
         if not train or self.n_drop_slots == 0:
             P.drop_scale.fill_(1.0)
             return
         if drop_u is None:
-            # one launch; the step counter lives on the device, so a graph replay draws fresh numbers
-            ops.drop_path_scales(self._keep, P.drop_scale, P.drop_u, self.n_drop_slots, P.B, self._drop_seed,
-                                 self._drop_counter)
+            # the step counter lives on the device, so a graph replay draws fresh numbers.  The draw rides in the forward's first
+            # launch (tulip_patch_embed_fwd_draw: run_forward picks it up) instead of being a launch of its own at the head of the chain
+            draw = (self._keep, P.drop_scale, P.drop_u, self.n_drop_slots, P.B, self._drop_seed, self._drop_counter)
+            if self.draw_in_embed:
+                self._pending_draw = (P, draw)
+            else:
+                ops.drop_path_scales(*draw)
             return
         P.drop_u.copy_(drop_u)                     # injected draws (parity tests against the oracle)
         torch.floor(self._keep + P.drop_u, out=P.drop_scale)
         P.drop_scale.div_(self._keep)
+
+    draw_in_embed = os.environ.get("TULIP_DRAW_IN_EMBED", "1") != "0"
+    _pending_draw = None
 
     def _ds(self, P: Plan, sp: BlockSpec, branch: int):
         if sp.slot < 0:
@@ -674,11 +682,16 @@ class TulipEngine:
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
         kw = 8 if m.circular_padding else m.patch_size[1]
+        pend, self._pending_draw = self._pending_draw, None
+        if pend is not None and pend[0] is not P:          # (drawn for another plan: issue it on its own)
+            ops.drop_path_scales(*pend[1])
+            pend = None
         ops.patch_embed_fwd(P.x_in, W_.p32("patch_embed.proj.weight"), W_.p32("patch_embed.proj.bias"),
                             W_.p32("patch_embed.norm.weight"), W_.p32("patch_embed.norm.bias"), P["enc0.in"], B,
                             m.in_chans, m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw,
                             m.circular_padding, self.eps,
-                            out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E)
+                            out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E,
+                            draw=pend[1] if pend is not None else None)
         two_packs = pack_on_side and W_.pk_active and self.split_pack and nl > 2
         if pack_on_side and W_.pk_active:
             self._fork_pack(0 if two_packs else None)

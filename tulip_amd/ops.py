@@ -161,10 +161,19 @@ def layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, rows, C, merge=False,
 
 
 def patch_embed_fwd(img, w, b, gamma, beta, out, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps, out_bf16=None,
-                    ld_bf16=0):
-    rc = _lib.load().tulip_patch_embed_fwd(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, Hin, Win, E,
-                                           p0, p1, kw, int(circular), eps, _p(out_bf16), ld_bf16, _stream())
-    check(rc, "tulip_patch_embed_fwd")
+                    ld_bf16=0, draw=None):
+    """draw = (keep, scale, u_out, nslots, B, seed, counter): the step's DropPath draws (drop_path_scales) ride in this launch."""
+    if draw is None:
+        rc = _lib.load().tulip_patch_embed_fwd(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, Hin, Win, E,
+                                               p0, p1, kw, int(circular), eps, _p(out_bf16), ld_bf16, _stream())
+        check(rc, "tulip_patch_embed_fwd")
+        return
+    keep, scale, u_out, nslots, Bd, seed, counter = draw
+    dd = _lib.DropDraw(_p(keep), _p(scale), _p(u_out), nslots, Bd, int(seed) & (2 ** 64 - 1), _p(counter))
+    rc = _lib.load().tulip_patch_embed_fwd_draw(_p(img), _p(w), _p(b), _p(gamma), _p(beta), _p(out), B, Cin, Hin, Win, E,
+                                                p0, p1, kw, int(circular), eps, _p(out_bf16), ld_bf16, ctypes.byref(dd),
+                                                _stream())
+    check(rc, "tulip_patch_embed_fwd_draw")
 
 
 def patch_embed_bwd(img, w, b, gamma, dout, dw, db, dgamma, dbeta, B, Cin, Hin, Win, E, p0, p1, kw, circular, eps,
