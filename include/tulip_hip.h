@@ -493,6 +493,9 @@ int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t strea
 /* diagnostics: *dst = the 100 MHz constant device clock (s_memrealtime) when the stream reaches this point; capturable
  * (tools/step_stamps.py time-lines a captured training step with it, no tracer attached) */
 int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream);
+/* Layout version of the structs and signatures in this header (round 3: tulip_wgrad_item, tulip_reduce_region and tulip_adamw_ref grew
+ * fields, entry points were added): a caller built against another version must not bind. */
+#define TULIP_ABI_VERSION 3
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);
 

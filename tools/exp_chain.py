@@ -51,7 +51,7 @@ def no_adamw(eng):
 
 
 run("full step", lambda e: None)
-run("no weight-gradient GEMMs (folds stay)", no_wgrad)
+run("no weight-gradient GEMMs (folds stay; every weight is then stepped by the full AdamW launch at the end)", no_wgrad)
 from tulip_amd import ops as _ops
 _rg, _rr = _ops.wgrad_group, _ops.reduce_rows_multi
 run("weight-gradient GEMMs, nothing folded", no_folds)

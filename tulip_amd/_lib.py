@@ -60,6 +60,7 @@ class PackItem(ctypes.Structure):
 
 
 REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 64
+ABI_VERSION = 3      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -162,7 +163,7 @@ def load() -> ctypes.CDLL:
             raise TulipHipError(f"symbol {name} missing from {LIB_PATH}") from e
         fn.argtypes = argtypes
         fn.restype = c_char_p if name == "tulip_build_arch" else c_int
-    if lib.tulip_abi_version() != 1:
+    if lib.tulip_abi_version() != ABI_VERSION:
         raise TulipHipError("libtulip_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

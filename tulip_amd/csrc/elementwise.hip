@@ -495,5 +495,5 @@ extern "C" int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream) {
     return TULIP_OK;
 }
 
-extern "C" int tulip_abi_version(void) { return 1; }
+extern "C" int tulip_abi_version(void) { return TULIP_ABI_VERSION; }
 extern "C" const char* tulip_build_arch(void) { return "gfx950"; }
