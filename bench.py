@@ -170,7 +170,7 @@ def kernel_rooflines(trainer, reps=5):
             deep = deep and kchunk >= 256
             f += 2.0 * it.Nw * it.Kw * it.Mtok
             by += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * it.Nw * it.Kw + 4.0 * it.Nw      # operands once, fp32 dW + db once
-            if it.dW in trainer.eng.adam_fused and eff == 1:     # (a token-split item's step is taken by the fold of its slabs)
+            if it.reserved_ == 1 and eff == 1:     # (a token-split item's step is taken by the fold of its slabs)
                 # in the step this item's write-out takes the AdamW step (Trainer.fuse_adamw): parameter + two moments read and
                 # written, bf16 shadow written, the gradient itself never stored (26 B instead of 4 B per element)
                 by += 22.0 * it.Nw * it.Kw
@@ -180,7 +180,7 @@ def kernel_rooflines(trainer, reps=5):
         # the weight gradients of a stage leave as ONE grouped launch; timed without its fold (the `fold` family)
         rec.append(("wgrad", "wgrad_group_kernel (192x192 / 384x96 / 96x384 tiles)" if big
                     else f"gemm_group_kernel<64, true, true, {ksub}>",
-                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False), f, by, slab))
+                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False, adam=adam), f, by, slab))
         real["wgrad_group"](items, extra, ws, ws_bytes, fold, adam)
 
     def block(name, fam, bwd, C_of):
@@ -204,7 +204,10 @@ def kernel_rooflines(trainer, reps=5):
     for n, fn in patched.items():
         setattr(ops, n, fn)
     try:
-        trainer._fwd_bwd(lambda tag: None)
+        # the recording pass issues what a captured step issues, optimizer steps in the weight-gradient write-outs included (the
+        # isolated re-launches below then move the bytes `algorithmic_bytes_per_launch` counts; this runs after the timed steps,
+        # the parameters are not used again)
+        trainer._fwd_bwd(lambda tag: None, apply_adamw=trainer._adam_mask is not None)
         torch.cuda.synchronize()
     finally:
         for n in patched:
