@@ -688,6 +688,9 @@ def main():
         out["comm"] = comm_report(trainer, args, world, device)
         out["comm"]["world_size_rccl"] = dist.get_world_size()
         out["comm"]["backend"] = dist.get_backend()
+        # graphs per step: the chain's segments (cut at the bucket points) + the detached last side group of each bucket
+        out["comm"]["graph_segments"] = len(trainer._segments[True]) if getattr(trainer, "_segments", None) else 0
+        out["comm"]["detached_bucket_graphs"] = len(getattr(trainer, "_det_graphs", {}))
         out["comm"]["collective_smoke"] = smoke
         out["comm"]["launcher"] = "bench.py spawn_ranks" if os.environ.get("TULIP_BENCH_SPAWNED") else "external (torch.distributed.run)"
     if rank == 0 and world == 1 and not args.no_secondary and args.batch == 8 and args.model == "tulip_base":

@@ -27,6 +27,7 @@ def main():
     lo, hi = O.synthetic_batch(cfg, 4, seed=77)
     res = {"init": Trainer(build(cfg, sd, train=True), 4, use_graph=False).eng.params.flat.cpu()}
     for name, kw in [("plain", dict()), ("segments", dict(force_segments=True, bucket_mb=0.05)),
+                     ("segments_joined", dict(force_segments=True, bucket_mb=0.05)),     # TULIP_DETACH_BUCKETS=0, see below
                      ("segments_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, bucket_adamw=True)),
                      ("segments_bf16", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16")),
                      ("segments_bf16_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16",
@@ -35,13 +36,16 @@ def main():
                      ("eager_segments", dict(force_segments=True, bucket_mb=0.05, use_graph=False))]:
         torch.manual_seed(11)
         m = build(cfg, sd, train=True)
+        # "segments": the last side group of a bucket is a graph of its own behind the segment (Trainer.detach_buckets, the default);
+        # "segments_joined": forked inside the segment and joined at the cut
+        os.environ["TULIP_DETACH_BUCKETS"] = "0" if name == "segments_joined" else "1"
         tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, **kw)
         tr.load_batch(lo.cuda(), hi.cuda())
         losses = [tr.step().clone() for _ in range(steps)]
         torch.cuda.synchronize()
         res[name] = {"flat": tr.eng.params.flat.cpu(), "losses": torch.stack(losses).cpu(),
                      "segments": len(tr._segments[True]) if tr.use_graph else 0, "buckets": len(tr.bucketer.buckets),
-                     "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw}
+                     "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw, "detached": len(tr._det_graphs)}
     from tests.conftest import describe_flat_diff
     for name in [k for k in res if k != "init"]:
         ref = res["eager_plain"] if name.startswith("eager") else res["plain"]

@@ -35,10 +35,12 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
         print(f"{name}: update-vector relative L2 difference to the fp32 exchange {rel:.3e}")
         assert g["segmented"] and 0 < rel <= 3e-2, (name, rel)
         assert (g["losses"][-1, 0] - plain["losses"][-1, 0]).abs().item() <= 2e-2 * plain["losses"][-1, 0].item()
-    for name in ("segments", "segments_bucket_adamw", "eager_segments"):
+    # the bucket's last side group as a graph of its own behind the segment (the default) / forked and joined inside it
+    assert got["segments"]["detached"] >= 2 and got["segments_joined"]["detached"] == 0
+    for name in ("segments", "segments_joined", "segments_bucket_adamw", "eager_segments"):
         g = got[name]
         assert g["segmented"] and g["buckets"] >= 2
-        if name == "segments":
+        if name in ("segments", "segments_joined"):
             assert g["segments"] == g["buckets"] + 1 and not g["bucket_adamw"]
         if name == "segments_bucket_adamw":
             assert g["segments"] == g["buckets"] and g["bucket_adamw"]

@@ -1033,6 +1033,22 @@ class TulipEngine:
         with torch.cuda.stream(st):
             self._issue_pending(ws, pending)
 
+    # run_backward(join_tags=...) under Trainer._capture: see hook() in run_backward
+    detach_buckets = False
+    _detached = None
+
+    def take_detached(self):
+        d, self._detached = self._detached, None
+        return d
+
+    def issue_detached(self, pending, ws: int):
+        """The side group hook() held back, on the CURRENT stream (the capture of its own graph); the scatter regions it leaves
+        for "the next side launch" are folded right behind it."""
+        self._issue_pending(ws, pending)
+        if self._carry:
+            carry, self._carry = list(self._carry), ()
+            ops.reduce_rows_multi(carry, adam=self._adam_arg())
+
     def _wait_side(self):
         """The current stream waits for everything issued on the side streams so far (queued work stays queued)."""
         self._release_deferred()
@@ -1261,6 +1277,7 @@ class TulipEngine:
         B, E, nl = P.B, m.embed_dim, m.num_layers
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
+        self._detached = None
         self.grad_overwrite = bool(overwrite)
         self._gflat = gflat
         self.adam_apply = bool(apply_adamw and overwrite and self.adam_ctx is not None)
@@ -1281,8 +1298,19 @@ class TulipEngine:
             if self._lagged_hook is not None:           # two hooks without a block in between
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
-            self._flush_wgrads()
             bucket = join_tags is not None and tag in join_tags
+            if bucket and self.detach_buckets and tag != "embed" and self.overlap_wgrad and self._pending:
+                # The bucket's LAST side group is not forked inside this capture at all: the caller (Trainer._capture) ends the
+                # chain's graph segment here, captures the group as a graph of its own (issue_detached) that is replayed on
+                # another stream behind the segment, with the bucket's all-reduce behind it -- and the chain's next segment
+                # starts at once instead of waiting for the group at the cut.  Older groups of the bucket were forked inside
+                # the segment and are joined here (they ran beside the bucket's last blocks).
+                self._release_deferred()
+                self._detached, self._pending = self._pending, []
+                self._wait_side()
+                user_hook(tag)
+                return
+            self._flush_wgrads()
             if tag == "embed":
                 join_and_fire(tag)
             elif bucket and self.lag_bucket_join:

@@ -119,6 +119,15 @@ class Trainer:
         # step stopped making progress (a hung collective shows as the segment tag it followed)
         self.progress = (0, "init")
         self._side = torch.cuda.Stream(device=device) if use_graph else None
+        # N > 1, captured steps: the last side group of every bucket but the final one is a graph of its own on this stream (own
+        # split-K workspace), so that a cut of the step graph does not make the chain wait for it (TULIP_DETACH_BUCKETS=0: the
+        # group is forked inside the segment and joined at the cut, one block late)
+        self.detach_buckets = bool(use_graph and self.segmented and not self.bucket_adamw
+                                   and os.environ.get("TULIP_DETACH_BUCKETS", "1") != "0")
+        self._det_stream = torch.cuda.Stream(device=device) if self.detach_buckets else None
+        self._ws_det = (torch.empty(self.eng.WS_ELEMS + (1 << 20), dtype=torch.float32, device=device)
+                        if self.detach_buckets else None)
+        self._det_graphs, self._det_events = {}, {}
         self.process_group = process_group
         if self.world > 1:
             # DistributedDataParallel's constructor broadcasts rank 0's parameters and buffers (main_lidar_upsampling.py:277
@@ -338,6 +347,8 @@ class Trainer:
         Capture mode is thread-local: HIP calls of other threads (the RCCL watchdog polling its events) must not
         invalidate the capture."""
         segs = []
+        if update:
+            self._det_graphs = {}
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -347,13 +358,29 @@ class Trainer:
             def hook(tag):
                 nonlocal cur
                 if update and self.segmented and tag in self.bucketer.by_tag:
-                    self._cast_bucket_down(tag)
+                    det = self.eng.take_detached()
+                    if det is None:
+                        self._cast_bucket_down(tag)
                     cur.capture_end()
+                    if det is not None:
+                        # the bucket's last side group as a graph of its own (TulipEngine.detach_buckets): replayed behind this
+                        # segment on the detached stream, the all-reduce behind it; the chain's next segment does not wait for it
+                        sg = torch.cuda.CUDAGraph()
+                        with torch.cuda.stream(self._det_stream):
+                            sg.capture_begin(capture_error_mode="thread_local")
+                            self.eng.issue_detached(det, self._ws_det.data_ptr())
+                            self._cast_bucket_down(tag)
+                            sg.capture_end()
+                        self._det_graphs[tag] = sg
                     segs.append((cur, tag))
                     cur = torch.cuda.CUDAGraph()
                     cur.capture_begin(capture_error_mode="thread_local")
 
-            self._fwd_bwd(hook, update, apply_adamw=update and self._adam_mask is not None)
+            self.eng.detach_buckets = bool(update and self.segmented and self.detach_buckets)
+            try:
+                self._fwd_bwd(hook, update, apply_adamw=update and self._adam_mask is not None)
+            finally:
+                self.eng.detach_buckets = False
             if not update:
                 cur.capture_end()
                 segs.append((cur, None))
@@ -452,7 +479,16 @@ class Trainer:
                 graph.replay()
                 if tag is not None:
                     self.progress = (self.t, f"all_reduce:{tag}")
-                    self._bucket_done(tag)
+                    sg = self._det_graphs.get(tag) if update else None
+                    if sg is None:
+                        self._bucket_done(tag)
+                    else:
+                        ev = self._det_events.setdefault(tag, torch.cuda.Event())
+                        ev.record()
+                        with torch.cuda.stream(self._det_stream):
+                            self._det_stream.wait_event(ev)
+                            sg.replay()
+                            self._bucket_done(tag)
         if update and self.bucket_adamw:
             self._finish_buckets()
         self.eng.params.pack_dirty = self.eng.params.pack_dirty or mark_pack_dirty
