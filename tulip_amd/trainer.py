@@ -122,8 +122,7 @@ class Trainer:
         # N > 1, captured steps: the last side group of every bucket but the final one is a graph of its own on this stream (own
         # split-K workspace), so that a cut of the step graph does not make the chain wait for it (TULIP_DETACH_BUCKETS=0: the
         # group is forked inside the segment and joined at the cut, one block late)
-        self.detach_buckets = bool(use_graph and self.segmented and not self.bucket_adamw
-                                   and os.environ.get("TULIP_DETACH_BUCKETS", "1") != "0")
+        self.detach_buckets = bool(use_graph and self.segmented and os.environ.get("TULIP_DETACH_BUCKETS", "1") != "0")
         self._det_stream = torch.cuda.Stream(device=device) if self.detach_buckets else None
         self._ws_det = (torch.empty(self.eng.WS_ELEMS + (1 << 20), dtype=torch.float32, device=device)
                         if self.detach_buckets else None)
