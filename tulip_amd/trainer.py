@@ -482,7 +482,9 @@ class Trainer:
                     if sg is None:
                         self._bucket_done(tag)
                     else:
-                        ev = self._det_events.setdefault(tag, torch.cuda.Event())
+                        ev = self._det_events.get(tag)
+                        if ev is None:
+                            ev = self._det_events[tag] = torch.cuda.Event()
                         ev.record()
                         with torch.cuda.stream(self._det_stream):
                             self._det_stream.wait_event(ev)
