@@ -31,16 +31,22 @@ __device__ __forceinline__ void load_x(const bf16_t* __restrict__ xn, const Tail
         }
 }
 
-template <int KS>
+// FULL: E == 32 KS, every lane's 8 columns exist -- no exec-masked branch (and no zero fill) around each of the KS loads of a channel:
+// with them the channel loop was 82 instructions for 6 MFMAs, and four waves per SIMD take turns on its issue slots
+template <int KS, bool FULL = false>
 __device__ __forceinline__ void expand_channel(const bf16_t* __restrict__ We, const TailGeom& g, int c, int li, int gq,
                                                const bf16x8 (&xb)[2][KS], f32x4 (&acc)[2]) {
     bf16x8 wa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int k = ks * 32 + gq * 8;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (k < g.E) v = *(const bf16x8*)(We + (size_t)(c * 16 + li) * g.E + k);
-        wa[ks] = v;
+        if constexpr (FULL) {
+            wa[ks] = *(const bf16x8*)(We + (size_t)(c * 16 + li) * (KS * 32) + k);
+        } else {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (k < g.E) v = *(const bf16x8*)(We + (size_t)(c * 16 + li) * g.E + k);
+            wa[ks] = v;
+        }
     }
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
@@ -50,6 +56,9 @@ __device__ __forceinline__ void expand_channel(const bf16_t* __restrict__ We, co
         acc[mf] = a;  // a[r] = Z[token li of frag mf][c*16 + 4*gq + r]
     }
 }
+
+// LeakyReLU(0.01)(z) = max(z, 0.01 z): the same value as the compare / select form, two instructions instead of three
+__device__ __forceinline__ float leaky01(float z) { return fmaxf(z, 0.01f * z); }
 
 __device__ __forceinline__ size_t pred_off(const TailGeom& g, int tok, int i) {
     const int t = fast_div(tok, g.W), w = tok - t * g.W;
@@ -71,20 +80,20 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const bf16_t* __restri
     load_x<KS>(xn, g, m0, li, gq, xb);
     float pacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int cper = (g.E + 3) / 4, c0 = wid * cper, c1 = min(g.E, c0 + cper);
-    for (int c = c0; c < c1; ++c) {
-        f32x4 acc[2];
-        expand_channel<KS>(We, g, c, li, gq, xb, acc);
-        const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
-        const float wc = wd[c];
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    auto channels = [&](auto F) {
+        for (int c = c0; c < c1; ++c) {
+            f32x4 acc[2];
+            expand_channel<KS, decltype(F)::value>(We, g, c, li, gq, xb, acc);
+            const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
+            const float wc = wd[c];
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+            for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = acc[mf][r] + bb[r];
-                pacc[mf][r] += wc * (z > 0.f ? z : 0.01f * z);
-            }
-    }
+                for (int r = 0; r < 4; ++r) pacc[mf][r] += wc * leaky01(acc[mf][r] + bb[r]);
+        }
+    };
+    if (g.E == KS * 32) channels(std::true_type{}); else channels(std::false_type{});      // (uniform)
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
         *(float4*)&red[wid][mf * 16 + li][gq * 4] = make_float4(pacc[mf][0], pacc[mf][1], pacc[mf][2], pacc[mf][3]);
@@ -170,20 +179,20 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_ln_kernel(const TailNorm nrm,
     }
     float pacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int cper = (g.E + 3) / 4, c0 = wid * cper, c1 = min(g.E, c0 + cper);
-    for (int c = c0; c < c1; ++c) {
-        f32x4 acc[2];
-        expand_channel<KS>(We, g, c, li, gq, xb, acc);
-        const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
-        const float wc = wd[c];
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    auto channels = [&](auto F) {
+        for (int c = c0; c < c1; ++c) {
+            f32x4 acc[2];
+            expand_channel<KS, decltype(F)::value>(We, g, c, li, gq, xb, acc);
+            const float4 b4 = *(const float4*)(be + c * 16 + gq * 4);
+            const float wc = wd[c];
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+            for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = acc[mf][r] + bb[r];
-                pacc[mf][r] += wc * (z > 0.f ? z : 0.01f * z);
-            }
-    }
+                for (int r = 0; r < 4; ++r) pacc[mf][r] += wc * leaky01(acc[mf][r] + bb[r]);
+        }
+    };
+    if (g.E == KS * 32) channels(std::true_type{}); else channels(std::false_type{});      // (uniform)
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
         *(float4*)&red[wid][mf * 16 + li][gq * 4] = make_float4(pacc[mf][0], pacc[mf][1], pacc[mf][2], pacc[mf][3]);
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_dgrad_kernel(const bf16_t* __
             for (int ks = 0; ks < KS; ++ks) {
                 const int k = ks * 32 + gq * 8;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (k < E) {
+                if (NB == 2 * KS || k < E) {              // (E == 32 KS at compile time: no branch around the load, see expand_channel)
                     v = *(const bf16x8*)(We + (size_t)((c + cc) * 16 + li) * E + k);
                     *(bf16x8*)(tile + (cc * 16 + li) * PITCH + k * 2) = v;
                 }
