@@ -72,6 +72,9 @@ def _gemm_instance(M, N, K, a_trans, b_trans, splits):
         grid = gn * -(-M // 64) * eff
         ksub = 4 if (grid <= 400 and kchunk >= 256) else 1
     t = lambda f: "true" if f else "false"
+    bks = 128 if ksub == 4 else 32
+    if not a_trans and M % bm == 0 and N % 96 == 0 and kchunk % bks == 0 and K % kchunk == 0:
+        return f"gemm_kernel_full<{bm}, {t(b_trans)}, {ksub}>"          # whole tiles only: no bounds tests around the loads
     return f"gemm_kernel<{bm}, {t(a_trans)}, {t(b_trans)}, {ksub}>"
 
 

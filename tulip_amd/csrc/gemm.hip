@@ -21,6 +21,7 @@
 // per-sample DropPath multiplier, PixelShuffle(2) scatter (PatchUnmerging) and its inverse, fp32 accumulate, and
 // split-K partial slabs (deterministic fold).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "tulip_hip.h"
@@ -54,6 +55,7 @@ struct GemmArgs {
 };
 
 int gemm_touch_on = 1;
+int gemm_full_on = getenv("TULIP_GEMM_FULL") ? atoi(getenv("TULIP_GEMM_FULL")) : 1;     // dev switch: 0 = the bounds-checked kernels everywhere
 
 // launch heuristics (compile-time; mirrored by bench.py's kernel-name bookkeeping)
 #define TULIP_GEMM_MID_TILES 512    // taller tiles only while the launch still has this many of them (two rounds of the chip)
@@ -76,7 +78,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
 // ---- global -> registers (16 B chunks), zero fill out of range -------------------------------
-template <int ROWS, bool T, int KSUB>
+// FULL: the launcher checked that every tile is whole (M, N multiples of the tile, the K range of a workgroup a multiple of the
+// stage depth): no bounds test -- i.e. no exec-masked branch and no zero fill -- around the loads (the bounds-checked kernel carries
+// 92 s_and_saveexec and 113 v_mov for its 64 static loads; 37 chain GEMMs of the batch-8 step isolated: 381 -> 355 us).  Walking the
+// 96-row operand's 4 x 384 chunks as ONE list of 6 per thread, which also removes the half-empty second slot per sub-tile,
+// measured much slower (522 us) and is not done.
+template <int ROWS, bool T, int KSUB, bool FULL = false>
 struct Stage {
     static constexpr int NCHUNK = ROWS * 4;                 // 16-B chunks per 32-deep k sub-tile
     static constexpr int PER_THREAD = (NCHUNK + 255) / 256;
@@ -98,12 +105,12 @@ struct Stage {
                     if (!T) {
                         int row = c >> 2, kc = c & 3;
                         int gr = row0 + row, gk = ks + kc * 8;
-                        if (gr < nrows && gk < kend) v = *(const uint4*)(base + (size_t)gr * ld + gk);
+                        if (FULL || (gr < nrows && gk < kend)) v = *(const uint4*)(base + (size_t)gr * ld + gk);
                     } else {
                         constexpr int CPR = ROWS / 8;  // chunks per k row
                         int k = c / CPR, mc = c % CPR;
                         int gk = ks + k, gr = row0 + mc * 8;
-                        if (gk < kend && gr < nrows) v = *(const uint4*)(base + (size_t)gk * ld + gr);
+                        if (FULL || (gk < kend && gr < nrows)) v = *(const uint4*)(base + (size_t)gk * ld + gr);
                     }
                 }
                 r[sidx][i] = v;
@@ -262,12 +269,12 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
 }
 
 // one output tile (bx, by) of K range bz: the body of both the plain and the grouped launch
-template <int BM, bool A_T, bool B_T, int KSUB>
+template <int BM, bool A_T, bool B_T, int KSUB, bool FULL = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz) {
     constexpr int FM = BM / 32;  // 16-row fragments per wave in M
     constexpr int FN = 3;
-    using SA = Stage<BM, A_T, KSUB>;
-    using SB = Stage<BN, B_T, KSUB>;
+    using SA = Stage<BM, A_T, KSUB, FULL>;
+    using SB = Stage<BN, B_T, KSUB, FULL>;
     constexpr int A_BYTES = KSUB * SA::SUB_BYTES, B_BYTES = KSUB * SB::SUB_BYTES;
     constexpr int BKS = BK * KSUB;  // k depth of one pipeline stage
     constexpr int STG_PITCH = BN * 4 + 16;                 // fp32 staging row pitch (bank-spread)
@@ -441,6 +448,11 @@ template <int BM, bool A_T, bool B_T, int KSUB>
 // MFMAs with AGPR accumulators issue at ~60 % of the rate, tools/probe_mfma.hip; the 128-deep k stages take 80-150 KB of LDS)
 __global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
     gemm_tile<BM, A_T, B_T, KSUB>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// whole tiles only (Stage<..., FULL>): the forward / data-gradient form -- what the GEMMs of the bench configurations launch
+template <int BM, bool B_T, int KSUB>
+__global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_kernel_full(const GemmArgs p) {
+    gemm_tile<BM, false, B_T, KSUB, true>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several independent GEMMs in ONE launch (the weight gradients of a Swin block: each alone fills a fraction of the
@@ -780,16 +792,34 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
     if (bm == 64) {
         dim3 grid(gn, (p.M + 63) / 64, splits);
         // 128-deep k stages (80-150 KB LDS, 1-2 workgroups/CU) pay while the grid is at most ~1.5 waves of the chip
-        if ((int)(grid.x * grid.y * grid.z) <= TULIP_GEMM_KSUB_GRID && p.kchunk >= 256)
+        const bool deep = (int)(grid.x * grid.y * grid.z) <= TULIP_GEMM_KSUB_GRID && p.kchunk >= 256;
+        const int bks = deep ? 128 : 32;
+        const bool full = gemm_full_on && !A_T && p.M % 64 == 0 && p.N % BN == 0 && p.kchunk % bks == 0 && p.K % p.kchunk == 0;
+        if constexpr (!A_T) {
+            if (full) {
+                if (deep) hipLaunchKernelGGL((gemm_kernel_full<64, B_T, 4>), grid, dim3(256), 0, stream, p);
+                else hipLaunchKernelGGL((gemm_kernel_full<64, B_T, 1>), grid, dim3(256), 0, stream, p);
+                TULIP_CHECK_LAUNCH();
+                return TULIP_OK;
+            }
+        }
+        if (deep)
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 4>), grid, dim3(256), 0, stream, p);
         else
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
-    } else if (bm == 256) {
-        dim3 grid(gn, (p.M + 255) / 256, splits);
-        hipLaunchKernelGGL((gemm_kernel<256, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
     } else {
-        dim3 grid(gn, (p.M + 127) / 128, splits);
-        hipLaunchKernelGGL((gemm_kernel<128, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
+        const bool full = gemm_full_on && !A_T && p.M % bm == 0 && p.N % BN == 0 && p.kchunk % 32 == 0 && p.K % p.kchunk == 0;
+        dim3 grid(gn, (p.M + bm - 1) / bm, splits);
+        if constexpr (!A_T) {
+            if (full) {
+                if (bm == 256) hipLaunchKernelGGL((gemm_kernel_full<256, B_T, 1>), grid, dim3(256), 0, stream, p);
+                else hipLaunchKernelGGL((gemm_kernel_full<128, B_T, 1>), grid, dim3(256), 0, stream, p);
+                TULIP_CHECK_LAUNCH();
+                return TULIP_OK;
+            }
+        }
+        if (bm == 256) hipLaunchKernelGGL((gemm_kernel<256, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<128, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
     }
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
