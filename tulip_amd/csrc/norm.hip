@@ -28,7 +28,8 @@ __device__ __forceinline__ size_t src_off(const RowGeom& g, int row, int e) {
 
 // ------------------------------------------------------------------ forward
 // LPR lanes per row, NCH float4 chunks per lane held in registers (C <= 4*LPR*NCH)
-template <int LPR, int NCH>
+// EXACT: C == 4 LPR NCH (the launcher checked): no lane ever holds a chunk beyond the row -- no exec-masked branch around the loads
+template <int LPR, int NCH, bool EXACT = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * LPR;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 v[i] = *(const float4*)(x + src_off(g, row, c * 4));
                 s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             } else {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * LPR;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
                 ss += (a * a + b * b) + (cc * cc + d * d);
             }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * LPR;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 const float4 ga = *(const float4*)(gamma + c * 4);
                 const float4 be = *(const float4*)(beta + c * 4);
                 const float o0 = (v[i].x - mu) * rs * ga.x + be.x, o1 = (v[i].y - mu) * rs * ga.y + be.y;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------ backward (dx)
-template <int LPR, int NCH>
+template <int LPR, int NCH, bool EXACT = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx,
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * LPR;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 const float4 xv = *(const float4*)(x + src_off(g, row, c * 4));
                 uint2 d;
                 if (slabs) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * LPR;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 const size_t off = src_off(g, row, c * 4);
                 float4 o = make_float4(rs * (gy[i].x - m1 - xh[i].x * m2), rs * (gy[i].y - m1 - xh[i].y * m2),
                                        rs * (gy[i].z - m1 - xh[i].z * m2), rs * (gy[i].w - m1 - xh[i].w * m2));
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * LPR;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 *(float4*)(mine + c * 4) = pg[i];
                 *(float4*)(mine + g.C + c * 4) = pb[i];
             }
@@ -231,12 +232,21 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const bf16_t* __rest
 template <typename F>
 int dispatch_ln(int C, F&& f) {
     const int nch = C >> 2;
-    if (nch <= 16 * 2) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
-    if (nch <= 16 * 4) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
-    if (nch <= 64 * 2) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
-    if (nch <= 64 * 4) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
-    if (nch <= 64 * 8) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 8>{});
-    if (nch <= 64 * 24) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 24>{});
+    auto go = [&](auto lpr, auto n) {
+        if (nch == decltype(lpr)::value * decltype(n)::value) return f(lpr, n, std::true_type{});
+        return f(lpr, n, std::false_type{});
+    };
+    // widths whose row is a whole number of chunks per lane get exactly that many (768 -> 3, 1536 -> 6, 3072 -> 12: the 768-wide
+    // LayerNorms of the deep stage ran with 4 slots per lane, one of them empty, each behind a bounds branch)
+    if (nch == 64 * 3) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 3>{}, std::true_type{});
+    if (nch == 64 * 6) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 6>{}, std::true_type{});
+    if (nch == 64 * 12) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 12>{}, std::true_type{});
+    if (nch <= 16 * 2) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
+    if (nch <= 16 * 4) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
+    if (nch <= 64 * 2) return go(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
+    if (nch <= 64 * 4) return go(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
+    if (nch <= 64 * 8) return go(std::integral_constant<int, 64>{}, std::integral_constant<int, 8>{});
+    if (nch <= 64 * 24) return go(std::integral_constant<int, 64>{}, std::integral_constant<int, 24>{});
     return TULIP_ERR_ARG;
 }
 
@@ -608,11 +618,11 @@ extern "C" int tulip_layernorm_fwd(const float* x, const float* gamma, const flo
     if (rows <= 0) return TULIP_OK;
     if (!geom_ok(rows, C, merge, B, H, W)) return TULIP_ERR_ARG;
     RowGeom g{C, merge, B, H, W};
-    return dispatch_ln(C, [&](auto lpr, auto nch) {
+    return dispatch_ln(C, [&](auto lpr, auto nch, auto exact) {
         constexpr int LPR = decltype(lpr)::value, NCH = decltype(nch)::value;
         const int rpb = 256 / LPR;
         const int grid = std::min((rows + rpb - 1) / rpb, 256 * 16);
-        hipLaunchKernelGGL((ln_fwd_kernel<LPR, NCH>), dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd,
+        hipLaunchKernelGGL((ln_fwd_kernel<LPR, NCH, decltype(exact)::value>), dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd,
                            rows, g, eps);
         TULIP_CHECK_LAUNCH();
         return TULIP_OK;
@@ -750,12 +760,12 @@ static int layernorm_bwd_impl(const uint16_t* dy, const float* slabs, int nslab,
     if (param_partials && ln_bwd_part_rows(rows, C) == 0) return TULIP_ERR_ARG;
     if (dx_bf16 && cast_rowscale && (int64_t)rows * C >= (int64_t)1 << 31) return TULIP_ERR_ARG;   // 32-bit token index
     RowGeom g{C, merge, B, H, W};
-    return dispatch_ln(C, [&](auto lpr, auto nch) {
+    return dispatch_ln(C, [&](auto lpr, auto nch, auto exact) {
         constexpr int LPR = decltype(lpr)::value, NCH = decltype(nch)::value;
         const int rpb = 256 / LPR;
         const int grid = param_partials ? ln_bwd_part_rows(rows, C) : std::min((rows + rpb - 1) / rpb, 256 * 16);
         const size_t lds = param_partials ? (size_t)rpb * 2 * C * sizeof(float) : 0;
-        hipLaunchKernelGGL((ln_bwd_kernel<LPR, NCH>), dim3(grid), dim3(256), lds, stream, dy, x, mean, rstd, gamma,
+        hipLaunchKernelGGL((ln_bwd_kernel<LPR, NCH, decltype(exact)::value>), dim3(grid), dim3(256), lds, stream, dy, x, mean, rstd, gamma,
                            dres, dx, rows, g, param_partials, dx_bf16, cast_rowscale,
                            cast_rows_per_sample > 0 ? cast_rows_per_sample : 1, slabs, nslab);
         TULIP_CHECK_LAUNCH();
