@@ -400,8 +400,9 @@ def spawn_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` with no launcher in the environment: run the N ranks under torch.distributed.run on
     this node (one process per GPU, rendezvous on 127.0.0.1 -- the reference's `torchrun --nproc_per_node N`,
     bash_scripts/tulip_upsampling_kitti.sh:35).  The ranks inherit stdout: rank 0's JSON line is this process's output.
-    If the captured-graph step fails on the first attempt the run is repeated once with --no-graph (eager launches, the
-    same kernels and collectives), so that a multi-GPU number exists either way; the line then says "hip_graph": false."""
+    If the captured-graph step fails the run is repeated, first with the detached bucket graphs off (TULIP_DETACH_BUCKETS=0:
+    the round-2 structure), then with --no-graph (eager launches, the same kernels and collectives), so that a multi-GPU
+    number exists either way; the line then carries "graph_path_failed": true and the list of failed attempts."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -412,12 +413,23 @@ def spawn_ranks(n: int, argv) -> int:
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
     rc = subprocess.call(base + list(argv), env=env)
-    if rc != 0 and "--no-graph" not in argv and os.environ.get("TULIP_BENCH_NO_RETRY", "0") != "1":
-        sys.stderr.write(f"bench.py: the {n}-rank run exited with status {rc}; retrying once with --no-graph\n")
+    # A failed attempt is repeated with the next more conservative step structure; every repeat carries the history of the
+    # failures in TULIP_BENCH_ATTEMPTS, and the JSON line says so ("graph_path_failed", "attempts") -- a number measured on
+    # a fallback is never mistaken for the captured, detached-bucket path.
+    ladder = [("detach_buckets_off", {"TULIP_DETACH_BUCKETS": "0"}, []), ("no_graph", {}, ["--no-graph"])]
+    history, current = [], "default"
+    for tag, extra_env, extra_argv in ladder:
+        if rc == 0 or "--no-graph" in argv or os.environ.get("TULIP_BENCH_NO_RETRY", "0") == "1":
+            break
+        history.append({"attempt": current, "rc": rc})
+        current = tag
+        sys.stderr.write(f"bench.py: the {n}-rank run exited with status {rc}; retrying with {tag}\n")
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             base[base.index("--master-port") + 1] = str(sk.getsockname()[1])
-        rc = subprocess.call(base + list(argv) + ["--no-graph"], env=env)
+        env2 = dict(env, **extra_env)
+        env2["TULIP_BENCH_ATTEMPTS"] = json.dumps(history)
+        rc = subprocess.call(base + list(argv) + extra_argv, env=env2)
     return rc
 
 
@@ -487,6 +499,19 @@ def collective_smoke(device, world: int, nbytes: int):
     return out
 
 
+def replicas_identical(trainer, device) -> bool:
+    """Data-parallel replicas apply the same averaged gradients to the same weights: after any number of steps the flat
+    parameter buffers of all ranks are equal bit for bit (DistributedDataParallel's invariant).  Checked through two order-
+    sensitive checksums (MIN == MAX over ranks)."""
+    flat = trainer.eng.params.flat
+    w = torch.arange(1, 1025, device=device, dtype=torch.float64).repeat((flat.numel() + 1023) // 1024)[:flat.numel()]
+    s = torch.stack([flat.double().sum(), (flat.double() * w).sum(), trainer.m.double().sum(), trainer.v.double().sum()])
+    lo_, hi_ = s.clone(), s.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo_, hi_)) and bool(torch.isfinite(s).all())
+
+
 def reference_loop(args, device, steps=20, warmup=5):
     """The reference's OWN calling convention on the drop-in module, unchanged (engine_upsampling.py:69-100,
     util/misc.py:292-305, main_lidar_upsampling.py:282-283): torch.autocast around model(lo, hi), GradScaler
@@ -527,6 +552,42 @@ def reference_loop(args, device, steps=20, warmup=5):
                       "torch.optim.AdamW + loss.item() + synchronize per step) on the drop-in module",
             "value": round(args.batch * steps / dt, 2), "unit": "range-images/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "steps": steps, "warmup": warmup, "final_loss": round(v, 6), "grad_scale": scaler.get_scale()}
+
+
+def secondary_eval_forward(args, device, iters=50, warmup=5):
+    """SURVEY 8(d) "Secondary: eval-forward images/s" -- the reference's call site is engine_upsampling.py:168-171
+    (`model(images_low_res, images_high_res, eval=True)` under no_grad) and the MC-dropout tile of 8 (:417-419).  The eval
+    forward of the headline model at batch 8 and 64 as a HIP graph (tulip_amd.infer.GraphedForward: the fused blocks in
+    their inference form, nothing a backward would read is written), HIP events around `iters` replays."""
+    import copy
+    from tulip_amd.infer import GraphedForward
+    a = copy.copy(args)
+    res = {"metric": "range-images/sec eval forward (KITTI 16->64x1024, bf16, HIP-graph replay)", "unit": "range-images/s",
+           "iters": iters, "warmup": warmup}
+    model = make_model(a).to(device).eval()
+    for Bi in (8, 64):
+        a.batch = Bi
+        lo, _ = synthetic(a, 0, device)
+        gf = GraphedForward(model, Bi, device)
+        gf(lo)
+        for _ in range(warmup):
+            gf()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            gf()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        if not bool(torch.isfinite(gf.pred).all()):
+            raise SystemExit("eval forward produced non-finite predictions")
+        res[f"batch{Bi}"] = {"value": round(Bi / ms * 1e3, 1), "ms_per_forward": round(ms, 4),
+                             "mfma_frac": round(Bi / ms * 1e3 * FLOP_FWD_BWD_PER_IMG / 3 / PEAK_BF16, 5)}
+        del gf
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def secondary_batch64(args, device, steps=30, warmup=15, attn_fp8=False):
@@ -570,8 +631,11 @@ def main():
     ap.add_argument("--img", type=int, nargs=2, default=[16, 1024])
     ap.add_argument("--target", type=int, nargs=2, default=[64, 1024])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="dtype of the gradient all-reduce (N>1): fp32 = DistributedDataParallel's exchange")
+    ap.add_argument("--grad-dtype", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="dtype of the gradient all-reduce (N>1): fp32 = DistributedDataParallel's exchange; auto = fp32 unless "
+                         "the measured bus bandwidth leaves it exposed and bf16 does not (tulip_amd.ddp.choose_comm_plan)")
+    ap.add_argument("--bucket-adamw", default="auto", choices=["auto", "on", "off"],
+                    help="N>1: the optimizer step per bucket behind that bucket's all-reduce (on) or once behind the last (off)")
     ap.add_argument("--bucket-mb", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -624,39 +688,105 @@ def main():
         phase("collective_smoke")
         # the largest gradient bucket of tulip_base (stage 3: 66 MB fp32) before any graph is captured
         smoke = collective_smoke(device, world, 66 << 20)
-    phase("trainer")
-    trainer = Trainer(model, args.batch, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, device=device,
-                      use_graph=not args.no_graph, grad_dtype=args.grad_dtype, bucket_mb=args.bucket_mb)
-    trainer_ref[0] = trainer
-    lo, hi = synthetic(args, rank, device)
-    trainer.load_batch(lo, hi)
+    # ---- N > 1: the exchange is CHOSEN from the bus bandwidth collective_smoke just measured, before anything is captured
+    # (tulip_amd.ddp.choose_comm_plan: every candidate with its prediction goes into `comm`), then measured; if what was
+    # chosen leaves more exchange exposed than predicted the alternative is measured too and the faster one is the line.
+    plan_info, plans_tried, fallback = None, [], None
+    grad_dtype = "fp32" if args.grad_dtype == "auto" else args.grad_dtype
+    bucket_adamw = {"auto": None, "on": True, "off": False}[args.bucket_adamw]
+    if world > 1:
+        from tulip_amd.ddp import choose_comm_plan, plan_buckets
+        phase("plan")
+        eng0 = model.engine()
+        eng0.bind(device)
+        buckets = plan_buckets(eng0.params.groups, eng0.params.total, int(args.bucket_mb * (1 << 20) / 4))
+        bw = float(os.environ.get("TULIP_BENCH_FAKE_BUSBW_GBPS", "0")) or smoke["bucket"]["busbw_GBps"]
+        plan_info = choose_comm_plan(buckets, world, bw, smoke["small"]["ms"], requested_dtype=args.grad_dtype,
+                                     requested_bucket_adamw=bucket_adamw)
+        plan_info["busbw_source"] = ("TULIP_BENCH_FAKE_BUSBW_GBPS (rehearsal)" if os.environ.get("TULIP_BENCH_FAKE_BUSBW_GBPS")
+                                     else "collective_smoke, largest bucket")
+        grad_dtype, bucket_adamw = plan_info["chosen"]["grad_dtype"], plan_info["chosen"]["bucket_adamw"]
 
-    phase("warmup")
-    for _ in range(args.warmup):
-        trainer.step()
-    torch.cuda.synchronize()
+    def run_plan(gd, ba):
+        """One Trainer on the chosen exchange: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize."""
+        phase(f"trainer {gd} bucket_adamw={ba}")
+        tr = Trainer(model, args.batch, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, device=device,
+                     use_graph=not args.no_graph, grad_dtype=gd, bucket_mb=args.bucket_mb, bucket_adamw=ba)
+        trainer_ref[0] = tr
+        lo, hi = synthetic(args, rank, device)
+        tr.load_batch(lo, hi)
+        phase("warmup")
+        for _ in range(args.warmup):
+            tr.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # wall clock brackets the K steps (the contract's number); one HIP event per step boundary on the launch stream
+        # gives the per-step distribution (SURVEY 8(d): median and min)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        phase("timed")
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            ls = tr.step()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        ps = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        if world > 1:
+            tmax = torch.tensor([dt_], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = tmax.item()
+        return tr, dt_, ps, ls
+
+    def drop(tr):
+        trainer_ref[0] = None
+        del tr
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    trainer, dt, per_step, losses = run_plan(grad_dtype, bucket_adamw)
+    comm = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # wall clock brackets the K steps (the contract's number); one HIP event per step boundary on the launch stream
-    # gives the per-step distribution (median and min)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    phase("timed")
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        losses = trainer.step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+        phase("replica_check")
+        same = replicas_identical(trainer, device)
+        if not same:
+            # the chosen structure let the replicas drift apart: not a number.  Back to the most conservative exchange (the
+            # order DistributedDataParallel + optimizer.step() has), said so in the line.
+            fallback = {"reason": "replicas diverged", "plan": {"grad_dtype": grad_dtype, "bucket_adamw": bucket_adamw,
+                                                              "detach_buckets": trainer.detach_buckets}}
+            drop(trainer)
+            os.environ["TULIP_DETACH_BUCKETS"] = "0"
+            grad_dtype, bucket_adamw = "fp32", False
+            trainer, dt, per_step, losses = run_plan(grad_dtype, bucket_adamw)
+            same = replicas_identical(trainer, device)
+        phase("comm_report")
+        comm = comm_report(trainer, args, world, device)
+        comm["replicas_identical"] = same
+        plans_tried.append({"grad_dtype": grad_dtype, "bucket_adamw": bool(trainer.bucket_adamw), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                            "exposed_exchange_ms": comm["exposed_exchange_ms"]})
+        step_ms = dt / args.steps * 1e3
+        adapt = (args.grad_dtype == "auto" and fallback is None and os.environ.get("TULIP_BENCH_ADAPT", "1") != "0"
+                 and grad_dtype == "fp32" and comm["exposed_exchange_ms"] > max(0.15, 0.07 * step_ms))
+        if adapt:
+            # the prediction said fp32 hides; the measurement says it does not: measure the bf16 exchange as well
+            keep = (trainer.bucket_adamw, dt, per_step, losses, comm)
+            drop(trainer)
+            trainer, dt2, per2, losses2 = run_plan("bf16", bucket_adamw)
+            same2 = replicas_identical(trainer, device)
+            comm2 = comm_report(trainer, args, world, device)
+            comm2["replicas_identical"] = same2
+            plans_tried.append({"grad_dtype": "bf16", "bucket_adamw": bool(trainer.bucket_adamw),
+                                "ms_per_step": round(dt2 / args.steps * 1e3, 4), "exposed_exchange_ms": comm2["exposed_exchange_ms"]})
+            if same2 and dt2 < 0.97 * dt:
+                grad_dtype, dt, per_step, losses, comm = "bf16", dt2, per2, losses2, comm2
+            else:       # fp32 stays the line; the trainer left alive is the bf16 one, which only matters to the roofline (N = 1)
+                _, dt, per_step, losses, comm = keep
     loss_val = losses[0].item()
     if not (loss_val == loss_val and abs(loss_val) < 1e9):
         raise SystemExit(f"non-finite loss {loss_val}")
@@ -687,20 +817,36 @@ def main():
                         "reference's own bf16-autocast band (max 8e-3 abs); gradients <= 1.5e-2 rel L2 per tensor "
                         "(tests/test_model_gpu.py)")
     if world > 1:
-        phase("comm_report")
-        out["comm"] = comm_report(trainer, args, world, device)
-        out["comm"]["world_size_rccl"] = dist.get_world_size()
-        out["comm"]["backend"] = dist.get_backend()
+        out["comm"] = comm
+        comm["world_size_rccl"] = dist.get_world_size()
+        comm["backend"] = dist.get_backend()
         # graphs per step: the chain's segments (cut at the bucket points) + the detached last side group of each bucket
-        out["comm"]["graph_segments"] = len(trainer._segments[True]) if getattr(trainer, "_segments", None) else 0
-        out["comm"]["detached_bucket_graphs"] = len(getattr(trainer, "_det_graphs", {}))
-        out["comm"]["collective_smoke"] = smoke
-        out["comm"]["launcher"] = "bench.py spawn_ranks" if os.environ.get("TULIP_BENCH_SPAWNED") else "external (torch.distributed.run)"
+        comm["graph_segments"] = len(trainer._segments[True]) if getattr(trainer, "_segments", None) else 0
+        comm["detached_bucket_graphs"] = len(getattr(trainer, "_det_graphs", {}))
+        comm["detach_buckets"] = bool(trainer.detach_buckets)
+        comm["collective_smoke"] = smoke
+        comm["launcher"] = "bench.py spawn_ranks" if os.environ.get("TULIP_BENCH_SPAWNED") else "external (torch.distributed.run)"
+        # the choice, its prediction, and what was measured (plans_tried[-1] or the faster of two is the line above)
+        comm["plan_chosen"] = plan_info["chosen"]
+        comm["plan_reason"] = plan_info["reason"]
+        comm["plan_candidates"] = plan_info["candidates"]
+        comm["plan_model"] = dict(plan_info["model"], busbw_source=plan_info["busbw_source"])
+        comm["predicted_exposed_exchange_ms"] = plan_info["chosen"]["predicted_exposed_exchange_ms"]
+        comm["plans_tried"] = plans_tried
+        comm["plan_fallback"] = fallback
+        out["config"]["grad_allreduce_dtype"] = grad_dtype
+    # a repeat after a failed attempt (spawn_ranks' ladder): say so in the line itself
+    attempts = json.loads(os.environ.get("TULIP_BENCH_ATTEMPTS", "[]"))
+    if attempts or fallback:
+        out["graph_path_failed"] = True
+        out["attempts"] = attempts
     if rank == 0 and world == 1 and not args.no_secondary and args.batch == 8 and args.model == "tulip_base":
         out["secondary"] = secondary_batch64(args, device)
         out["secondary_fp8_attention"] = secondary_batch64(args, device, attn_fp8=True)
     if rank == 0 and world == 1 and not args.no_reference_loop and headline:
         out["secondary_reference_loop"] = reference_loop(args, device)
+    if rank == 0 and world == 1 and not args.no_secondary and headline:
+        out["secondary_eval_forward"] = secondary_eval_forward(args, device)
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = kernel_rooflines(trainer)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -290,9 +290,22 @@ def golden_durlar(T):
     golden_model(T, "g6_durlar_large", large, batch=1, seed=0, with_grads=False, bf16_ref=True)
 
 
+def golden_base_2048(T):
+    """G13: tulip_base on the 2048-wide grids -- the reference's own DurLAR recipe (bash_scripts/tulip_upsampling_durlar.sh:
+    11,26-27: tulip_base, 32x2048 -> 128x2048) and the CARLA geometry with the base model (SURVEY 8(d) config 3 "run base
+    and large"): B=1, eval forward, sub-sampled prediction + both losses + the bf16-autocast self-consistency band."""
+    golden_model(T, "g13_base_16x2048", O.tulip_base_config(img_size=(16, 2048), target_img_size=(64, 2048)), batch=1, seed=3,
+                 with_grads=False, bf16_ref=True)
+    golden_model(T, "g13_base_32x2048", O.tulip_base_config(img_size=(32, 2048), target_img_size=(128, 2048)), batch=1, seed=4,
+                 with_grads=False, bf16_ref=True)
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     T = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "base2048":
+        golden_base_2048(T)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "alternates":
         golden_alternates(T)
         return
@@ -320,6 +333,7 @@ def main():
     golden_model(T, "g5_large_16x2048", large, batch=1, seed=0, with_grads=False, bf16_ref=False)
     golden_alternates(T)
     golden_durlar(T)
+    golden_base_2048(T)
     print("done")
 
 

@@ -62,3 +62,37 @@ def test_single_process_is_a_no_op():
     b.on_group_done("embed", flat)
     b.wait_all()
     assert torch.equal(flat, torch.arange(20.0)) and b.world == 1
+
+
+# ---------------------------------------------------------------------------------------------- the exchange chooser
+_BASE_BUCKETS = [("dec0", 0, 5_200_000), ("enc3", 5_200_000, 21_700_000), ("enc1", 21_700_000, 26_900_000),
+                 ("embed", 26_900_000, 27_150_000)]       # tulip_base, bucket_mb = 16 (elements)
+
+
+def test_comm_plan_chooser_branches():
+    """tulip_amd.ddp.choose_comm_plan (what `bench.py --gpus N` runs between collective_smoke and the first capture): every
+    branch -- fp32 kept when the measured bus bandwidth hides it, bf16 when fp32 would be exposed and bf16 is not, explicit
+    requests win, the per-bucket optimizer follows the predicted tail -- and the ring model's arithmetic."""
+    from tulip_amd.ddp import choose_comm_plan, predict_exposed_ms, close_fractions
+    # ring model: one 64-MB bucket closing at 50 % of a 1-ms backward, 8 ranks, 128 GB/s -> 2*7/8*64e6/128e9 = 0.875 ms
+    exp, per = predict_exposed_ms([64e6], [0.5], 1.0, 8, 128.0, 0.0)
+    assert abs(per[0] - 0.875) < 1e-9 and abs(exp - 0.375) < 1e-9
+    # collectives serialise on RCCL's stream: the second starts when the first ends, not when its bucket closes
+    exp, per = predict_exposed_ms([64e6, 64e6], [0.1, 0.2], 1.0, 8, 128.0, 0.0)
+    assert abs(exp - (0.1 + 2 * 0.875 - 1.0)) < 1e-9
+    assert close_fractions(["dec0", "enc3", "enc1", "embed"]) == [0.35, 0.51, 0.77, 1.0]
+    assert close_fractions(["a", "b"]) == [0.5, 1.0]
+    fast = choose_comm_plan(_BASE_BUCKETS, 8, 320.0, 0.03)
+    assert fast["chosen"]["grad_dtype"] == "fp32" and fast["chosen"]["predicted_exposed_exchange_ms"] < 0.1
+    slow = choose_comm_plan(_BASE_BUCKETS, 8, 120.0, 0.03)
+    assert slow["chosen"]["grad_dtype"] == "bf16"
+    e32 = next(c for c in slow["candidates"] if c["grad_dtype"] == "fp32" and not c["bucket_adamw"])
+    assert e32["predicted_exposed_exchange_ms"] > 0.1 + slow["chosen"]["predicted_exposed_exchange_ms"]
+    forced = choose_comm_plan(_BASE_BUCKETS, 8, 120.0, 0.03, requested_dtype="fp32", requested_bucket_adamw=False)
+    assert forced["chosen"]["grad_dtype"] == "fp32" and forced["chosen"]["bucket_adamw"] is False
+    assert "requested" in forced["reason"]
+    assert len(fast["candidates"]) == 4 and fast["model"]["world"] == 8
+    # the per-bucket optimizer is chosen when it shortens the predicted tail (the single update waits for the last all-reduce)
+    assert fast["chosen"]["bucket_adamw"] is True
+    one = choose_comm_plan([("embed", 0, 1000)], 2, 100.0, 0.01)     # a single bucket: nothing to hide the update behind
+    assert one["chosen"]["bucket_adamw"] is False

@@ -149,6 +149,19 @@ def test_kitti_base_forward_vs_reference(golden_dir):
     assert abs(ll.item() - loss.item()) / loss.item() <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["g13_base_16x2048", "g13_base_32x2048"])
+def test_base_2048_forward_vs_reference(golden_dir, name):
+    """tulip_base on the 2048-wide grids (bash_scripts/tulip_upsampling_durlar.sh:11,26-27 trains base at 32x2048; CARLA's
+    16x2048 geometry with the base model): the oracle against the reference's fp32 forward, B=1, sub-sampled."""
+    z, meta, cfg = _load(golden_dir, name)
+    sd = O.key_seeded_state_dict(cfg, seed=meta["seed"])
+    lo, hi = O.synthetic_batch(cfg, meta["batch"], seed=1234 + meta["seed"])
+    with torch.no_grad():
+        pred, loss, pix = O.tulip_forward(sd, cfg, lo, hi)
+    np.testing.assert_allclose(pred.reshape(-1)[::257].numpy(), z["pred_sub257"], rtol=0, atol=5e-6)
+    assert abs(loss.item() - float(z["loss"])) <= 1e-6 and abs(pix.item() - float(z["pixel_loss"])) <= 1e-6
+
+
 def test_adamw_step_matches_torch():
     torch.manual_seed(0)
     p0 = torch.randn(7, 5)

@@ -73,3 +73,80 @@ class GradBucketer:
         for w in self.pending:
             w.wait()          # stream-level dependency for NCCL/RCCL; blocking for gloo
         self.pending.clear()
+
+
+# ---------------------------------------------------------------------------------------------- choosing the exchange
+# Where in the backward a completion group's last gradient has been launched, as a fraction of the backward's duration
+# (tools/step_stamps.py on tulip_base, KITTI, batch 8: profiles/r3_step_stamps.txt; other depths: evenly spaced).
+_CLOSE_FRACTION_4 = {"head": 0.06, "dec2": 0.12, "dec1": 0.24, "dec0": 0.35, "enc3": 0.51, "enc2": 0.65, "enc1": 0.77,
+                     "enc0": 0.90, "embed": 1.0}
+
+
+def close_fractions(tags: Sequence[str]) -> List[float]:
+    if all(t in _CLOSE_FRACTION_4 for t in tags):
+        return [_CLOSE_FRACTION_4[t] for t in tags]
+    return [(k + 1) / len(tags) for k in range(len(tags))]
+
+
+def predict_exposed_ms(bucket_bytes: Sequence[float], close_frac: Sequence[float], backward_ms: float, world: int,
+                       busbw_GBps: float, latency_ms: float) -> Tuple[float, List[float]]:
+    """Ring all-reduce model (nccl-tests convention: t = latency + 2 (N-1)/N S / busbw); the collectives of a step run one
+    after the other on RCCL's stream, each starting no earlier than its bucket closes.  Returns (time the last all-reduce
+    ends behind the end of the backward, per-bucket milliseconds)."""
+    f = 2.0 * (world - 1) / world
+    end, per = 0.0, []
+    for nbytes, frac in zip(bucket_bytes, close_frac):
+        t = latency_ms + f * nbytes / (busbw_GBps * 1e6)
+        per.append(t)
+        end = max(end, frac * backward_ms) + t
+    return max(0.0, end - backward_ms), per
+
+
+def choose_comm_plan(buckets: Sequence[Tuple[str, int, int]], world: int, busbw_GBps: float, latency_ms: float,
+                     backward_ms: float = 1.34, adamw_ms: float = 0.15, requested_dtype: str = "auto",
+                     requested_bucket_adamw: Optional[bool] = None, slack_ms: float = 0.10) -> dict:
+    """Pick the gradient exchange of an N-rank step BEFORE anything is captured, from the bus bandwidth bench.py's
+    collective_smoke measured on this node (reference: DistributedDataParallel's fp32 all-reduce, main_lidar_upsampling.py:277).
+
+    Candidates: gradient dtype fp32 (the reference's exchange) or bf16 (half the bytes, cast back to fp32 in front of AdamW)
+    x one AdamW launch behind the last all-reduce or one per bucket behind that bucket's all-reduce (beside the rest of
+    the backward).  fp32 stays unless its predicted exposed exchange exceeds `slack_ms` AND bf16 is predicted to save at
+    least that much; the per-bucket optimizer is chosen when the exchange of the LAST bucket is what the step waits for
+    anyway (its update then hides the other buckets' ~adamw_ms).  Explicit requests win.  Every candidate and its
+    prediction is returned so that the measurement can be read against it."""
+    tags = [t for t, _, _ in buckets]
+    fr = close_fractions(tags)
+    cands = []
+    for dt, el in (("fp32", 4), ("bf16", 2)):
+        nb = [(b - a) * el for _, a, b in buckets]
+        exposed, per = predict_exposed_ms(nb, fr, backward_ms, world, busbw_GBps, latency_ms)
+        for ba in (False, True):
+            # one AdamW behind everything: exposed exchange + the whole update; per bucket: only the last bucket's share
+            last_share = (buckets[-1][2] - buckets[-1][1]) / max(1, buckets[-1][2])
+            tail = adamw_ms * (last_share if ba else 1.0)
+            cands.append({"grad_dtype": dt, "bucket_adamw": ba, "predicted_exposed_exchange_ms": round(exposed, 4),
+                          "predicted_tail_ms": round(exposed + tail, 4), "per_bucket_allreduce_ms": [round(x, 4) for x in per]})
+    def pick(dt, ba):
+        return next(c for c in cands if c["grad_dtype"] == dt and c["bucket_adamw"] == ba)
+    reason = []
+    if requested_dtype in ("fp32", "bf16"):
+        dt = requested_dtype
+        reason.append(f"grad dtype {dt} requested")
+    else:
+        e32, e16 = pick("fp32", False)["predicted_exposed_exchange_ms"], pick("bf16", False)["predicted_exposed_exchange_ms"]
+        if e32 > slack_ms and e32 - e16 >= slack_ms:
+            dt = "bf16"
+            reason.append(f"fp32 exchange predicted {e32:.3f} ms exposed, bf16 {e16:.3f}")
+        else:
+            dt = "fp32"
+            reason.append(f"fp32 exchange predicted {e32:.3f} ms exposed (<= {slack_ms} or bf16 saves < {slack_ms})")
+    if requested_bucket_adamw is not None:
+        ba = bool(requested_bucket_adamw)
+        reason.append(f"per-bucket AdamW {'on' if ba else 'off'} requested")
+    else:
+        ba = pick(dt, True)["predicted_tail_ms"] + 0.02 < pick(dt, False)["predicted_tail_ms"]
+        reason.append("per-bucket AdamW predicted to " + ("win" if ba else "make no difference"))
+    chosen = dict(pick(dt, ba))
+    return {"chosen": chosen, "reason": "; ".join(reason), "candidates": cands, "model": {
+        "busbw_GBps": busbw_GBps, "latency_ms": latency_ms, "backward_ms": backward_ms, "adamw_ms": adamw_ms,
+        "close_fractions": dict(zip(tags, fr)), "world": world, "slack_ms": slack_ms}}
