@@ -701,7 +701,9 @@ def main():
         eng0.bind(device)
         buckets = plan_buckets(eng0.params.groups, eng0.params.total, int(args.bucket_mb * (1 << 20) / 4))
         bw = float(os.environ.get("TULIP_BENCH_FAKE_BUSBW_GBPS", "0")) or smoke["bucket"]["busbw_GBps"]
-        plan_info = choose_comm_plan(buckets, world, bw, smoke["small"]["ms"], requested_dtype=args.grad_dtype,
+        lat = float(os.environ.get("TULIP_BENCH_FAKE_LATENCY_MS", "-1"))
+        lat = smoke["small"]["ms"] if lat < 0 else lat
+        plan_info = choose_comm_plan(buckets, world, bw, lat, requested_dtype=args.grad_dtype,
                                      requested_bucket_adamw=bucket_adamw)
         plan_info["busbw_source"] = ("TULIP_BENCH_FAKE_BUSBW_GBPS (rehearsal)" if os.environ.get("TULIP_BENCH_FAKE_BUSBW_GBPS")
                                      else "collective_smoke, largest bucket")

@@ -216,6 +216,10 @@ int tulip_patch_embed_bwd_blocks(int ntok);
  * function the forward ran).  Default 0/1: the reference's bf16 / fp16 scores. */
 #define TULIP_ATTN_MASKED 1
 #define TULIP_ATTN_FP8 2
+/* bit 2, the fused block kernels (tulip_swin96_block_fwd / _bwd, tulip_swinw_block_fwd / _bwd) only: the fc1_pre buffer carries bf16(gelu'(h)) from the forward to the backward instead
+ * of the fc1 pre-activation h itself -- the derivative is all the backward wants from h (autograd of tulip.py:196), and the
+ * forward has erf and the Gaussian at hand.  Forward and backward of a block must agree on it. */
+#define TULIP_BLOCK_FC1_GRAD 4
 int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_table, const int32_t* rel_index, uint16_t* out, int B,
                           int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream);
 /* dqkv from dout.  d(bias) leaves as R = tulip_window_attn_bwd_partial_rows(...) partial rows per head:
@@ -419,7 +423,9 @@ int tulip_kitti_range_map(const float* points, int64_t n, int rows, int cols, fl
  * kernels write it: xn1 [M][96] bf16, qkv [M][288] bf16, attn_out [M][96] bf16, x1 [M][96] fp32, xn2 [M][96] bf16,
  * fc1_pre / fc1_act [M][384] bf16, mean/rstd [M] fp32.  drop_scale_* : per-sample DropPath multipliers or NULL.
  * Inference form: ALL eleven saved-activation pointers (x1, xn1, qkv, attn_out, xn2, fc1_pre, fc1_act, mean1, rstd1, mean2,
- * rstd2) NULL -- only x_out (and the wide kernels' out_bf16) is written; some but not all NULL is an argument error. */
+ * rstd2) NULL -- only x_out (and the wide kernels' out_bf16) is written.  tulip_swin96_block_fwd only: qkv and fc1_pre
+ * (both) NULL with the other nine given -- the lean training form for the recomputing backward (tulip_swin96_bwd_desc).
+ * Any other mix of NULL and non-NULL is an argument error. */
 typedef struct tulip_swin96_desc {
     const float* x_in; float* x1; float* x_out;
     void* xn1; void* qkv; void* attn_out; void* xn2; void* fc1_pre; void* fc1_act;
@@ -431,6 +437,9 @@ typedef struct tulip_swin96_desc {
     int B; int H; int W; int shift_h; int shift_w; int masked; float eps;
 } tulip_swin96_desc;
 int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream);
+/* diagnostic twins (tools/swin96_phases.py): stamps[(workgroup * 8 + wave) * 16 + k] = s_memtime (shader clock) at phase
+ * boundary k of every wave; workgroups = tulip_swin96_bwd_partial_rows(B, H, W) */
+int tulip_swin96_block_fwd_profiled(const tulip_swin96_desc* d, uint64_t* stamps, hipStream_t stream);
 
 /* Backward of the same block in ONE launch (replaces, for C = 96, the chain tulip_gemm_bf16(EPI_GELU_BWD) ->
  * tulip_gemm_bf16 -> tulip_layernorm_bwd -> tulip_gemm_bf16 -> tulip_window_attn_bwd -> tulip_gemm_bf16 ->
@@ -451,9 +460,16 @@ typedef struct tulip_swin96_bwd_desc {
     void* dx_bf16; const float* dx_bf16_scale;
     float* norm1_partials; float* norm2_partials; float* bias_partials;
     int B; int H; int W; int shift_h; int shift_w; int masked;
+    /* Recomputation form (C = 96 only, round 4): qkv == NULL and fc1_pre == NULL -- the forward was launched without them
+     * (tulip_swin96_block_fwd with qkv = fc1_pre = NULL writes 2.1 instead of 3.5 KB per token) and the backward recomputes
+     * both from x_in / x1, the saved statistics and the weights it holds in LDS anyway, with the forward's own operand
+     * fragments and accumulation order (the forward's bits).  Needs the four bias vectors the forward added; ignored (may be
+     * NULL) when qkv / fc1_pre are given.  tulip_swinw_block_bwd does not read them. */
+    const float* b_qkv; const float* b_fc1; const float* norm1_bias; const float* norm2_bias;
 } tulip_swin96_bwd_desc;
 int tulip_swin96_bwd_partial_rows(int B, int H, int W);
 int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream);
+int tulip_swin96_block_bwd_profiled(const tulip_swin96_bwd_desc* d, uint64_t* stamps, hipStream_t stream);
 
 /* The same two launches for the wider stages, C = 192 and C = 384 (heads of 32, window 2x8, MLP C -> 4C -> C; H even,
  * W % 16 == 0; tulip_swinw_supported): a workgroup owns 2 or 4 neighbouring windows with one wave per head, every GEMM

@@ -392,11 +392,11 @@ def test_inference_form_of_the_fused_blocks(B):
         P.pred.fill_(float("nan"))
         for sp in eng.blocks:                                  # the saved tensors of the fused blocks: poisoned
             if eng._fusable96(sp) or eng._fusable_wide(sp, B):
-                P[sp.prefix + ".qkv"].fill_(7.0)
+                P[sp.prefix + ".xn1"].fill_(7.0)             # (xn1: every training form writes it; the C = 96 one no longer writes qkv)
         eng.run_forward(P, with_loss=False)
         torch.cuda.synchronize()
         assert eng._no_save == no_save
-        touched = [bool((P[sp.prefix + ".qkv"] != 7.0).any()) for sp in eng.blocks
+        touched = [bool((P[sp.prefix + ".xn1"] != 7.0).any()) for sp in eng.blocks
                    if eng._fusable96(sp) or eng._fusable_wide(sp, B)]
         assert touched and all(t != no_save for t in touched)  # written in the training form only
         preds.append(P.pred.clone())

@@ -90,6 +90,10 @@ def _forward(stage, shifted, B, fp8):
         res[fused] = {k: P[p + "." + k].float().clone() for k in names}
         res[fused]["out"], res[fused]["out_bf16"] = out.clone(), ob.float().clone()
     eng.fuse_wide = True
+    if eng._hgrad_wide(sp, B):      # round 4: the fused forward hands gelu'(h) to the fused backward in the fc1_pre buffer
+        h = res[False]["h"]
+        res[False]["h"] = (0.5 * (1 + torch.erf(h * 0.7071067811865476)) + h * torch.exp(-0.5 * h * h) * 0.3989422804014327
+                           ).bfloat16().float()
     for k, ref in res[False].items():
         a, b = res[True][k].reshape(-1), ref.reshape(-1)
         assert torch.isfinite(a).all(), k
@@ -151,15 +155,37 @@ def _backward(stage, shifted, B, fp8):
                 r["g:" + n[len(p) + 1:]] = gflat[o:o + q.numel()].clone()
         res[fused] = r
     eng.fuse_wide = eng.fuse_wide_bwd = True
+    # (c) the pair as the step runs it: fused forward -> fused backward, with gelu'(h) handed over in the fc1_pre buffer
+    # (TULIP_BLOCK_FC1_GRAD, round 4) -- the saved tensors now come from the fused forward
+    assert eng._hgrad_wide(sp, B) == eng.fc1_grad_wide
+    eng._block_fwd(P, sp, xin, out)
+    gflat = torch.zeros(eng.params.total, device=DEV)
+    G = lambda name: gflat.data_ptr() + 4 * eng.params.offset[name]
+    dx = dy.clone()
+    cast_buf.zero_()
+    eng._pending, eng._lagged_hook = [], None
+    eng._block_bwd(P, sp, xin, dx, G, have_dyb=False, next_cast=(cast_buf, None, sp.H * sp.W))
+    torch.cuda.synchronize()
+    r = {"dx": dx.clone(), "dx_bf16": cast_buf.float().clone(), "dh": P[p + ".dh"].float().clone(),
+         "dqkv": P[p + ".dqkv"].float().clone(), "dyb_a": P[p + ".dyb_a"].float().clone(), "dyb_m": P[p + ".dyb_m"].float().clone()}
+    for n, q in m.named_parameters():
+        if n.startswith(p + "."):
+            o = eng.params.offset[n]
+            r["g:" + n[len(p) + 1:]] = gflat[o:o + q.numel()].clone()
+    res["pair"] = r
     eng.overlap_wgrad = saved
-    for k, ref in res[False].items():
-        a, b = res[True][k].reshape(-1), ref.reshape(-1)
-        assert torch.isfinite(a).all(), k
-        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
-        print(f"{k:44s} rel {rel:.3e}")
-        assert b.norm().item() > 0, k
-        # the unfused chain rounds d(norm input) to bf16 between its kernels, the fused one keeps it in fp32
-        assert rel <= (2e-2 if "bias_table" in k else 6e-3), (k, rel)
+    for tag in (True, "pair"):
+        for k, ref in res[False].items():
+            a, b = res[tag][k].reshape(-1), ref.reshape(-1)
+            assert torch.isfinite(a).all(), k
+            rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+            print(f"{str(tag):5s} {k:44s} rel {rel:.3e}")
+            assert b.norm().item() > 0, k
+            # the unfused chain rounds d(norm input) to bf16 between its kernels, the fused one keeps it in fp32; the pair also
+            # differs by the forward's isolated bf16 flips and the bf16 rounding of gelu'(h)
+            lim = (2e-2 if "bias_table" in k else 6e-3) * (1.0 if tag is True else 1.35)
+            assert rel <= lim, (tag, k, rel)
+    res[True] = res["pair"]                                    # (b) below checks the pair against the oracle
     if sp.slot >= 0:       # sample 0: both branches dropped -> the block is the identity there
         assert torch.equal(res[True]["dx"][: M // B], dy[: M // B])
     # ---- (b) directly against the oracle's autograd of the block

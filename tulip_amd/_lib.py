@@ -29,7 +29,8 @@ class Swin96BwdDesc(ctypes.Structure):
                                  "w_proj", "w_fc1", "w_fc2", "norm1_weight", "norm2_weight", "bias_table", "rel_index",
                                  "drop_scale_attn", "drop_scale_mlp", "d_out_mlp", "d_fc1_pre", "d_out_attn", "d_qkv",
                                  "dx_bf16", "dx_bf16_scale", "norm1_partials", "norm2_partials", "bias_partials")] + \
-               [(n, I) for n in ("B", "H", "W", "shift_h", "shift_w", "masked")]
+               [(n, I) for n in ("B", "H", "W", "shift_h", "shift_w", "masked")] + \
+               [(n, P) for n in ("b_qkv", "b_fc1", "norm1_bias", "norm2_bias")]
 
 
 class ReduceRegion(ctypes.Structure):
@@ -67,6 +68,8 @@ SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P, L, P],
     "tulip_swin96_block_fwd": [P, P],
     "tulip_swin96_block_bwd": [P, P],
+    "tulip_swin96_block_fwd_profiled": [P, P, P],
+    "tulip_swin96_block_bwd_profiled": [P, P, P],
     "tulip_swin96_bwd_partial_rows": [I, I, I],
     "tulip_swinw_supported": [I, I, I],
     "tulip_swinw_block_fwd": [P, I, P, P],

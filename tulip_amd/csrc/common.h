@@ -161,6 +161,9 @@ __device__ __forceinline__ bf16x8 round_through_fp8(bf16x8 v) {
 #define TULIP_ATTN_MASKED 1
 #define TULIP_ATTN_FP8 2
 #endif
+#ifndef TULIP_BLOCK_FC1_GRAD
+#define TULIP_BLOCK_FC1_GRAD 4
+#endif
 
 // a / d for a >= 0, d > 0 with d uniform over the launch (a kernel argument): the token grids, tokens per sample etc.
 // are powers of two in every configuration of the reference, and a 32-bit integer divide is ~40 VALU instructions
@@ -235,6 +238,14 @@ __device__ __forceinline__ f32x2 gelu_exact_grad2(f32x2 x) {
     f32x2 e, g;
     gelu_terms2(x, e, g);
     return __builtin_elementwise_fma(x * 0.39894228040143267794f, g, (e + 1.0f) * 0.5f);
+}
+// both at once: the forward of a fused block that hands gelu'(h) to its backward (TULIP_BLOCK_FC1_GRAD)
+__device__ __forceinline__ void gelu_exact_and_grad2(f32x2 x, f32x2& y, f32x2& dy) {
+    f32x2 e, g;
+    gelu_terms2(x, e, g);
+    const f32x2 e1 = e + 1.0f;
+    y = x * 0.5f * e1;                                                            // gelu_exact2's operation order: same bits
+    dy = __builtin_elementwise_fma(x * 0.39894228040143267794f, g, e1 * 0.5f);    // gelu_exact_grad2's
 }
 __device__ __forceinline__ float gelu_exact(float x) {
     float e, g;

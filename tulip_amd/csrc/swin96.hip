@@ -16,6 +16,14 @@
 
 namespace {
 
+#ifndef TULIP_SWIN96_IGLP
+#define TULIP_SWIN96_IGLP 0          // dev: -DTULIP_SWIN96_IGLP=1 asks the scheduler for its DS-read / MFMA interleave (iglp_opt 0)
+#endif
+#if TULIP_SWIN96_IGLP
+#define IGLP() __builtin_amdgcn_iglp_opt(0)
+#else
+#define IGLP() ((void)0)
+#endif
 constexpr int C = 96, HID = 384;
 constexpr int NW = 8;                     // windows (= waves) per workgroup: 128 tokens share one copy of the weights
 constexpr int NT = NW * 64;
@@ -39,7 +47,9 @@ struct Swin96Args {
     const float *ds0, *ds1;               // DropPath multipliers per sample (attention / MLP branch) or nullptr
     int B, H, W, sh, sw, masked;
     float eps, scale;
+    unsigned long long* prof;             // optional: s_memtime stamps [workgroup][wave][16] at the phase boundaries (dev)
 };
+#define TULIP_STAMP(k) do { if constexpr (PROF) { if (lane == 0) a.prof[((size_t)blockIdx.x * NW + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
 __device__ __forceinline__ int region(int x, int X, int wsz, int ssz) {       // create_mask slices, tulip.py:261-266
     return (ssz == 0 || x >= X - ssz) ? 2 : (x >= X - wsz ? 1 : 0);
@@ -61,6 +71,21 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
 // weight fragment in the chained-operand k order: k slots 0..3 <- columns c0..c0+3, slots 4..7 <- c0+16..c0+19
 __device__ __forceinline__ bf16x8 wfrag(const unsigned char* rowp, int c0) {
     return cat8(*(const bf16x4*)(rowp + c0 * 2), *(const bf16x4*)(rowp + (c0 + 16) * 2));
+}
+// LayerNorm output of one token row held as 6 x 4 channels (16n + 4gq + r), rounded to bf16: the ONE place the forward and the
+// backward's recomputation (swin96_bwd_kernel<true>) go through, with floating-point contraction pinned -- the backward must see
+// exactly the operand bits the forward's GEMMs saw, or its recomputed qkv / fc1 pre-activation would differ from the forward's
+// in the last bf16 digit now and then
+__device__ __forceinline__ void ln_apply(const f32x4 (&xv)[6], float mu, float rs, const float* gam, const float* bet, int gq,
+                                         bf16x4 (&p)[6]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const int c0 = 16 * n + 4 * gq;
+        const float4 ga = *(const float4*)(gam + c0), be = *(const float4*)(bet + c0);
+        p[n] = pack4(__builtin_fmaf((xv[n][0] - mu) * rs, ga.x, be.x), __builtin_fmaf((xv[n][1] - mu) * rs, ga.y, be.y),
+                     __builtin_fmaf((xv[n][2] - mu) * rs, ga.z, be.z), __builtin_fmaf((xv[n][3] - mu) * rs, ga.w, be.w));
+    }
 }
 // global [ROWS][COLS] bf16 -> LDS rows of PITCH bytes; every thread keeps PER 16-byte loads in flight
 template <int ROWS, int COLS, int PITCH>
@@ -110,9 +135,15 @@ struct StagedWeights {
     }
 };
 
-// SAVE = false: the inference form (eval / MC-dropout forward: nothing is kept for a backward) -- 116 of the 129 MB a launch
-// moves at batch 8 are the saved activations
-template <bool SAVE>
+// SAVE = 0: the inference form (eval / MC-dropout forward: nothing is kept for a backward) -- 116 of the 129 MB a launch
+// moves at batch 8 are the saved activations.  SAVE = 1 (round 4): what the fused backward with recomputation needs -- x1, the
+// statistics and the four bf16 operands of the weight-gradient GEMMs (xn1, attention output, xn2, gelu(h)); qkv and the fc1
+// pre-activation h (1344 of 3472 B per token) are recomputed by swin96_bwd_kernel<true> from x / x1.  SAVE = 2: everything,
+// as the separate kernels write it (the unfused backward reads qkv and h).
+// SAVE = 3: as 2, but the fc1_pre buffer receives bf16(gelu'(h)) instead of h (TULIP_BLOCK_FC1_GRAD): the only thing the
+// backward does with h is that derivative (~12 vector instructions per element there, two more here where erf and the
+// Gaussian are at hand anyway).  PROF: the diagnostic twin with shader-clock stamps (tools/swin96_phases.py).
+template <int SAVE, bool PROF>
 __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
@@ -130,6 +161,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     int ww = ws + a.sw; if (ww >= a.W) ww -= a.W;
     const size_t row = ((size_t)b * a.H + hh) * a.W + ww;
     const int lab = 3 * region(hs, a.H, 2, a.sh) + region(ws, a.W, 8, a.sw);
+    TULIP_STAMP(0);
 
     // the token's row: lane owns channels 16n + 4gq .. +3 (n = 0..5) -- the accumulator layout of every GEMM below
     f32x4 xv[6];
@@ -146,18 +178,23 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
 #pragma unroll
         for (int h = 0; h < 3; ++h) rpb[h][r] = a.bias_table[e + h];
     }
-    stage_weights<288, C, PW>(a.wqkv, smem + OFF_A, tid);
-    stage_weights<C, C, PW>(a.wproj, smem + OFF_WPROJ, tid);
-    stage_weights<C, HID, PW2>(a.w2, smem + OFF_W2, tid);
-    for (int i = tid; i < P_N; i += NT) {
-        float v;
-        if (i < P_BQKV) v = a.b1[i];
-        else if (i < P_BPROJ) v = a.bqkv[i - P_BQKV];
-        else if (i < P_B2) v = a.bproj[i - P_BPROJ];
-        else if (i < P_G2) v = a.b2[i - P_B2];
-        else if (i < P_BE2) v = a.g2[i - P_G2];
-        else v = a.be2[i - P_BE2];
-        prm[i] = v;
+    // Every load of the prologue is issued before the first LDS write (round 4: three stage_weights calls and the parameter loop
+    // were six dependent L2 round trips, 12 k of the kernel's 50 k cycles at batch 8 -- tools/swin96_phases.py)
+    {
+        StagedWeights<288, C> sq; StagedWeights<C, C> sp; StagedWeights<C, HID> s2;
+        sq.load(a.wqkv, tid);
+        sp.load(a.wproj, tid);
+        s2.load(a.w2, tid);
+        // b_fc1[384] b_qkv[288] b_proj[96] b_fc2[96] norm2.weight[96] norm2.bias[96] as 264 float4
+        const int i4 = tid * 4;
+        const float* src = i4 < P_BQKV ? a.b1 + i4 : i4 < P_BPROJ ? a.bqkv + (i4 - P_BQKV) : i4 < P_B2 ? a.bproj + (i4 - P_BPROJ)
+                         : i4 < P_G2 ? a.b2 + (i4 - P_B2) : i4 < P_BE2 ? a.g2 + (i4 - P_G2) : a.be2 + (i4 - P_BE2);
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < P_N) pv = *(const float4*)src;
+        sq.template store<PW>(smem + OFF_A, tid);
+        sp.template store<PW>(smem + OFF_WPROJ, tid);
+        s2.template store<PW2>(smem + OFF_W2, tid);
+        if (i4 < P_N) *(float4*)(prm + i4) = pv;
     }
 
     // ---- norm1 (tulip.py:340)
@@ -177,21 +214,18 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
         if (SAVE && gq == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
         bf16x4 p1[6];
-#pragma unroll
-        for (int n = 0; n < 6; ++n) {
-            const int c0 = 16 * n + 4 * gq;
-            const float4 ga = *(const float4*)(a.g1 + c0), be = *(const float4*)(a.be1 + c0);
-            p1[n] = pack4((xv[n][0] - mu) * rs * ga.x + be.x, (xv[n][1] - mu) * rs * ga.y + be.y,
-                          (xv[n][2] - mu) * rs * ga.z + be.z, (xv[n][3] - mu) * rs * ga.w + be.w);
-        }
+        ln_apply(xv, mu, rs, a.g1, a.be1, gq, p1);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if constexpr (SAVE) store_bf16_tile_pair(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
+            if constexpr (SAVE != 0) store_bf16_tile_pair(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
             xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
         }
     }
+    TULIP_STAMP(1);
     __syncthreads();                                        // weights of phase 1, W2 and the parameter vectors are in LDS
+    TULIP_STAMP(2);
 
+    IGLP();
     // ---- qkv Linear (tulip.py:298): acc lane = 4 consecutive output channels 16j + 4gq + r of token t
     bf16x4 qkvp[18];
 #pragma unroll
@@ -203,11 +237,12 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), xfrag[s], acc, 0, 0, 0);
         const float4 bq = *(const float4*)(prm + P_BQKV + 16 * j + 4 * gq);
         qkvp[j] = pack4(acc[0] + bq.x, acc[1] + bq.y, acc[2] + bq.z, acc[3] + bq.w);
-        if (SAVE && (j & 1)) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
+        if (SAVE >= 2 && (j & 1)) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
     }
 
     // fc1.weight rows 0..287 replace qkv.weight in LDS once every wave is through the qkv GEMM: fetched now, written
     // behind the attention core (the stall of a restage between two barriers was ~10 % of this kernel)
+    TULIP_STAMP(3);
     StagedWeights<288, C> w1a;
     w1a.load(a.w1, tid);
 
@@ -250,15 +285,18 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb, o, 0, 0, 0);   // o[r] = O[t][16dc + 4gq + r]
             op[dc] = pack4(o[0], o[1], o[2], o[3]);
         }
-        if constexpr (SAVE) store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
+        if constexpr (SAVE != 0) store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
 
+    TULIP_STAMP(4);
     __syncthreads();                                        // nobody reads qkv.weight any more
+    TULIP_STAMP(5);
     w1a.template store<PW>(smem + OFF_A, tid);
     StagedWeights<96, C> w1b;                               // rows 288..383 go where proj.weight is: behind the proj GEMM
     w1b.load(a.w1 + 288 * C, tid);
 
+    IGLP();
     // ---- proj Linear + DropPath + residual (tulip.py:318,344), then norm2 (:347); x1 replaces x in xv
     const float s0 = a.ds0 ? a.ds0[b] : 1.0f, s1v = a.ds1 ? a.ds1[b] : 1.0f;
     bf16x8 x2frag[3];
@@ -275,7 +313,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const float4 bp = *(const float4*)(prm + P_BPROJ + c0);
             xv[n2] = (f32x4){xv[n2][0] + s0 * (acc[0] + bp.x), xv[n2][1] + s0 * (acc[1] + bp.y),
                              xv[n2][2] + s0 * (acc[2] + bp.z), xv[n2][3] + s0 * (acc[3] + bp.w)};
-            if constexpr (SAVE) *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
+            if constexpr (SAVE != 0) *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
             sum += (xv[n2][0] + xv[n2][1]) + (xv[n2][2] + xv[n2][3]);
         }
         sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
@@ -289,24 +327,20 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
         if (SAVE && gq == 0) { a.mean2[row] = mu; a.rstd2[row] = rs; }
         bf16x4 p2[6];
-#pragma unroll
-        for (int n2 = 0; n2 < 6; ++n2) {
-            const int c0 = 16 * n2 + 4 * gq;
-            const float4 ga = *(const float4*)(prm + P_G2 + c0), be = *(const float4*)(prm + P_BE2 + c0);
-            p2[n2] = pack4((xv[n2][0] - mu) * rs * ga.x + be.x, (xv[n2][1] - mu) * rs * ga.y + be.y,
-                           (xv[n2][2] - mu) * rs * ga.z + be.z, (xv[n2][3] - mu) * rs * ga.w + be.w);
-        }
+        ln_apply(xv, mu, rs, prm + P_G2, prm + P_BE2, gq, p2);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if constexpr (SAVE) store_bf16_tile_pair(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
+            if constexpr (SAVE != 0) store_bf16_tile_pair(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
             x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
         }
     }
 
     // ---- the rest of fc1.weight replaces proj.weight
+    TULIP_STAMP(6);
     __syncthreads();
     w1b.template store<PW>(smem + OFF_WPROJ, tid);
     __syncthreads();
+    TULIP_STAMP(7);
 
     // ---- fc1 -> exact-erf GELU -> fc2 (tulip.py:195-198), 32 hidden channels at a time, chained in registers
     f32x4 acc3[6];
@@ -314,6 +348,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     for (int n2 = 0; n2 < 6; ++n2) acc3[n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int p = 0; p < 12; ++p) {
+        IGLP();
         bf16x4 gp[2], hq[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -326,21 +361,28 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const int c0 = 16 * j + 4 * gq;
             const float4 bb = *(const float4*)(prm + P_B1 + c0);
             const bf16x4 hp = pack4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
-            hq[jj] = hp;
-            const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
-            const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
-            gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
+            const f32x2 h01 = {bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])}, h23 = {bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])};
+            if constexpr (SAVE == 3) {                                                           // GELU of the stored h + its derivative
+                f32x2 g01, g23, d01, d23;
+                gelu_exact_and_grad2(h01, g01, d01);
+                gelu_exact_and_grad2(h23, g23, d23);
+                gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
+                hq[jj] = pack4(d01.x, d01.y, d23.x, d23.y);
+            } else {
+                hq[jj] = hp;
+                const f32x2 g01 = gelu_exact2(h01), g23 = gelu_exact2(h23);                      // GELU of the stored h
+                gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
+            }
         }
-        if constexpr (SAVE) {
-            store_bf16_tile_pair(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
-            store_bf16_tile_pair(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
-        }
+        if constexpr (SAVE >= 2) store_bf16_tile_pair(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
+        if constexpr (SAVE != 0) store_bf16_tile_pair(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
         const bf16x8 gf = cat8(gp[0], gp[1]);
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
             acc3[n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(smem + OFF_W2 + (16 * n2 + t) * PW2, 32 * p + 4 * gq), gf,
                                                                acc3[n2], 0, 0, 0);
     }
+    TULIP_STAMP(8);
 #pragma unroll
     for (int n2 = 0; n2 < 6; ++n2) {
         const int c0 = 16 * n2 + 4 * gq;
@@ -349,6 +391,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             make_float4(xv[n2][0] + s1v * (acc3[n2][0] + bb.x), xv[n2][1] + s1v * (acc3[n2][1] + bb.y),
                         xv[n2][2] + s1v * (acc3[n2][2] + bb.z), xv[n2][3] + s1v * (acc3[n2][3] + bb.w));
     }
+    TULIP_STAMP(9);
 }
 
 
@@ -370,7 +413,8 @@ constexpr int BOFF_T = BOFF_WPROJ + 96 * PT;     // NW x (Q | K | dO) 1-KiB tile
 constexpr int BOFF_RED = BOFF_T + NW * 3072;     // fp32 [NW][192] norm2 | [NW][192] norm1 | [NW][768] bias partial sums
 constexpr int BOFF_GAM = BOFF_W1 + 384 * PT;     // 162816: norm2.weight[96] norm1.weight[96] fp32 (beyond both layouts)
 constexpr int BSMEM = BOFF_GAM + 2 * C * 4;
-static_assert(BOFF_RED + NW * (192 + 192 + 768) * 4 <= BOFF_GAM, "attention-half layout overlaps the norm weights");
+constexpr int BOFF_BQKV = BOFF_RED + NW * (192 + 192 + 768) * 4;   // qkv.bias[288] fp32 (attention half, recomputation form)
+static_assert(BOFF_BQKV + 288 * 4 <= BOFF_GAM, "attention-half layout overlaps the norm weights");
 static_assert(BSMEM <= 163840, "LDS");
 
 struct Swin96BwdArgs {
@@ -380,6 +424,7 @@ struct Swin96BwdArgs {
     const float *mean1, *rstd1, *mean2, *rstd2;
     const bf16_t *wqkv, *wproj, *w1, *w2;
     const float *g1, *g2;
+    const float *bqkv, *b1, *be1, *be2;          // recomputation form (qkv == h == nullptr): the biases the forward added
     const float* bias_table; const int* rel_index;
     const float *ds0, *ds1;
     bf16_t *dyb_m, *dh, *dyb_a, *dqkv;           // bf16 operands of the fc2 / fc1 / proj / qkv weight gradients
@@ -387,6 +432,7 @@ struct Swin96BwdArgs {
     float *lnpart1, *lnpart2, *biaspart;         // [workgroups][192], [workgroups][192], [workgroups][768]
     int B, H, W, sh, sw, masked;
     float scale;
+    unsigned long long* prof;
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -472,6 +518,16 @@ __device__ __forceinline__ void put_red(float* row, const float (&red)[3], int t
     }
 }
 
+// RECOMP (round 4): qkv and the fc1 pre-activation h are not read -- the forward no longer writes them (swin96_fwd_kernel<1>) --
+// but recomputed from x / x1, the saved statistics and the weights that are in LDS anyway: norm1 -> qkv (54 MFMAs per window)
+// and norm2 -> fc1 (72) with the forward's own operand fragments, accumulation order and bias adds, i.e. the forward's bits.
+// The [out][in] LDS copy that the data-gradient GEMMs read transposed is read PLAIN for it (two 8-byte reads per fragment; with
+// the 32 B x odd pitch of the transpose reads tokens t and t + 8 share a bank: 2-way).  2.7 KB per token less HBM traffic
+// for the forward / backward pair, 126 more MFMAs per window.
+// HGRAD (round 4): the fc1_pre buffer holds bf16(gelu'(h)), written by swin96_fwd_kernel<3> (TULIP_BLOCK_FC1_GRAD) -- the MLP
+// half then multiplies with it instead of evaluating erf / exp for 384 values per token (100 of the loop's 134 vector
+// instructions per 32 hidden channels).
+template <bool RECOMP, bool HGRAD, bool PROF>
 __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BSMEM];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
@@ -488,21 +544,45 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     const size_t row = ((size_t)b * a.H + hh) * a.W + ww;
     const int lab = 3 * region(hs, a.H, 2, a.sh) + region(ws, a.W, 8, a.sw);
     const float s0 = a.ds0 ? a.ds0[b] : 1.0f, s1v = a.ds1 ? a.ds1[b] : 1.0f;
+    TULIP_STAMP(0);
 
-    // ---- stage fc2 / fc1 weights; meanwhile fetch the incoming gradient row and the norm2 input row
+    // ---- stage fc2 / fc1 weights.  Every load of the prologue -- weights, the incoming gradient row, statistics, the norm
+    // weights, the relative-position index -- is issued before the first wait (round 4: they were four dependent round trips)
+    f32x4 dy[6], x1v[6];
+    int ridx_q[4], ridx_k[4];
+    float mu2, rs2;
     {
         Staged<C, HID> w2s; Staged<HID, C> w1s;
         stage_load<C, HID>(a.w2, w2s, tid);
         stage_load<HID, C>(a.w1, w1s, tid);
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const float4 u = *(const float4*)(a.dx + row * C + 16 * n + 4 * gq);
+            dy[n] = (f32x4){u.x, u.y, u.z, u.w};
+        }
+        mu2 = a.mean2[row]; rs2 = a.rstd2[row];
+        if constexpr (HGRAD && !RECOMP) {     // the norm2 input row now: behind the (short) MLP loop its loads would queue behind the dh stores
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                const float4 u = *(const float4*)(a.x1 + row * C + 16 * n + 4 * gq);
+                x1v[n] = (f32x4){u.x, u.y, u.z, u.w};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ridx_q[r] = a.rel_index[t * 16 + gq * 4 + r]; ridx_k[r] = a.rel_index[(gq * 4 + r) * 16 + t]; }
+        float gv = 0.f;
+        if (tid < 2 * C) gv = tid < C ? a.g2[tid] : a.g1[tid - C];
         stage_store<C, HID, PT2>(w2s, smem + BOFF_W2, tid);
         stage_store<HID, C, PT>(w1s, smem + BOFF_W1, tid);
+        if (tid < 2 * C) gam[tid] = gv;
     }
-    if (tid < 2 * C) gam[tid] = tid < C ? a.g2[tid] : a.g1[tid - C];
-    f32x4 dy[6], x1v[6];
+    // relative-position bias seen from the query side (query t, key 4gq+r) and from the key side (query 4gq+r, key t)
+    float bias_q[3][4], bias_k[3][4];
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
-        const float4 u = *(const float4*)(a.dx + row * C + 16 * n + 4 * gq);
-        dy[n] = (f32x4){u.x, u.y, u.z, u.w};
+    for (int r = 0; r < 4; ++r) {
+        const int eq = ridx_q[r] * 3, ek = ridx_k[r] * 3;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) { bias_q[h][r] = a.bias_table[eq + h]; bias_k[h][r] = a.bias_table[ek + h]; }
     }
     bf16x8 dyf[3];
     {
@@ -517,37 +597,62 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             dyf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
         }
     }
-    const float mu2 = a.mean2[row], rs2 = a.rstd2[row];
-    // relative-position bias seen from the query side (query t, key 4gq+r) and from the key side (query 4gq+r, key t)
-    float bias_q[3][4], bias_k[3][4];
+    // recomputation form: xn2 = norm2(x1) as the forward formed it (the row is fetched again for norm2' behind the loop: L2)
+    bf16x8 x2frag[3];
+    if constexpr (RECOMP) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int eq = a.rel_index[t * 16 + gq * 4 + r] * 3, ek = a.rel_index[(gq * 4 + r) * 16 + t] * 3;
+        for (int n = 0; n < 6; ++n) {
+            const float4 u = *(const float4*)(a.x1 + row * C + 16 * n + 4 * gq);
+            x1v[n] = (f32x4){u.x, u.y, u.z, u.w};
+        }
+        bf16x4 p2[6];
+        ln_apply(x1v, mu2, rs2, a.g2, a.be2, gq, p2);
 #pragma unroll
-        for (int h = 0; h < 3; ++h) { bias_q[h][r] = a.bias_table[eq + h]; bias_k[h][r] = a.bias_table[ek + h]; }
+        for (int s = 0; s < 3; ++s) x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
     }
+    TULIP_STAMP(1);
     __syncthreads();
+    TULIP_STAMP(2);
 
     // ---- MLP half (tulip.py:346-351 backwards): per 32 hidden channels  dg = dy.W2 -> dh = dg*gelu'(h) -> dxn2 += dh.W1
     f32x4 acc2[6];
 #pragma unroll
     for (int n = 0; n < 6; ++n) acc2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* hrow = a.h + row * HID + 4 * gq;
-    bf16x4 hn[2] = {*(const bf16x4*)(hrow), *(const bf16x4*)(hrow + 16)};
+    const bf16_t* hrow = RECOMP ? nullptr : a.h + row * HID + 4 * gq;
+    bf16x4 hn[2];
+    float4 bn[2];
+    if constexpr (RECOMP) { bn[0] = *(const float4*)(a.b1 + 4 * gq); bn[1] = *(const float4*)(a.b1 + 16 + 4 * gq); }
+    else { hn[0] = *(const bf16x4*)(hrow); hn[1] = *(const bf16x4*)(hrow + 16); }
 #pragma unroll 2
     for (int p = 0; p < 12; ++p) {
-        const bf16x4 hc[2] = {hn[0], hn[1]};
-        if (p + 1 < 12) { hn[0] = *(const bf16x4*)(hrow + 32 * (p + 1)); hn[1] = *(const bf16x4*)(hrow + 32 * (p + 1) + 16); }
+        IGLP();
+        bf16x4 hc[2];
+        float4 bc[2];
+        if constexpr (RECOMP) {
+            bc[0] = bn[0]; bc[1] = bn[1];
+            if (p + 1 < 12) { bn[0] = *(const float4*)(a.b1 + 32 * (p + 1) + 4 * gq); bn[1] = *(const float4*)(a.b1 + 32 * (p + 1) + 16 + 4 * gq); }
+        } else {
+            hc[0] = hn[0]; hc[1] = hn[1];
+            if (p + 1 < 12) { hn[0] = *(const bf16x4*)(hrow + 32 * (p + 1)); hn[1] = *(const bf16x4*)(hrow + 32 * (p + 1) + 16); }
+        }
         bf16x4 dp[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j0 = 32 * p + 16 * jj;
+            if constexpr (RECOMP) {     // h tile = fc1(xn2) + bias, rounded to bf16: swin96_fwd_kernel's fc1 step
+                f32x4 ah = {0.f, 0.f, 0.f, 0.f};
+                const unsigned char* wr = smem + BOFF_W1 + (j0 + t) * PT;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), x2frag[s], ah, 0, 0, 0);
+                hc[jj] = pack4(ah[0] + bc[jj].x, ah[1] + bc[jj].y, ah[2] + bc[jj].z, ah[3] + bc[jj].w);
+            }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_W2, PT2, 32 * s, j0, t, gq), dyf[s], acc, 0, 0, 0);
-            const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hc[jj][0]), bf2f((bf16_t)hc[jj][1])});
-            const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hc[jj][2]), bf2f((bf16_t)hc[jj][3])});
+            f32x2 d01 = {bf2f((bf16_t)hc[jj][0]), bf2f((bf16_t)hc[jj][1])}, d23 = {bf2f((bf16_t)hc[jj][2]), bf2f((bf16_t)hc[jj][3])};
+            if constexpr (!HGRAD || RECOMP) { d01 = gelu_exact_grad2(d01); d23 = gelu_exact_grad2(d23); }
             dp[jj] = pack4(acc[0] * d01.x, acc[1] * d01.y, acc[2] * d23.x, acc[3] * d23.y);
         }
         store_bf16_tile_pair(a.dh + row * HID + 32 * p, dp[0], dp[1], gq);
@@ -557,14 +662,24 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_W1, PT, 32 * p, 16 * n, t, gq), df, acc2[n], 0, 0, 0);
     }
 
+    TULIP_STAMP(3);
     // ---- the attention-half weights are fetched while norm2 is differentiated
     Staged<288, C> wqs; Staged<C, C> wps;
     stage_load<288, C>(a.wqkv, wqs, tid);
     stage_load<C, C>(a.wproj, wps, tid);
+    if constexpr (!HGRAD || RECOMP) {
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
-        const float4 u = *(const float4*)(a.x1 + row * C + 16 * n + 4 * gq);
-        x1v[n] = (f32x4){u.x, u.y, u.z, u.w};
+        for (int n = 0; n < 6; ++n) {
+            const float4 u = *(const float4*)(a.x1 + row * C + 16 * n + 4 * gq);
+            x1v[n] = (f32x4){u.x, u.y, u.z, u.w};
+        }
+    }
+    if constexpr (RECOMP) {     // the incoming gradient row again (L2): 24 registers that need not live through the loop above
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const float4 u = *(const float4*)(a.dx + row * C + 16 * n + 4 * gq);
+            dy[n] = (f32x4){u.x, u.y, u.z, u.w};
+        }
     }
     float red2[3];
     ln_bwd_row(acc2, x1v, mu2, rs2, gam, t, gq, red2);
@@ -583,18 +698,54 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             daf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
         }
     }
-    // q, k, v of this token, all heads, in the chained k order (dims 4gq.., 16+4gq.. of each head)
+    // q, k, v of this token, all heads, in the chained k order (dims 4gq.., 16+4gq.. of each head): read back, or (RECOMP)
+    // recomputed behind the barrier from xn1 = norm1(x) as the forward formed it
     bf16x4 qkvr[18];
-#pragma unroll
-    for (int j = 0; j < 18; ++j) qkvr[j] = *(const bf16x4*)(a.qkv + row * 288 + 16 * j + 4 * gq);
+    bf16x8 xfrag[3];
     const float mu1 = a.mean1[row], rs1 = a.rstd1[row];
+    if constexpr (!RECOMP) {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) qkvr[j] = *(const bf16x4*)(a.qkv + row * 288 + 16 * j + 4 * gq);
+    }
+    TULIP_STAMP(4);
     __syncthreads();                                          // every wave is done with fc1 / fc2 weights
+    TULIP_STAMP(5);
     stage_store<288, C, PT>(wqs, smem + BOFF_WQKV, tid);
     stage_store<C, C, PT>(wps, smem + BOFF_WPROJ, tid);
     float* redw = (float*)(smem + BOFF_RED);
     put_red(redw + wid * 192, red2, t, gq);
+    if constexpr (RECOMP) {     // (the x row is fetched here, not in front of the barrier: the staged weights hold 40 registers there)
+        if (tid < 288) ((float*)(smem + BOFF_BQKV))[tid] = a.bqkv[tid];
+        f32x4 xr[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const float4 u = *(const float4*)(a.xin + row * C + 16 * n + 4 * gq);
+            xr[n] = (f32x4){u.x, u.y, u.z, u.w};
+        }
+        bf16x4 p1[6];
+        ln_apply(xr, mu1, rs1, a.g1, a.be1, gq, p1);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);
+    }
     __syncthreads();
+    TULIP_STAMP(6);
 
+    IGLP();
+    if constexpr (RECOMP) {     // qkv = xn1 . Wqkv^T + bias, rounded to bf16: swin96_fwd_kernel's qkv step
+        const float* bq = (const float*)(smem + BOFF_BQKV);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const unsigned char* wr = smem + BOFF_WQKV + (16 * j + t) * PT;
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), xfrag[s], acc, 0, 0, 0);
+            const float4 b4 = *(const float4*)(bq + 16 * j + 4 * gq);
+            qkvr[j] = pack4(acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w);
+        }
+    }
+
+    TULIP_STAMP(7);
     // ---- proj' : dO = dyb_a . Wproj   (tulip.py:318 backwards)
     bf16x4 dop[6];
 #pragma unroll
@@ -605,6 +756,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_WPROJ, PT, 32 * s, 16 * n, t, gq), daf[s], acc, 0, 0, 0);
         dop[n] = pack4(acc[0], acc[1], acc[2], acc[3]);
     }
+    TULIP_STAMP(8);
     // ---- attention' per head (tulip.py:300-317 backwards; same algebra as attn_bwd_kernel)
     unsigned char* ldsQ = smem + BOFF_T + wid * 3072;
     unsigned char* ldsK = ldsQ + 1024;
@@ -680,6 +832,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             dqkvp[12 + 2 * h + dc] = pack4(dv[0], dv[1], dv[2], dv[3]);
         }
     }
+    TULIP_STAMP(9);
 #pragma unroll
     for (int j = 0; j < 9; ++j) store_bf16_tile_pair(a.dqkv + row * 288 + 32 * j, dqkvp[2 * j], dqkvp[2 * j + 1], gq);
 
@@ -698,6 +851,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int n = 0; n < 6; ++n)
             acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag_t(smem + BOFF_WQKV, PT, 32 * s, 16 * n, t, gq), f, acc1[n], 0, 0, 0);
     }
+    TULIP_STAMP(10);
     float red1[3];
     ln_bwd_row(acc1, xv, mu1, rs1, gam + C, t, gq, red1);
     const float cs = a.dx_scale ? a.dx_scale[b] : 1.0f;
@@ -713,6 +867,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int n = 0; n < 3; ++n) store_bf16_tile_pair(a.dx_bf16 + row * C + 32 * n, ob[2 * n], ob[2 * n + 1], gq);
     }
     put_red(redw + NW * 192 + wid * 192, red1, t, gq);
+    TULIP_STAMP(11);
     __syncthreads();
     // ---- one partial row per workgroup: waves summed in a fixed order
     for (int i = tid; i < 192 + 192 + 768; i += NT) {
@@ -725,11 +880,12 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int w = 0; w < NW; ++w) sacc += src[w * stride];
         *dst = sacc;
     }
+    TULIP_STAMP(12);
 }
 
 }  // namespace
 
-extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream) {
+static int swin96_fwd_impl(const tulip_swin96_desc* d, unsigned long long* prof, hipStream_t stream) {
     if (!d || d->B <= 0 || d->H <= 0 || (d->H & 1) || d->W <= 0 || (d->W & 63) || d->shift_h < 0 ||
         d->shift_h >= d->H || d->shift_w < 0 || d->shift_w >= d->W)
         return TULIP_ERR_ARG;
@@ -745,17 +901,30 @@ extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t st
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
+    a.prof = prof;
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
-    // every saved-activation pointer NULL: the inference form
-    const bool save = d->xn1 || d->qkv || d->attn_out || d->x1 || d->xn2 || d->fc1_pre || d->fc1_act || d->mean1 || d->rstd1 ||
-                      d->mean2 || d->rstd2;
-    if (save && !(d->xn1 && d->qkv && d->attn_out && d->x1 && d->xn2 && d->fc1_pre && d->fc1_act && d->mean1 && d->rstd1 &&
-                  d->mean2 && d->rstd2))
-        return TULIP_ERR_ARG;
-    if (save) hipLaunchKernelGGL(swin96_fwd_kernel<true>, dim3(blocks), dim3(NT), 0, stream, a);
-    else hipLaunchKernelGGL(swin96_fwd_kernel<false>, dim3(blocks), dim3(NT), 0, stream, a);
+    // every saved-activation pointer NULL: the inference form; qkv and fc1_pre alone NULL: the backward recomputes them
+    const bool core = d->xn1 && d->attn_out && d->x1 && d->xn2 && d->fc1_act && d->mean1 && d->rstd1 && d->mean2 && d->rstd2;
+    const bool any = d->xn1 || d->qkv || d->attn_out || d->x1 || d->xn2 || d->fc1_pre || d->fc1_act || d->mean1 || d->rstd1 ||
+                     d->mean2 || d->rstd2;
+    if (any && !(core && (!d->qkv == !d->fc1_pre))) return TULIP_ERR_ARG;
+    const bool hgrad = (d->masked & TULIP_BLOCK_FC1_GRAD) != 0;
+    const dim3 g(blocks), b(NT);
+    if (prof) {                                         // diagnostic twin: the full training forms only
+        if (!any || !d->qkv) return TULIP_ERR_ARG;
+        if (hgrad) hipLaunchKernelGGL((swin96_fwd_kernel<3, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((swin96_fwd_kernel<2, true>), g, b, 0, stream, a);
+    } else if (!any) hipLaunchKernelGGL((swin96_fwd_kernel<0, false>), g, b, 0, stream, a);
+    else if (!d->qkv) hipLaunchKernelGGL((swin96_fwd_kernel<1, false>), g, b, 0, stream, a);
+    else if (hgrad) hipLaunchKernelGGL((swin96_fwd_kernel<3, false>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((swin96_fwd_kernel<2, false>), g, b, 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
+}
+
+extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream) { return swin96_fwd_impl(d, nullptr, stream); }
+extern "C" int tulip_swin96_block_fwd_profiled(const tulip_swin96_desc* d, uint64_t* stamps, hipStream_t stream) {
+    return swin96_fwd_impl(d, (unsigned long long*)stamps, stream);
 }
 
 extern "C" int tulip_swin96_bwd_partial_rows(int B, int H, int W) {
@@ -763,7 +932,7 @@ extern "C" int tulip_swin96_bwd_partial_rows(int B, int H, int W) {
     return B * (H / 2) * (W / (8 * NW));
 }
 
-extern "C" int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream) {
+static int swin96_bwd_impl(const tulip_swin96_bwd_desc* d, unsigned long long* prof, hipStream_t stream) {
     if (!d || d->B <= 0 || d->H <= 0 || (d->H & 1) || d->W <= 0 || (d->W & 63) || d->shift_h < 0 ||
         d->shift_h >= d->H || d->shift_w < 0 || d->shift_w >= d->W)
         return TULIP_ERR_ARG;
@@ -774,6 +943,10 @@ extern "C" int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_
     a.wqkv = (const bf16_t*)d->w_qkv; a.wproj = (const bf16_t*)d->w_proj; a.w1 = (const bf16_t*)d->w_fc1;
     a.w2 = (const bf16_t*)d->w_fc2;
     a.g1 = d->norm1_weight; a.g2 = d->norm2_weight;
+    a.bqkv = d->b_qkv; a.b1 = d->b_fc1; a.be1 = d->norm1_bias; a.be2 = d->norm2_bias;
+    // qkv and fc1_pre both NULL: the recomputation form (needs the four bias vectors the forward added)
+    const bool recomp = !d->qkv && !d->fc1_pre;
+    if (recomp ? !(d->b_qkv && d->b_fc1 && d->norm1_bias && d->norm2_bias) : !(d->qkv && d->fc1_pre)) return TULIP_ERR_ARG;
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.dyb_m = (bf16_t*)d->d_out_mlp; a.dh = (bf16_t*)d->d_fc1_pre; a.dyb_a = (bf16_t*)d->d_out_attn;
     a.dqkv = (bf16_t*)d->d_qkv;
@@ -781,8 +954,21 @@ extern "C" int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_
     a.lnpart1 = d->norm1_partials; a.lnpart2 = d->norm2_partials; a.biaspart = d->bias_partials;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.scale = 0.17677669529663687f;
+    a.prof = prof;
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
-    hipLaunchKernelGGL(swin96_bwd_kernel, dim3(blocks), dim3(NT), 0, stream, a);
+    const bool hgrad = (d->masked & TULIP_BLOCK_FC1_GRAD) != 0;
+    const dim3 g(blocks), b(NT);
+    if (prof) {
+        if (recomp) hipLaunchKernelGGL((swin96_bwd_kernel<true, false, true>), g, b, 0, stream, a);
+        else if (hgrad) hipLaunchKernelGGL((swin96_bwd_kernel<false, true, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((swin96_bwd_kernel<false, false, true>), g, b, 0, stream, a);
+    } else if (recomp) hipLaunchKernelGGL((swin96_bwd_kernel<true, false, false>), g, b, 0, stream, a);
+    else if (hgrad) hipLaunchKernelGGL((swin96_bwd_kernel<false, true, false>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((swin96_bwd_kernel<false, false, false>), g, b, 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
+}
+extern "C" int tulip_swin96_block_bwd(const tulip_swin96_bwd_desc* d, hipStream_t stream) { return swin96_bwd_impl(d, nullptr, stream); }
+extern "C" int tulip_swin96_block_bwd_profiled(const tulip_swin96_bwd_desc* d, uint64_t* stamps, hipStream_t stream) {
+    return swin96_bwd_impl(d, (unsigned long long*)stamps, stream);
 }

@@ -233,11 +233,12 @@ __device__ __forceinline__ TokMap make_map(int B, int H, int W, int sh, int sw) 
 }
 
 // MODE: bits 0-1 = the L2 warm-up (0 none, 1 every workgroup, 2 the first 256); bit 2 = the inference form (eval / MC-dropout
-// forward: the activations a backward would need are not written)
+// forward: the activations a backward would need are not written); bit 3 = the fc1_pre buffer receives gelu'(h), not h
 template <int C, int G, int MODE>
 __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWArgs a) {
     constexpr int WARM = MODE & 3;
     constexpr bool SAVE = !(MODE & 4);
+    constexpr bool HGRAD = (MODE & 8) != 0;     // round 4 (TULIP_BLOCK_FC1_GRAD): the fc1_pre buffer receives bf16(gelu'(h)) instead of h
     using Z = Geo<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
@@ -492,9 +493,17 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             if constexpr (D == 2) bb = b1v[ch][i]; else bb = ld4(a.b1 + n);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const bf16x4 hp = pack4(acc[i][g][0] + bb[0], acc[i][g][1] + bb[1], acc[i][g][2] + bb[2], acc[i][g][3] + bb[3]);
-                const f32x2 g01 = gelu_exact2((f32x2){bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])});      // GELU of the stored h
-                const f32x2 g23 = gelu_exact2((f32x2){bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])});
+                bf16x4 hp = pack4(acc[i][g][0] + bb[0], acc[i][g][1] + bb[1], acc[i][g][2] + bb[2], acc[i][g][3] + bb[3]);
+                const f32x2 h01 = {bf2f((bf16_t)hp[0]), bf2f((bf16_t)hp[1])}, h23 = {bf2f((bf16_t)hp[2]), bf2f((bf16_t)hp[3])};
+                f32x2 g01, g23;                                                                        // GELU of the (rounded) h
+                if constexpr (HGRAD && SAVE) {      // ... and its derivative: all the backward wants from h
+                    f32x2 d01, d23;
+                    gelu_exact_and_grad2(h01, g01, d01);
+                    gelu_exact_and_grad2(h23, g23, d23);
+                    hp = pack4(d01.x, d01.y, d23.x, d23.y);
+                } else {
+                    g01 = gelu_exact2(h01); g23 = gelu_exact2(h23);
+                }
                 const bf16x4 gp = pack4(g01.x, g01.y, g23.x, g23.y);
                 put4<T>(GB, 16 * g + t, n, gp);
                 if (i & 1) {    // two adjacent tiles: one 16-byte store per lane (common.h)
@@ -558,7 +567,11 @@ int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
     // the workgroups that are resident first warm their XCD's L2 with the block's weights (WeightWarm)
     const int warm = (a.prof || !swinw_warm || blocks < 8) ? 0 : (blocks <= 256 ? 1 : 2);
     const dim3 grid(blocks), block(Geo<C, G>::NT);
-    if (a.qkv) {
+    if (a.qkv && (a.masked & TULIP_BLOCK_FC1_GRAD)) {       // training form, gelu'(h) handed to the backward
+        if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 9>), grid, block, 0, stream, a);
+        else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 10>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 8>), grid, block, 0, stream, a);
+    } else if (a.qkv) {
         if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 1>), grid, block, 0, stream, a);
         else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 2>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 0>), grid, block, 0, stream, a);
@@ -661,8 +674,12 @@ __device__ __forceinline__ void ln_bwd_part2(f32x4 (&d)[2][G], const f32x4 (&xh)
     }
 }
 
-template <int C, int G, int WARM>
+// BMODE: bits 0-1 = the L2 warm-up as in the forward; bit 2 (round 4, TULIP_BLOCK_FC1_GRAD) = the fc1_pre buffer holds
+// bf16(gelu'(h)), written by the forward's MODE bit 3, and the MLP half multiplies with it instead of evaluating erf / exp
+template <int C, int G, int BMODE>
 __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinWBwdArgs a) {
+    constexpr int WARM = BMODE & 3;
+    constexpr bool HGRAD = (BMODE & 4) != 0;
     using Z = GeoB<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
@@ -739,8 +756,8 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const f32x2 d01 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[i][g][0]), bf2f((bf16_t)hv[i][g][1])});
-                const f32x2 d23 = gelu_exact_grad2((f32x2){bf2f((bf16_t)hv[i][g][2]), bf2f((bf16_t)hv[i][g][3])});
+                f32x2 d01 = {bf2f((bf16_t)hv[i][g][0]), bf2f((bf16_t)hv[i][g][1])}, d23 = {bf2f((bf16_t)hv[i][g][2]), bf2f((bf16_t)hv[i][g][3])};
+                if constexpr (!HGRAD) { d01 = gelu_exact_grad2(d01); d23 = gelu_exact_grad2(d23); }    // HGRAD: the forward left gelu'(h) there
                 const bf16x4 dp = pack4(acc[i][g][0] * d01.x, acc[i][g][1] * d01.y, acc[i][g][2] * d23.x, acc[i][g][3] * d23.y);
                 put4<T>(DH, 16 * g + t, n, dp);
                 if (i & 1) store_bf16_tile_pair(a.dh + rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1), dprev[g], dp, gq);
@@ -964,12 +981,17 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 template <int C, int G>
 int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
-    if (blocks <= 256 && blocks >= 8 && swinw_warm)
-        hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 1>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
-    else if (blocks > 256 && swinw_warm)
-        hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 2>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
-    else
-        hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 0>), dim3(blocks), dim3(GeoB<C, G>::NT), 0, stream, a);
+    const int warm = (blocks <= 256 && blocks >= 8 && swinw_warm) ? 1 : (blocks > 256 && swinw_warm) ? 2 : 0;
+    const dim3 grid(blocks), block(GeoB<C, G>::NT);
+    if (a.masked & TULIP_BLOCK_FC1_GRAD) {      // the fc1_pre buffer holds gelu'(h) (bit 2 of the template's mode)
+        if (warm == 1) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 5>), grid, block, 0, stream, a);
+        else if (warm == 2) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 6>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 4>), grid, block, 0, stream, a);
+    } else {
+        if (warm == 1) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 1>), grid, block, 0, stream, a);
+        else if (warm == 2) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 0>), grid, block, 0, stream, a);
+    }
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
 }

@@ -470,6 +470,31 @@ class TulipEngine:
     fuse_block96 = os.environ.get("TULIP_FUSE_BLOCK96", "1") != "0"
     fuse_block96_bwd = os.environ.get("TULIP_FUSE_BLOCK96_BWD", "1") != "0"
 
+    # round 4: the C = 96 forward no longer writes qkv and the fc1 pre-activation (1344 of 3472 B per token); the fused backward
+    # recomputes both from x / x1 with the weights it holds in LDS anyway (csrc/swin96.hip swin96_bwd_kernel<true>).
+    # TULIP_SWIN96_RECOMPUTE=0: the round-3 form (everything saved and read back)
+    # Measured (profiles/README.md round 4): the forward gains 1 us at batch 8 / 25 us at batch 64 (it is not store-bound), the
+    # backward loses 12 / 45 us (126 more MFMAs per window, bank conflicts of the plain reads at the transpose pitch): off by
+    # default, kept as a tested form (bit-identical outputs, tests/test_round4_gpu.py).
+    recompute96 = os.environ.get("TULIP_SWIN96_RECOMPUTE", "0") != "0"
+    # round 4: the fused C = 96 forward writes bf16(gelu'(h)) where it used to write h (same bytes); the only thing the backward
+    # does with h is that derivative (100 of 134 vector instructions per 32 hidden channels of its MLP loop).
+    # TULIP_FC1_GRAD=0: h is saved and the backward evaluates gelu' itself
+    fc1_grad96 = os.environ.get("TULIP_FC1_GRAD", "1") != "0"
+
+    def _hgrad96(self, sp: BlockSpec) -> bool:
+        return (self.fc1_grad96 and self.fuse_block96 and self.fuse_block96_bwd and self._fusable96(sp)
+                and not self._recomp96(sp))
+
+    # ... and the same hand-off in the fused wide blocks (csrc/swinw.hip): TULIP_FC1_GRAD_WIDE=0 switches it off there
+    fc1_grad_wide = os.environ.get("TULIP_FC1_GRAD_WIDE", "1") != "0"
+
+    def _hgrad_wide(self, sp: BlockSpec, B: int) -> bool:
+        return self.fc1_grad_wide and self.fuse_wide and self.fuse_wide_bwd and self._fusable_wide(sp, B)
+
+    def _recomp96(self, sp: BlockSpec) -> bool:
+        return self.recompute96 and self.fuse_block96 and self.fuse_block96_bwd and self._fusable96(sp)
+
     def _fusable96(self, sp: BlockSpec) -> bool:
         """csrc/swin96.hip covers the embed-width-96 block: 3 heads x 32, window 2x8, MLP 96 -> 384 -> 96."""
         return (sp.C == 96 and sp.nh == 3 and self.hidden(sp.C) == 384 and tuple(sp.win) == (2, 8) and sp.W % 64 == 0
@@ -481,9 +506,12 @@ class TulipEngine:
     # q, k).  Off by default: the reference computes the scores from bf16 / fp16 operands.
     attn_fp8 = os.environ.get("TULIP_ATTN_FP8", "0") == "1"
 
-    def _mask_arg(self, sp: BlockSpec) -> int:
-        """`masked` argument of the attention / block kernels: bit 0 shifted-window mask, bit 1 fp8 scores."""
-        return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0)
+    def _mask_arg(self, sp: BlockSpec, B: Optional[int] = None) -> int:
+        """`masked` argument of the attention / block kernels: bit 0 shifted-window mask, bit 1 fp8 scores, bit 2 (fused
+        blocks, TULIP_BLOCK_FC1_GRAD; B = the plan's batch size for the wide ones) the fc1_pre buffer carries gelu'(h) from
+        the forward to the backward."""
+        hg = self._hgrad96(sp) or (B is not None and self._hgrad_wide(sp, B))
+        return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0) | (4 if hg else 0)
 
     fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
     fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
@@ -551,7 +579,8 @@ class TulipEngine:
             wf = W_.p16p if wide else W_.p16           # the wide kernel streams fragment-major copies of the weights
             # forward without a backward behind it (run_forward(with_loss=False): eval / MC-dropout inference): the kernels'
             # inference form -- none of the activations a backward would read is written (90 % of the C = 96 kernel's traffic)
-            sv = (lambda k: None) if self._no_save else (lambda k: P[p + k])
+            lean = (not wide) and self._recomp96(sp)                # qkv / fc1 pre-activation: recomputed by the backward
+            sv = (lambda k: None) if self._no_save else (lambda k: None if (lean and k in (".qkv", ".h")) else P[p + k])
             launch(
                 x_in=xin, x1=sv(".x1"), x_out=xout, xn1=sv(".xn1"), qkv=sv(".qkv"), attn_out=sv(".o"),
                 xn2=sv(".xn2"), fc1_pre=sv(".h"), fc1_act=sv(".g"), mean1=sv(".mean1"),
@@ -564,7 +593,7 @@ class TulipEngine:
                 norm2_weight=W_.p32(p + ".norm2.weight"), norm2_bias=W_.p32(p + ".norm2.bias"),
                 bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=B, H=sp.H, W=sp.W,
-                shift_h=sp.sft[0], shift_w=sp.sft[1], masked=self._mask_arg(sp), eps=self.eps)
+                shift_h=sp.sft[0], shift_w=sp.sft[1], masked=self._mask_arg(sp, B), eps=self.eps)
             if out_bf16 is not None and not wide:
                 ops.cast_f32_bf16(xout, out_bf16, M, C)
             return
@@ -1150,8 +1179,12 @@ class TulipEngine:
             apart = P.scratch("apart." + p, R * nh * 256)
             launch = (lambda **kw: ops.swinw_block_bwd(C, **kw)) if wide else ops.swin96_block_bwd
             wt = W_.p16t if wide else W_.p16          # the wide kernel streams fragment-major TRANSPOSED weights
+            lean = (not wide) and self._recomp96(sp)
+            extra = dict(b_qkv=W_.p32(p + ".attn.qkv.bias"), b_fc1=W_.p32(p + ".mlp.fc1.bias"),
+                         norm1_bias=W_.p32(p + ".norm1.bias"), norm2_bias=W_.p32(p + ".norm2.bias")) if lean else {}
             launch(
-                dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=P[p + ".qkv"], fc1_pre=P[p + ".h"], mean1=P[p + ".mean1"],
+                dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=None if lean else P[p + ".qkv"], fc1_pre=None if lean else P[p + ".h"],
+                mean1=P[p + ".mean1"],
                 rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
                 w_qkv=wt(p + ".attn.qkv.weight"), w_proj=wt(p + ".attn.proj.weight"),
                 w_fc1=wt(p + ".mlp.fc1.weight"), w_fc2=wt(p + ".mlp.fc2.weight"),
@@ -1160,7 +1193,7 @@ class TulipEngine:
                 drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), d_out_mlp=dyb, d_fc1_pre=dh,
                 d_out_attn=P[p + ".dyb_a"], d_qkv=dqkv, dx_bf16=cb, dx_bf16_scale=cs, norm1_partials=ln1,
                 norm2_partials=ln2, bias_partials=apart, B=B, H=sp.H, W=sp.W, shift_h=sp.sft[0], shift_w=sp.sft[1],
-                masked=self._mask_arg(sp))
+                masked=self._mask_arg(sp, B), **extra)
             self._release_deferred()
             self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
             self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))

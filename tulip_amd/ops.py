@@ -376,14 +376,18 @@ def kitti_range_map(points, n, rows, cols, ang_start_y, ang_res_y, ang_res_x, ma
                                             _stream()), "tulip_kitti_range_map")
 
 
-def swin96_block_fwd(**kw):
-    """tulip_swin96_block_fwd: keyword arguments are the fields of tulip_swin96_desc (tensors or addresses)."""
+def swin96_block_fwd(stamps=None, **kw):
+    """tulip_swin96_block_fwd: keyword arguments are the fields of tulip_swin96_desc (tensors or addresses).
+    stamps (int64 device tensor): the profiled twin."""
     d = _lib.Swin96Desc()
     for name, _t in _lib.Swin96Desc._fields_:
         v = kw.pop(name, None)
         setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
     if kw:
         raise TypeError(f"unknown fields {sorted(kw)}")
+    if stamps is not None:
+        check(_lib.load().tulip_swin96_block_fwd_profiled(ctypes.byref(d), _p(stamps), _stream()), "tulip_swin96_block_fwd_profiled")
+        return
     check(_lib.load().tulip_swin96_block_fwd(ctypes.byref(d), _stream()), "tulip_swin96_block_fwd")
 
 
@@ -455,7 +459,7 @@ def swin96_bwd_partial_rows(B, H, W) -> int:
     return _lib.load().tulip_swin96_bwd_partial_rows(B, H, W)
 
 
-def swin96_block_bwd(**kw):
+def swin96_block_bwd(stamps=None, **kw):
     """tulip_swin96_block_bwd: keyword arguments are the fields of tulip_swin96_bwd_desc (tensors or addresses)."""
     d = _lib.Swin96BwdDesc()
     for name, _t in _lib.Swin96BwdDesc._fields_:
@@ -463,4 +467,7 @@ def swin96_block_bwd(**kw):
         setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked") else v)
     if kw:
         raise TypeError(f"unknown fields {sorted(kw)}")
+    if stamps is not None:
+        check(_lib.load().tulip_swin96_block_bwd_profiled(ctypes.byref(d), _p(stamps), _stream()), "tulip_swin96_block_bwd_profiled")
+        return
     check(_lib.load().tulip_swin96_block_bwd(ctypes.byref(d), _stream()), "tulip_swin96_block_bwd")
