@@ -110,13 +110,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             s[r] = x;
             mx = fmaxf(mx, x);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mx); sum += s[r]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         const bf16x4 pb = pack4(s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv);
         bf16_t* dst = out + (size_t)row * g.C + h * P + gq * 4;
@@ -195,13 +193,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
             sq[r] = xq; sk[r] = xk;
             mx = fmaxf(mx, xq);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum += __expf(sq[r] - mx);
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float lse = mx + __logf(sum);  // for query li
         float pq[4], pk[4], delta = 0.f;
 #pragma unroll
@@ -210,8 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
             pk[r] = __expf(sk[r] - __shfl(lse, gq * 4 + r, 64));
             delta += pq[r] * dpq[r];
         }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);  // sum_key P*dP for query li
+        delta = rows_sum(delta);  // sum_key P*dP for query li
         float dsq[4], dsk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -180,6 +180,32 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// v (op) v[lane ^ 16] and v (op) v[lane ^ 32] without the LDS round trip of __shfl_xor (ds_bpermute_b32, ~100 cycles in a dependent
+// chain -- the softmax of one attention head is four of them in a row): gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// the odd 16-lane rows (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another; fed the same
+// value twice they return [even-row value, odd-row value] ([lower-half value, upper-half value]) in every lane.  op is
+// commutative: the same bits as the shuffle form.
+template <class OP>
+__device__ __forceinline__ float xor16_reduce(float v, OP op) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+template <class OP>
+__device__ __forceinline__ float xor32_reduce(float v, OP op) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+// sum / max over the four 16-lane rows of a wave (lanes t, t + 16, t + 32, t + 48): every lane gets the result
+__device__ __forceinline__ float rows_sum(float v) {
+    auto add = [](float a, float b) { return a + b; };
+    return xor32_reduce(xor16_reduce(v, add), add);
+}
+__device__ __forceinline__ float rows_max(float v) {
+    auto mx = [](float a, float b) { return fmaxf(a, b); };
+    return xor32_reduce(xor16_reduce(v, mx), mx);
+}
 template <int WIDTH, class OP>
 __device__ __forceinline__ float group_reduce(float v, OP op) {
     static_assert(WIDTH == 2 || WIDTH == 4 || WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "WIDTH");
@@ -187,6 +213,9 @@ __device__ __forceinline__ float group_reduce(float v, OP op) {
     if (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));          // quad_perm [2,3,0,1]: lane ^ 2
     if (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));         // row_half_mirror: the other quad of the 8-lane half
     if (WIDTH >= 16) v = op(v, dpp_move<0x140>(v));        // row_mirror: the other half of the 16-lane row
+    // (the last two steps stay on __shfl_xor here: the permlane form is the same arithmetic -- tools/probe_permlane.hip -- but it
+    // moves the compiler's fma contraction around the call in the LayerNorm / patch-embedding kernels, and the tiny L1-loss
+    // fixtures, whose gradient is a sign function of the prediction, are sensitive to single-ulp changes there)
     if (WIDTH >= 32) v = op(v, __shfl_xor(v, 16, 64));
     if (WIDTH >= 64) v = op(v, __shfl_xor(v, 32, 64));
     return v;

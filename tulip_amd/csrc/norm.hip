@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void patch_embed_bwd16_kernel(const float* __r
         }
     }
     // fold the wave's 4 token slots (lanes sub, sub+16, sub+32, sub+48), then the 4 waves through LDS
-    auto fold4 = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    auto fold4 = [](float v) { return rows_sum(v); };
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
 #pragma unroll

@@ -203,14 +203,14 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         float s1 = 0.f;
 #pragma unroll
         for (int n = 0; n < 6; ++n) s1 += (xv[n][0] + xv[n][1]) + (xv[n][2] + xv[n][3]);
-        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s1 = rows_sum(s1);
         const float mu = s1 * (1.0f / C);
         float s2 = 0.f;
 #pragma unroll
         for (int n = 0; n < 6; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float d = xv[n][r] - mu; s2 += d * d; }
-        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        s2 = rows_sum(s2);
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
         if (SAVE && gq == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
         bf16x4 p1[6];
@@ -268,13 +268,11 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             sc[r] = x;
             mx = fmaxf(mx, x);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sc[r] = __expf(sc[r] - mx); sum += sc[r]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         const bf16x4 pb = pack4(sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv);
         bf16x4 op[2];
@@ -316,14 +314,14 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             if constexpr (SAVE != 0) *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
             sum += (xv[n2][0] + xv[n2][1]) + (xv[n2][2] + xv[n2][3]);
         }
-        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float mu = sum * (1.0f / C);
         float s2 = 0.f;
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float d = xv[n2][r] - mu; s2 += d * d; }
-        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        s2 = rows_sum(s2);
         const float rs = rsqrtf(s2 * (1.0f / C) + a.eps);
         if (SAVE && gq == 0) { a.mean2[row] = mu; a.rstd2[row] = rs; }
         bf16x4 p2[6];
@@ -468,14 +466,18 @@ __device__ __forceinline__ void stage_store(const Staged<ROWS, COLS>& st, unsign
     }
 }
 // one halving step of the 16-lane reduce-scatter: after the steps with m = 8, 4, 2, 1 on 48 values, lane t holds the
-// sums over the 16 token lanes of values 3t .. 3t+2 in v[0..2]
+// sums over the 16 token lanes of values 3t .. 3t+2 in v[0..2].  The partner of a step only has to sit in the other half of
+// the 2m-lane group (each lane keeps the half its OWN bit m selects, so any perfect matching across the halves gives the
+// same sums): row_mirror / row_half_mirror / quad_perm are modifiers of a vector-ALU move, where lane ^ m through
+// __shfl_xor was a ds_bpermute round trip per value (45 per LayerNorm backward, two per block)
 template <int HALF, int M>
 __device__ __forceinline__ void halve(float (&v)[48], int t) {
     const bool up = (t & M) != 0;
+    constexpr int CTRL = M == 8 ? 0x140 : M == 4 ? 0x141 : M == 2 ? 0x4E : 0xB1;   // row_mirror, row_half_mirror, quad [2,3,0,1], [1,0,3,2]
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
         const float a = v[i], b = v[HALF + i];
-        v[i] = (up ? b : a) + __shfl_xor(up ? a : b, M, 64);
+        v[i] = (up ? b : a) + dpp_move<CTRL>(up ? a : b);
     }
 }
 // LayerNorm backward of one token row held as 6 x 4 channels (16n + 4gq + r): d <- rstd*(d*gamma - m1 - xhat*m2);
@@ -499,8 +501,8 @@ __device__ __forceinline__ void ln_bwd_row(f32x4 (&d)[6], const f32x4 (&xv)[6], 
             s2 += d[n][r] * xh[n][r];
         }
     }
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    s1 = rows_sum(s1);
+    s2 = rows_sum(s2);
     const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
 #pragma unroll
     for (int n = 0; n < 6; ++n)
@@ -792,13 +794,11 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             sq[r] = xq; sk[r] = xk;
             mx = fmaxf(mx, xq);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum += __expf(sq[r] - mx);
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float lse = mx + __logf(sum);
         float pq[4], pk[4], delta = 0.f;
 #pragma unroll
@@ -807,8 +807,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             pk[r] = __expf(sk[r] - __shfl(lse, gq * 4 + r, 64));
             delta += pq[r] * dpq[r];
         }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);
+        delta = rows_sum(delta);
         float dsq[4], dsk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -381,13 +381,11 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             sc[r] = x;
             mx = fmaxf(mx, x);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sc[r] = __expf(sc[r] - mx); sum += sc[r]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         const bf16x4 pb = pack4(sc[0] * inv, sc[1] * inv, sc[2] * inv, sc[3] * inv);
         bf16x4 opp[2];
@@ -429,14 +427,14 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                 sm += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
             }
             // statistics of this wave's 32 channels of token t: (mean, sum of squared deviations)
-            sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+            sm = rows_sum(sm);
             const float mw = sm * (1.0f / 32);
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float d = x1v[i][g][r] - mw; q += d * d; }
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            q = rows_sum(q);
             if (gq == 0) STAT[wid * T + 16 * g + t] = make_float2(mw, q);
         }
     }
@@ -642,8 +640,8 @@ __device__ __forceinline__ void ln_bwd_part1(f32x4 (&d)[2][G], f32x4 (&xh)[2][G]
                 s2 += d[i][g][r] * xh[i][g][r];
             }
         }
-        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        s1 = rows_sum(s1);
+        s2 = rows_sum(s2);
         if (gq == 0) STAT[wid * T + 16 * g + t] = make_float2(s1, s2);
     }
 #pragma unroll
@@ -889,13 +887,11 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 sq[r] = xq; sk[r] = xk;
                 mx = fmaxf(mx, xq);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = rows_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum += __expf(sq[r] - mx);
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = rows_sum(sum);
             const float lse = mx + __logf(sum);
             float pq[4], pk[4], delta = 0.f;
 #pragma unroll
@@ -904,8 +900,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 pk[r] = __expf(sk[r] - __shfl(lse, gq * 4 + r, 64));
                 delta += pq[r] * dpq[r];
             }
-            delta += __shfl_xor(delta, 16, 64);
-            delta += __shfl_xor(delta, 32, 64);
+            delta = rows_sum(delta);
             float dsq[4], dsk[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

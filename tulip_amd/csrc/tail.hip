@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_ln_kernel(const TailNorm nrm,
             v[ks][4] = b.x; v[ks][5] = b.y; v[ks][6] = b.z; v[ks][7] = b.w;
             sm += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
         }
-        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+        sm = rows_sum(sm);
         const float mu = sm * invE;
         float q = 0.f;
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_ln_kernel(const TailNorm nrm,
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mu; q += d * d; }
             }
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        q = rows_sum(q);
         const float rs = rsqrtf(q * invE + nrm.eps);
         if (wid == 0 && gq == 0 && valid) { nrm.mean[tok] = mu; nrm.rstd[tok] = rs; }
 #pragma unroll
@@ -713,8 +713,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && NC <= 2 ? 2 : 1)) void tail_
             *(float4*)(ow + (size_t)oc * E + 16 * n + 4 * gq) =
                 make_float4(wc * acc[cc][n][0], wc * acc[cc][n][1], wc * acc[cc][n][2], wc * acc[cc][n][3]);
         float b = wc * bsum[cc];
-        b += __shfl_xor(b, 16, 64);
-        b += __shfl_xor(b, 32, 64);
+        b = rows_sum(b);
         if (gq == 0) ob_[oc] = b;
     }
 }
