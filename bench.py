@@ -516,8 +516,10 @@ def reference_loop(args, device, steps=20, warmup=5):
     """The reference's OWN calling convention on the drop-in module, unchanged (engine_upsampling.py:69-100,
     util/misc.py:292-305, main_lidar_upsampling.py:282-283): torch.autocast around model(lo, hi), GradScaler
     scale -> backward -> unscale_ -> step -> update, torch.optim.AdamW(betas=(0.9, 0.95)) over timm-style decay groups,
-    the per-iteration loss read-back and torch.cuda.synchronize().  Eager launches through the autograd bridge: what a
-    user gets with zero edits, next to the fused Trainer step of the headline."""
+    the per-iteration loss read-back and torch.cuda.synchronize().  The module's forward and backward are one HIP-graph replay
+    each behind the autograd bridge (TulipEngine._module_sequence; first call eager, second captures); optimizer, scaler and
+    the three host synchronisations per step are PyTorch's own: what a user gets with zero edits, next to the fused
+    Trainer step of the headline (host + device timeline of one step: profiles/r4_refloop_timeline.txt)."""
     model = make_model(args).to(device).train()
     decay = [p for p in model.parameters() if p.ndim > 1]
     no_decay = [p for p in model.parameters() if p.ndim <= 1]

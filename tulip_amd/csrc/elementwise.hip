@@ -111,17 +111,29 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
     const int ct = threadIdx.x & (CT - 1), rl = threadIdx.x >> (31 - __builtin_clz(CT));
     const int64_t col = (int64_t)(blockIdx.x - r.first_block) * CT + ct;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the optimizer state of a region whose sum IS the gradient: fetched beside the partial rows, not behind them (round 4: a fold
+    // launch was five or six dependent memory round trips -- 4 rows at a time, then parameter + moments -- for 17 MB: ~20 us)
+    const bool stepper = r.adam && rl == 0 && col < r.n4 && !r.scatter;
+    float4 pp, mm, vv;
+    size_t aidx = 0;
+    if (stepper) {
+        const AdamRef& ad = R.ad;
+        aidx = (size_t)((r.out + col * 4) - ad.g0);
+        pp = *(const float4*)(ad.p0 + aidx); mm = *(const float4*)(ad.m0 + aidx); vv = *(const float4*)(ad.v0 + aidx);
+    }
     if (col < r.n4) {
         const float* base = r.part + col * 4;
-        for (int s = rl; s < S; s += RL * 4) {
-            float4 v[4];
+        // 16 rows in flight per trip (a split-K fold of up to 16 slabs, or 16 x RL partial rows, is ONE round trip); summed in row order
+        for (int s = rl; s < S; s += RL * 16) {
+            float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int ss = s + u * RL;
-                v[u] = ss < S ? *(const float4*)(base + (int64_t)ss * r.stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = *(const float4*)(base + (int64_t)(ss < S ? ss : rl) * r.stride);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            for (int u = 0; u < 16; ++u)
+                if (s + u * RL < S) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     }
     if (RL > 1) {                                   // block-uniform
@@ -173,9 +185,8 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
             o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
             if (r.adam) {                               // block-uniform
                 const AdamRef& ad = R.ad;
-                const size_t idx = (size_t)((r.out + col * 4) - ad.g0);
+                const size_t idx = aidx;
                 const bool decay = ad.mask64 ? (ad.mask64[idx >> 6] & 1u) != 0 : true;
-                float4 pp = *(const float4*)(ad.p0 + idx), mm = *(const float4*)(ad.m0 + idx), vv = *(const float4*)(ad.v0 + idx);
                 adamw_step4(pp, mm, vv, o, adamw_coef(ad.hyper, decay));
                 *(float4*)(ad.p0 + idx) = pp; *(float4*)(ad.m0 + idx) = mm; *(float4*)(ad.v0 + idx) = vv;
                 *(uint2*)(ad.pb0 + idx) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));

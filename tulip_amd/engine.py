@@ -148,10 +148,28 @@ class FlatParams:
         return self.base16 + 2 * self.offset[name]
 
     def still_bound(self, model) -> bool:
-        for n, p in model.named_parameters():
-            if p.data_ptr() != self.base32 + 4 * self.offset[n]:
-                return False
-        return True
+        return self.current_params(model) is not None
+
+    def current_params(self, model):
+        """The module's parameters in flat-buffer order, or None if one of them no longer lives in the flat buffer (replaced, or
+        its storage re-created).  Called once per module forward (the reference's calling convention), so it reads the owning
+        sub-modules' `_parameters` dicts directly: three `named_parameters()` traversals per call were ~0.45 ms of host time
+        in front of a 0.8-ms forward (tools/refloop_timeline.py)."""
+        slots = getattr(self, "_slots", None)
+        if slots is None or self._slots_model is not model:
+            mods = dict(model.named_modules())
+            slots = []
+            for n in self.names:
+                mn, _, pn = n.rpartition(".")
+                slots.append((mods[mn]._parameters, pn, self.base32 + 4 * self.offset[n]))
+            self._slots, self._slots_model = slots, model
+        out = []
+        for d, k, ptr in slots:
+            p = d.get(k)
+            if p is None or p.data_ptr() != ptr:
+                return None
+            out.append(p)
+        return out
 
     def refresh_shadow(self):
         ops.cast_flat(self.flat, self.shadow, self.total)
@@ -383,8 +401,11 @@ class TulipEngine:
 
     def bind(self, device):
         """(Re-)flatten the parameters on `device` if the module's storage moved."""
-        if self.params is not None and self.device == device and self.params.still_bound(self.model):
-            return
+        self._cur_params = None
+        if self.params is not None and self.device == device:
+            self._cur_params = self.params.current_params(self.model)
+            if self._cur_params is not None:
+                return
         self.device = device
         self.plans.clear()
         self._graphs.clear()
@@ -1569,13 +1590,13 @@ class TulipEngine:
             self.run_forward(P, with_loss=False)
             return P.pred.clone()
         P.target.copy_(target.reshape(P.target.shape).float())
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
+        params = self._cur_params if self._cur_params is not None else self.params.current_params(self.model)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if not need_grad:
             self.draw_drop_scales(P, self.model.training)
             self.run_forward(P)
             return P.pred.clone(), P.losses[0].clone(), P.losses[1].clone()
-        params = [p for _, p in sorted(self.model.named_parameters(), key=lambda kv: self.params.offset[kv[0]])]
-        return _TulipFn.apply(self, P, *params)
+        return _TulipFn.apply(self, P, *params)            # (flat-buffer order: _TulipFn.backward returns the gradients in it)
 
 
 class _TulipFn(torch.autograd.Function):
