@@ -120,11 +120,31 @@ __device__ __forceinline__ bf16x8 mfma_operand_fence(bf16x8 v) {
     return __builtin_bit_cast(bf16x8, t);
 }
 
+// A store whose data nobody reads before this launch ends (the activations a fused block saves for its backward, the
+// operands it leaves for the weight-gradient launches): TULIP_STORE_LATE selects the cache policy of those stores --
+// 0 plain, 1 non-temporal (global_store ... nt).  Plain stores stay dirty in the XCD's L2 until the end-of-kernel
+// write-back (guide row `boundary`: + dirty bytes / 6 TB/s behind the launch).
+#ifndef TULIP_STORE_LATE
+#define TULIP_STORE_LATE 0
+#endif
+template <class V>
+__device__ __forceinline__ void store_late(V* p, V v) {
+#if TULIP_STORE_LATE == 1
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_late(float4* p, float4 v) {
+    store_late((f32x4*)p, (f32x4){v.x, v.y, v.z, v.w});
+}
+
 // Two adjacent 16-column tiles of one output row in the MFMA accumulator layout -- lane (t, gq) holds 4 bf16 of tile A at
 // columns 4 gq and 4 bf16 of tile B at columns 16 + 4 gq -- leave as ONE 16-byte store per lane instead of two 8-byte
 // ones: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other, after which an
 // even-gq lane holds columns [4 gq, 4 gq + 8) of tile A and an odd-gq lane columns [4 (gq - 1), + 8) of tile B.  The
 // fused block kernels are store-ISSUE bound in their write-outs: same bytes, same addresses, half the instructions.
+template <bool LATE = false>
 __device__ __forceinline__ void store_bf16_tile_pair(bf16_t* rowp, bf16x4 A, bf16x4 B, int gq) {
     typedef uint32_t u32x2_c __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x4_c2 __attribute__((ext_vector_type(4)));
@@ -132,7 +152,8 @@ __device__ __forceinline__ void store_bf16_tile_pair(bf16_t* rowp, bf16x4 A, bf1
     const auto r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
     const auto r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
     const int col = (gq & 1) ? 16 + 4 * (gq - 1) : 4 * gq;
-    *(u32x4_c2*)(rowp + col) = (u32x4_c2){r0[0], r1[0], r0[1], r1[1]};
+    if constexpr (LATE) store_late((u32x4_c2*)(rowp + col), (u32x4_c2){r0[0], r1[0], r0[1], r1[1]});
+    else *(u32x4_c2*)(rowp + col) = (u32x4_c2){r0[0], r1[0], r0[1], r1[1]};
 }
 
 // ---- fp8 (OCP e4m3, the gfx950 format) for the optional fp8 attention scores (BASELINE configs[4]) ------------------

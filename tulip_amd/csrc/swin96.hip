@@ -11,6 +11,10 @@
 // staged in LDS (W2 | {Wqkv,Wproj} then W1 in the same region, plus the bias / norm2 vectors: 163.7 of 163.8 KB).
 // Everything the backward needs (xn1, qkv, o, x1, xn2, h, g, the LayerNorm statistics) is written exactly as the
 // separate kernels write it, so the backward is unchanged.
+#ifndef TULIP_STORE_LATE_96
+#define TULIP_STORE_LATE_96 0          // plain stores measured faster here (see swinw.hip)
+#endif
+#define TULIP_STORE_LATE TULIP_STORE_LATE_96
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         ln_apply(xv, mu, rs, a.g1, a.be1, gq, p1);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if constexpr (SAVE != 0) store_bf16_tile_pair(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
+            if constexpr (SAVE != 0) store_bf16_tile_pair<true>(a.xn1 + row * C + 32 * s, p1[2 * s], p1[2 * s + 1], gq);
             xfrag[s] = cat8(p1[2 * s], p1[2 * s + 1]);   // k order within 32s: 4gq.., 16+4gq..
         }
     }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(wr, 32 * s + 4 * gq), xfrag[s], acc, 0, 0, 0);
         const float4 bq = *(const float4*)(prm + P_BQKV + 16 * j + 4 * gq);
         qkvp[j] = pack4(acc[0] + bq.x, acc[1] + bq.y, acc[2] + bq.z, acc[3] + bq.w);
-        if (SAVE >= 2 && (j & 1)) store_bf16_tile_pair(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
+        if (SAVE >= 2 && (j & 1)) store_bf16_tile_pair<true>(a.qkv + row * 288 + 16 * (j - 1), qkvp[j - 1], qkvp[j], gq);
     }
 
     // fc1.weight rows 0..287 replace qkv.weight in LDS once every wave is through the qkv GEMM: fetched now, written
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb, o, 0, 0, 0);   // o[r] = O[t][16dc + 4gq + r]
             op[dc] = pack4(o[0], o[1], o[2], o[3]);
         }
-        if constexpr (SAVE != 0) store_bf16_tile_pair(a.o + row * C + 32 * h, op[0], op[1], gq);
+        if constexpr (SAVE != 0) store_bf16_tile_pair<true>(a.o + row * C + 32 * h, op[0], op[1], gq);
         ofrag[h] = cat8(op[0], op[1]);                    // k order: d = 4gq+0..3, 16+4gq+0..3
     }
 
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
             const float4 bp = *(const float4*)(prm + P_BPROJ + c0);
             xv[n2] = (f32x4){xv[n2][0] + s0 * (acc[0] + bp.x), xv[n2][1] + s0 * (acc[1] + bp.y),
                              xv[n2][2] + s0 * (acc[2] + bp.z), xv[n2][3] + s0 * (acc[3] + bp.w)};
-            if constexpr (SAVE != 0) *(float4*)(a.x1 + row * C + c0) = make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]);
+            if constexpr (SAVE != 0) store_late((float4*)(a.x1 + row * C + c0), make_float4(xv[n2][0], xv[n2][1], xv[n2][2], xv[n2][3]));
             sum += (xv[n2][0] + xv[n2][1]) + (xv[n2][2] + xv[n2][3]);
         }
         sum = rows_sum(sum);
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
         ln_apply(xv, mu, rs, prm + P_G2, prm + P_BE2, gq, p2);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if constexpr (SAVE != 0) store_bf16_tile_pair(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
+            if constexpr (SAVE != 0) store_bf16_tile_pair<true>(a.xn2 + row * C + 32 * s, p2[2 * s], p2[2 * s + 1], gq);
             x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
         }
     }
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
                 gp[jj] = pack4(g01.x, g01.y, g23.x, g23.y);
             }
         }
-        if constexpr (SAVE >= 2) store_bf16_tile_pair(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
-        if constexpr (SAVE != 0) store_bf16_tile_pair(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
+        if constexpr (SAVE >= 2) store_bf16_tile_pair<true>(a.h + row * HID + 32 * p, hq[0], hq[1], gq);       // 16-byte stores (common.h)
+        if constexpr (SAVE != 0) store_bf16_tile_pair<true>(a.g + row * HID + 32 * p, gp[0], gp[1], gq);
         const bf16x8 gf = cat8(gp[0], gp[1]);
 #pragma unroll
         for (int n2 = 0; n2 < 6; ++n2)
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            store_bf16_tile_pair(a.dyb_m + row * C + 32 * s, pk[2 * s], pk[2 * s + 1], gq);
+            store_bf16_tile_pair<true>(a.dyb_m + row * C + 32 * s, pk[2 * s], pk[2 * s + 1], gq);
             dyf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
         }
     }
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
             if constexpr (!HGRAD || RECOMP) { d01 = gelu_exact_grad2(d01); d23 = gelu_exact_grad2(d23); }
             dp[jj] = pack4(acc[0] * d01.x, acc[1] * d01.y, acc[2] * d23.x, acc[3] * d23.y);
         }
-        store_bf16_tile_pair(a.dh + row * HID + 32 * p, dp[0], dp[1], gq);
+        store_bf16_tile_pair<true>(a.dh + row * HID + 32 * p, dp[0], dp[1], gq);
         const bf16x8 df = cat8(dp[0], dp[1]);
 #pragma unroll
         for (int n = 0; n < 6; ++n)
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            store_bf16_tile_pair(a.dyb_a + row * C + 32 * s, pk[2 * s], pk[2 * s + 1], gq);
+            store_bf16_tile_pair<true>(a.dyb_a + row * C + 32 * s, pk[2 * s], pk[2 * s + 1], gq);
             daf[s] = cat8(pk[2 * s], pk[2 * s + 1]);
         }
     }
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     }
     TULIP_STAMP(9);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) store_bf16_tile_pair(a.dqkv + row * 288 + 32 * j, dqkvp[2 * j], dqkvp[2 * j + 1], gq);
+    for (int j = 0; j < 9; ++j) store_bf16_tile_pair<true>(a.dqkv + row * 288 + 32 * j, dqkvp[2 * j], dqkvp[2 * j + 1], gq);
 
     // ---- qkv' : dxn1 = dqkv . Wqkv  (tulip.py:298 backwards), then norm1' and the residual
     f32x4 acc1[6], xv[6];

@@ -21,6 +21,13 @@
 // Per-channel parameter partial sums (LayerNorm affine, relative-position bias) are disjoint between waves, so each
 // wave writes its slice of the workgroup's partial row directly.
 #include <type_traits>
+// the activations saved for the backward / the operands left for the weight-gradient launches leave as non-temporal stores
+// (common.h, store_late): same-box A/B of the step 2.021 vs 2.035 ms at batch 8, 9.07 vs 9.13 at batch 64 (four pairs each;
+// isolated launches -1..-3 us).  The C = 96 kernels measured the other way (isolated forward 32.0 -> 35.4 us) and keep plain stores.
+#ifndef TULIP_STORE_LATE_W
+#define TULIP_STORE_LATE_W 1
+#endif
+#define TULIP_STORE_LATE TULIP_STORE_LATE_W
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -302,7 +309,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                     const int c = 4 * t + 64 * j;
                     const bf16x4 pk = pack4((xv[p][j].x - mu) * rs * ga[j].x + be[j].x, (xv[p][j].y - mu) * rs * ga[j].y + be[j].y,
                                             (xv[p][j].z - mu) * rs * ga[j].z + be[j].z, (xv[p][j].w - mu) * rs * ga[j].w + be[j].w);
-                    if constexpr (SAVE) *(bf16x4*)(a.xn1 + row * C + c) = pk;
+                    if constexpr (SAVE) store_late((bf16x4*)(a.xn1 + row * C + c), pk);
                     put4<T>(XN, tt, c, pk);
                 }
             }
@@ -346,7 +353,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             for (int g = 0; g < G; ++g) {
                 qkvp[i][g] = pack4(acc[i][g][0] + bqi[0], acc[i][g][1] + bqi[1], acc[i][g][2] + bqi[2], acc[i][g][3] + bqi[3]);
                 if (SAVE && (i & 1))      // two adjacent tiles: one 16-byte store per lane (common.h)
-                    store_bf16_tile_pair(a.qkv + rows[g] * (3 * C) + n - 16 - 4 * gq, qkvp[i - 1][g], qkvp[i][g], gq);
+                    store_bf16_tile_pair<true>(a.qkv + rows[g] * (3 * C) + n - 16 - 4 * gq, qkvp[i - 1][g], qkvp[i][g], gq);
             }
         }
     }
@@ -397,7 +404,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             opp[dc] = pack4(o[0], o[1], o[2], o[3]);
             put4<T>(XO, 16 * g + t, 32 * wid + 16 * dc + 4 * gq, opp[dc]);
         }
-        if constexpr (SAVE) store_bf16_tile_pair(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
+        if constexpr (SAVE) store_bf16_tile_pair<true>(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
     }
     TULIP_STAMP(5);
     __syncthreads();
@@ -423,7 +430,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             for (int i = 0; i < 2; ++i) {
                 const int c0 = 32 * wid + 16 * i + 4 * gq;
                 x1v[i][g] = x1v[i][g] + s0 * (acc[i][g] + bp[i]);
-                if constexpr (SAVE) *(float4*)(a.x1 + rows[g] * C + c0) = make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]);
+                if constexpr (SAVE) store_late((float4*)(a.x1 + rows[g] * C + c0), make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]));
                 sm += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
             }
             // statistics of this wave's 32 channels of token t: (mean, sum of squared deviations)
@@ -462,7 +469,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                            (x1v[i][g][2] - mu) * rs * ga2[i][2] + be2[i][2], (x1v[i][g][3] - mu) * rs * ga2[i][3] + be2[i][3]);
             put4<T>(XN, 16 * g + t, c0, pk2[i]);
         }
-        if constexpr (SAVE) store_bf16_tile_pair(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
+        if constexpr (SAVE) store_bf16_tile_pair<true>(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
     }
     f32x4 b1v[D == 2 ? 2 : 1][4];
     if constexpr (D == 2) {
@@ -507,8 +514,8 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                 if (i & 1) {    // two adjacent tiles: one 16-byte store per lane (common.h)
                     const size_t off = rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1);
                     if constexpr (SAVE) {
-                        store_bf16_tile_pair(a.h + off, hprev[g], hp, gq);
-                        store_bf16_tile_pair(a.g + off, gprev[g], gp, gq);
+                        store_bf16_tile_pair<true>(a.h + off, hprev[g], hp, gq);
+                        store_bf16_tile_pair<true>(a.g + off, gprev[g], gp, gq);
                     }
                 } else {
                     hprev[g] = hp; gprev[g] = gp;
@@ -721,7 +728,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 for (int j = 0; j < C / 64; ++j) {
                     const int c = 4 * t + 64 * j;
                     const bf16x4 pk = pack4(v[p][j].x * s1v, v[p][j].y * s1v, v[p][j].z * s1v, v[p][j].w * s1v);
-                    *(bf16x4*)(a.dyb_m + rowp[p] * C + c) = pk;
+                    store_late((bf16x4*)(a.dyb_m + rowp[p] * C + c), pk);
                     put4<T>(DY, tt, c, pk);
                 }
             }
@@ -758,7 +765,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 if constexpr (!HGRAD) { d01 = gelu_exact_grad2(d01); d23 = gelu_exact_grad2(d23); }    // HGRAD: the forward left gelu'(h) there
                 const bf16x4 dp = pack4(acc[i][g][0] * d01.x, acc[i][g][1] * d01.y, acc[i][g][2] * d23.x, acc[i][g][3] * d23.y);
                 put4<T>(DH, 16 * g + t, n, dp);
-                if (i & 1) store_bf16_tile_pair(a.dh + rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1), dprev[g], dp, gq);
+                if (i & 1) store_bf16_tile_pair<true>(a.dh + rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1), dprev[g], dp, gq);
                 else dprev[g] = dp;
             }
         }
@@ -827,7 +834,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             }
         }
 #pragma unroll
-        for (int g = 0; g < G; ++g) store_bf16_tile_pair(a.dyb_a + rows[g] * C + 32 * wid, pka[0][g], pka[1][g], gq);
+        for (int g = 0; g < G; ++g) store_bf16_tile_pair<true>(a.dyb_a + rows[g] * C + 32 * wid, pka[0][g], pka[1][g], gq);
     }
     __syncthreads();
 
@@ -927,7 +934,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 for (int sec = 0; sec < 3; ++sec) {
                     const int n = sec * C + 32 * wid + 16 * dc + 4 * gq;
                     put4<T>(DQ, 16 * g + t, n, o[sec]);
-                    if (dc) store_bf16_tile_pair(a.dqkv + rows[g] * (3 * C) + sec * C + 32 * wid, oprev[sec], o[sec], gq);
+                    if (dc) store_bf16_tile_pair<true>(a.dqkv + rows[g] * (3 * C) + sec * C + 32 * wid, oprev[sec], o[sec], gq);
                     else oprev[sec] = o[sec];
                 }
             }
