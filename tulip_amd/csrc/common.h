@@ -34,6 +34,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f,
 // per wave instruction, lane i lands at scratch + 16 i; nothing reads it, so every wave may share one KiB).
 // global_load_lds_dwordx4 via the compiler's builtin: no VGPR destination for the register allocator to move underneath an
 // in-flight load, and the compiler's own vmcnt accounting covers it.
+// The 4-byte form: every lane names its own address, lane i's word lands at scratch + 4 i (a 256-byte sink) -- one instruction
+// pulls up to 64 cache lines towards the XCD's L2 (the backward kernels' prefetch of the activations their forward saved).
+__device__ __forceinline__ void warm_touch4(const void* gptr, void* lds_scratch) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_scratch, 4, 0, 0);
+}
 __device__ __forceinline__ void warm_touch16(const void* gptr, void* lds_scratch) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_scratch, 16, 0, 0);
@@ -137,6 +143,58 @@ __device__ __forceinline__ void store_late(V* p, V v) {
 }
 __device__ __forceinline__ void store_late(float4* p, float4 v) {
     store_late((f32x4*)p, (f32x4){v.x, v.y, v.z, v.w});
+}
+
+// Optimizer state (parameter, moments, bf16 shadow) where the step is taken inside a weight-gradient write-out or a fold: every
+// element is read once and written once per step, 22 B per parameter.  TULIP_ADAM_NT = 1: non-temporal loads and stores (bit 0)
+// for it; bit 1: the split-K slabs / partial rows a fold reads (read once) as non-temporal loads.
+#ifndef TULIP_ADAM_NT
+#define TULIP_ADAM_NT 3          // same-box A/B of the step (profiles/r4_ab_nt_stores.txt): 0 -> 1: -14 us, 0 -> 3: -12 us at batch 8; batch 64 -0.2 % with 3
+#endif
+__device__ __forceinline__ float4 ld_state(const float* p) {
+#if TULIP_ADAM_NT & 1
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ void st_state(float* p, float4 v) {
+#if TULIP_ADAM_NT & 1
+    __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, (f32x4*)p);
+#else
+    *(float4*)p = v;
+#endif
+}
+__device__ __forceinline__ void st_state_bf16x4(bf16_t* p, uint2 v) {
+    typedef uint32_t u32x2_s __attribute__((ext_vector_type(2)));
+#if TULIP_ADAM_NT & 1
+    __builtin_nontemporal_store((u32x2_s){v.x, v.y}, (u32x2_s*)p);
+#else
+    *(uint2*)p = v;
+#endif
+}
+__device__ __forceinline__ float4 ld_partial(const float* p) {
+#if TULIP_ADAM_NT & 2
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *(const float4*)p;
+#endif
+}
+
+// A load of an activation the forward saved for this backward launch (read once, by one workgroup): TULIP_LOAD_SAVED_NT = 1
+// makes it non-temporal (the block's weights, which every workgroup streams from L2, are what should stay there).
+#ifndef TULIP_LOAD_SAVED_NT
+#define TULIP_LOAD_SAVED_NT 0
+#endif
+template <class V>
+__device__ __forceinline__ V ld_saved(const V* p) {
+#if TULIP_LOAD_SAVED_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
 }
 
 // Two adjacent 16-column tiles of one output row in the MFMA accumulator layout -- lane (t, gq) holds 4 bf16 of tile A at

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
     if (stepper) {
         const AdamRef& ad = R.ad;
         aidx = (size_t)((r.out + col * 4) - ad.g0);
-        pp = *(const float4*)(ad.p0 + aidx); mm = *(const float4*)(ad.m0 + aidx); vv = *(const float4*)(ad.v0 + aidx);
+        pp = ld_state(ad.p0 + aidx); mm = ld_state(ad.m0 + aidx); vv = ld_state(ad.v0 + aidx);
     }
     if (col < r.n4) {
         const float* base = r.part + col * 4;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int ss = s + u * RL;
-                v[u] = *(const float4*)(base + (int64_t)(ss < S ? ss : rl) * r.stride);
+                v[u] = ld_partial(base + (int64_t)(ss < S ? ss : rl) * r.stride);
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(const MultiRegio
                 const size_t idx = aidx;
                 const bool decay = ad.mask64 ? (ad.mask64[idx >> 6] & 1u) != 0 : true;
                 adamw_step4(pp, mm, vv, o, adamw_coef(ad.hyper, decay));
-                *(float4*)(ad.p0 + idx) = pp; *(float4*)(ad.m0 + idx) = mm; *(float4*)(ad.v0 + idx) = vv;
-                *(uint2*)(ad.pb0 + idx) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
+                st_state(ad.p0 + idx, pp); st_state(ad.m0 + idx, mm); st_state(ad.v0 + idx, vv);
+                st_state_bf16x4(ad.pb0 + idx, make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w)));
             } else {
                 *(float4*)(r.out + col * 4) = o;
             }

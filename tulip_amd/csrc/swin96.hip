@@ -415,6 +415,9 @@ constexpr int BOFF_T = BOFF_WPROJ + 96 * PT;     // NW x (Q | K | dO) 1-KiB tile
 constexpr int BOFF_RED = BOFF_T + NW * 3072;     // fp32 [NW][192] norm2 | [NW][192] norm1 | [NW][768] bias partial sums
 constexpr int BOFF_GAM = BOFF_W1 + 384 * PT;     // 162816: norm2.weight[96] norm1.weight[96] fp32 (beyond both layouts)
 constexpr int BSMEM = BOFF_GAM + 2 * C * 4;
+#ifndef TULIP_SWIN96_PREFETCH
+#define TULIP_SWIN96_PREFETCH 0         // measured: +6.5 us per launch warm, L2-cold and all-cold alike (profiles/README.md): off
+#endif
 constexpr int BOFF_BQKV = BOFF_RED + NW * (192 + 192 + 768) * 4;   // qkv.bias[288] fp32 (attention half, recomputation form)
 static_assert(BOFF_BQKV + 288 * 4 <= BOFF_GAM, "attention-half layout overlaps the norm weights");
 static_assert(BSMEM <= 163840, "LDS");
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
     f32x4 dy[6], x1v[6];
     int ridx_q[4], ridx_k[4];
     float mu2, rs2;
+    unsigned pf[5] = {0u, 0u, 0u, 0u, 0u};
     {
         Staged<C, HID> w2s; Staged<HID, C> w1s;
         stage_load<C, HID>(a.w2, w2s, tid);
@@ -578,6 +582,23 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int r = 0; r < 4; ++r) { ridx_q[r] = a.rel_index[t * 16 + gq * 4 + r]; ridx_k[r] = a.rel_index[(gq * 4 + r) * 16 + t]; }
         float gv = 0.f;
         if (tid < 2 * C) gv = tid < C ? a.g2[tid] : a.g1[tid - C];
+#if TULIP_SWIN96_PREFETCH
+        // In the training step everything the forward saved for this launch was written a millisecond and ~2 GB of traffic
+        // ago: every read of it is an HBM miss (isolated: 35 us warm, 54 us behind a 1-GB fill = the in-step figure), and the
+        // MLP loop below fetches its gelu'(h) fragments only one iteration (~1.3 k cycles) ahead.  The rows of this wave's 16
+        // tokens are touched here, behind the prologue's own loads: one 4-byte load per 128-byte line (6 lines of h, 4.5 of
+        // qkv, 3 of x per token, the norm1 statistics) into registers that are "used" at the barrier below.  (The same touches
+        // as LDS-destination loads -- no registers -- cost 6 us per launch: every LDS access behind them waits for vmcnt(0).)
+        if constexpr (!RECOMP) {
+            const unsigned char* hb = (const unsigned char*)(a.h + row * HID);
+            const unsigned char* qb = (const unsigned char*)(a.qkv + row * 288);
+            pf[0] = *(const unsigned*)(hb + 128 * gq);
+            pf[1] = *(const unsigned*)(hb + 512 + 128 * (gq & 1));
+            pf[2] = *(const unsigned*)(qb + 128 * gq);
+            pf[3] = *(const unsigned*)(gq < 2 ? qb + 512 + 60 * gq : (const unsigned char*)(gq == 2 ? a.mean1 + row : a.rstd1 + row));
+            pf[4] = *(const unsigned*)((const unsigned char*)(a.xin + row * C) + 128 * (gq < 2 ? gq : 2));
+        }
+#endif
         stage_store<C, HID, PT2>(w2s, smem + BOFF_W2, tid);
         stage_store<HID, C, PT>(w1s, smem + BOFF_W1, tid);
         if (tid < 2 * C) gam[tid] = gv;
@@ -617,6 +638,9 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
         for (int s = 0; s < 3; ++s) x2frag[s] = cat8(p2[2 * s], p2[2 * s + 1]);
     }
     TULIP_STAMP(1);
+#if TULIP_SWIN96_PREFETCH
+    asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]));
+#endif
     __syncthreads();
     TULIP_STAMP(2);
 

@@ -28,6 +28,9 @@
 #define TULIP_STORE_LATE_W 1
 #endif
 #define TULIP_STORE_LATE TULIP_STORE_LATE_W
+#ifdef TULIP_LOAD_SAVED_NT_W
+#define TULIP_LOAD_SAVED_NT TULIP_LOAD_SAVED_NT_W
+#endif
 #include "common.h"
 #include "tulip_hip.h"
 
@@ -774,7 +777,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int g = 0; g < G; ++g) hv[i][g] = *(const bf16x4*)(a.h + rows[g] * HID + 128 * wid + 64 * ch + 16 * i + 4 * gq);
+            for (int g = 0; g < G; ++g) hv[i][g] = ld_saved((const bf16x4*)(a.h + rows[g] * HID + 128 * wid + 64 * ch + 16 * i + 4 * gq));
     };
     {
         // (the activation loads stay BEHIND the GEMM they follow: vmcnt retires in order, so a strided HBM load issued
@@ -812,7 +815,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             gam[i] = ld4(a.g2 + 32 * wid + 16 * i + 4 * gq);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                xv[i][g] = ld4(a.x1 + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
+                xv[i][g] = ld_saved((const f32x4*)(a.x1 + rows[g] * C + 32 * wid + 16 * i + 4 * gq));
                 dyv[i][g] = ld4(a.dx + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
             }
         }
@@ -859,7 +862,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            qkvr[i][g] = *(const bf16x4*)(a.qkv + rows[g] * (3 * C) + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq);
+            qkvr[i][g] = ld_saved((const bf16x4*)(a.qkv + rows[g] * (3 * C) + (i >> 1) * C + 32 * wid + 16 * (i & 1) + 4 * gq));
     // ---- attention' of this head, one window at a time (tulip.py:300-317 backwards; algebra of attn_bwd_kernel)
     {
         unsigned char* ldsQ = smem + Z::OFF_ATT + wid * 3072;
@@ -954,7 +957,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         for (int i = 0; i < 2; ++i) {
             gam[i] = ld4(a.g1 + 32 * wid + 16 * i + 4 * gq);
 #pragma unroll
-            for (int g = 0; g < G; ++g) xv[i][g] = ld4(a.xin + rows[g] * C + 32 * wid + 16 * i + 4 * gq);
+            for (int g = 0; g < G; ++g) xv[i][g] = ld_saved((const f32x4*)(a.xin + rows[g] * C + 32 * wid + 16 * i + 4 * gq));
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) { mu[g] = a.mean1[rows[g]]; rs[g] = a.rstd1[rows[g]]; }
@@ -1020,6 +1023,18 @@ struct TrList { TrItem it[TULIP_PACK_MAX]; int n; };
 __device__ __forceinline__ size_t packed_offset(int n, int k, int K) {      // element (n, k) of a [N][K] matrix
     return ((size_t)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + ((n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
 }
+#ifndef TULIP_PACK_LOAD_NT
+#define TULIP_PACK_LOAD_NT 0
+#endif
+__device__ __forceinline__ uint4 pack_src(const uint4* p) {
+#if TULIP_PACK_LOAD_NT
+    typedef unsigned u32x4_p __attribute__((ext_vector_type(4)));
+    const u32x4_p v = __builtin_nontemporal_load((const u32x4_p*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *p;
+#endif
+}
 __global__ __launch_bounds__(256) void pack_multi_kernel(const TrList L) {
     __shared__ bf16_t tile[64][66];
     int i = 0;
@@ -1031,14 +1046,14 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const TrList L) {
         for (int e = threadIdx.x; e < 64 * 8; e += 256) {
             const int r = r0 + (e >> 3), c8 = c0 + (e & 7) * 8;
             if (r < m.rows && c8 < m.cols)
-                *(uint4*)(m.dst + packed_offset(r, c8, m.cols)) = *(const uint4*)(m.src + (size_t)r * m.cols + c8);
+                *(uint4*)(m.dst + packed_offset(r, c8, m.cols)) = pack_src((const uint4*)(m.src + (size_t)r * m.cols + c8));
         }
         return;
     }
     for (int e = threadIdx.x; e < 64 * 8; e += 256) {
         const int r = e >> 3, c8 = (e & 7) * 8;
         if (r0 + r < m.rows && c0 + c8 < m.cols) {
-            const uint4 v = *(const uint4*)(m.src + (size_t)(r0 + r) * m.cols + c0 + c8);
+            const uint4 v = pack_src((const uint4*)(m.src + (size_t)(r0 + r) * m.cols + c0 + c8));
             const bf16_t* pv = (const bf16_t*)&v;
 #pragma unroll
             for (int k = 0; k < 8; ++k) tile[r][c8 + k] = pv[k];
