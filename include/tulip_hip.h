@@ -492,6 +492,17 @@ int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hip
  * phase boundary k of every wave (waves = C/32; workgroups = tulip_swinw_bwd_partial_rows); tools/swinw_phases.py */
 int tulip_swinw_block_fwd_profiled(const tulip_swin96_desc* d, int C, void* out_bf16, uint64_t* stamps,
                                    hipStream_t stream);
+/* Split form of the forward (round 4; C = 384 where a workgroup owns ONE window, i.e. few windows: batch 8 at stage 2 is 128
+ * workgroups on 256 CUs, each streaming the block's 3.5 MB of weights): two workgroups per window.  Both run the attention
+ * half, each takes half of the MLP's hidden channels; the two fc2 partial sums meet in `exchange` (tulip_swinw_split_bytes
+ * bytes, 16-byte aligned, zero before the first launch, left zeroed; its last 4 bytes per window are arrival tickets): the
+ * last-arriving workgroup of a pair adds its partner's partial and writes the block output, nobody waits.  Same arguments,
+ * tensors and results (the fc2 sum is formed as two halves: last-bit differences) as tulip_swinw_block_fwd in its training
+ * form with TULIP_BLOCK_FC1_GRAD or in its inference form; stamps optional (the profiled twin).  tulip_swinw_split_bytes returns 0 where the form
+ * does not exist (then call tulip_swinw_block_fwd). */
+int tulip_swinw_split_bytes(int C, int B, int H, int W);
+int tulip_swinw_block_fwd_split(const tulip_swin96_desc* d, int C, void* out_bf16, void* exchange, size_t exchange_bytes,
+                                uint64_t* stamps, hipStream_t stream);
 int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W);
 /* Launches of at most 256 workgroups (the whole grid resident at once) start by spreading the block's weights over the
  * L2 of each XCD (every wave touches a few KiB nobody else touches): in a training step the weights are cold, and the
@@ -503,6 +514,11 @@ int tulip_swinw_set_warm(int on);
  * bit-compare test only; results are identical either way).  Process-wide. */
 int tulip_gemm_set_touch(int on);
 int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream);
+/* split form of the backward (see tulip_swinw_block_fwd_split; the same exchange buffer may serve both directions of a block):
+ * the MLP half's hidden channels are halved between the two workgroups of a window, the partial sums of d(norm2 output) meet in
+ * `exchange`, the last arriver runs norm2' .. norm1' alone.  Needs TULIP_BLOCK_FC1_GRAD in d->masked.  Partial rows: one per
+ * WINDOW, tulip_swinw_bwd_partial_rows as for tulip_swinw_block_bwd. */
+int tulip_swinw_block_bwd_split(const tulip_swin96_bwd_desc* d, int C, void* exchange, size_t exchange_bytes, hipStream_t stream);
 int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream);
 
 /* library self-description */

@@ -50,6 +50,9 @@ def test_pure_host_entry_points():
     assert lib.tulip_layernorm_bwd_partial_rows(64, 1536) == 16
     assert lib.tulip_layernorm_bwd_partial_rows(16, 6144) == 0
     assert lib.tulip_patch_embed_bwd_blocks(32768) == 512
+    # the split form of the fused C = 384 block exists where a workgroup owns one window: 2 x 2 x 768 lanes x 16 B + a ticket per window
+    assert lib.tulip_swinw_split_bytes(384, 8, 4, 64) == 128 * (2 * 2 * 768 * 16 + 4)
+    assert lib.tulip_swinw_split_bytes(384, 16, 4, 64) == 0 and lib.tulip_swinw_split_bytes(192, 8, 8, 128) == 0
     r = lib.tulip_window_attn_bwd_partial_rows(8, 16, 256, 3, 2, 8)
     assert 1 <= r <= 2048 // 3 + 1
 

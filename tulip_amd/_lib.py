@@ -74,10 +74,13 @@ SIGNATURES = {
     "tulip_swinw_supported": [I, I, I],
     "tulip_swinw_block_fwd": [P, I, P, P],
     "tulip_swinw_block_fwd_profiled": [P, I, P, P, P],
+    "tulip_swinw_split_bytes": [I, I, I, I],
+    "tulip_swinw_block_fwd_split": [P, I, P, P, ctypes.c_size_t, P, P],
     "tulip_swinw_bwd_partial_rows": [I, I, I, I],
     "tulip_swinw_set_warm": [I],
     "tulip_gemm_set_touch": [I],
     "tulip_swinw_block_bwd": [P, I, P],
+    "tulip_swinw_block_bwd_split": [P, I, P, ctypes.c_size_t, P],
     "tulip_pack_bf16_multi": [P, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],

@@ -26,6 +26,9 @@
 #include "common.h"
 #include "tulip_hip.h"
 
+#ifndef TULIP_GEMM_FAST_SHUF
+#define TULIP_GEMM_FAST_SHUF 1
+#endif
 namespace {
 
 constexpr int BN = 96;
@@ -417,6 +420,58 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
         __syncthreads();
+        if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_PIXSHUF2_F32 && (p.N & 31) == 0) {                        // (uniform)
+            // PixelShuffle(2) write-out, vectorised: an item is (row, sub-position q = 2i + j, 8 output channels) -- its eight values
+            // sit 16 B apart in the staged row (columns 4c + q) and leave as ONE 16-byte bf16 store (+ two fp32 ones) into the fine
+            // token (2h + i, 2w + j); epilogue8's form of it is eight scattered 2-byte stores per thread
+#pragma unroll
+            for (int it = 0; it < (64 * (BN / 8)) / 256; ++it) {
+                const int c = tid + it * 256;
+                const int rl = c / (BN / 8), c8 = c - rl * (BN / 8);
+                const int q = c8 & 3, cg = c8 >> 2;
+                const int m = m0 + ps * 64 + rl, nb = n0 + cg * 32;
+                if (m < p.M && nb < p.N) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = *(const float*)(smem + rl * STG_PITCH + (cg * 32 + 4 * k + q) * 4);
+                    if (p.bias) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += p.bias[nb + 4 * k + q];
+                    }
+                    const int t = fast_div(m, p.psW), w = m - t * p.psW;
+                    const int b = fast_div(t, p.psH), h = t - b * p.psH;
+                    const size_t tok = ((size_t)b * 2 * p.psH + 2 * h + (q >> 1)) * (2 * p.psW) + 2 * w + (q & 1);
+                    const int cb = nb >> 2;
+                    if (p.out) {
+                        float* o = (float*)p.out + tok * (p.N >> 2) + cb;
+                        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    if (p.out2) *(uint4*)((bf16_t*)p.out2 + tok * p.ldo2 + cb) = pack8(v);
+                }
+            }
+        } else if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_UNSHUF2_BF16 && !p.bias && (p.M & 1) == 0) {     // (uniform)
+            // inverse shuffle: fine tokens 2w, 2w + 1 of one row (staged rows rl, rl + 1) are neighbours in the coarse token's
+            // channel quadruple -- an item is (row pair, 8 columns): eight 4-byte stores instead of sixteen 2-byte ones
+#pragma unroll
+            for (int it = 0; it < (32 * (BN / 8) + 255) / 256; ++it) {
+                const int c = tid + it * 256;
+                const int rp = c / (BN / 8), c8 = c - rp * (BN / 8);
+                const int rl = 2 * rp, m = m0 + ps * 64 + rl, n = n0 + c8 * 8;
+                if (rp < 32 && m < p.M && n < p.N) {
+                    const float4 a0 = *(const float4*)(smem + rl * STG_PITCH + c8 * 32), a1 = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
+                    const float4 b0 = *(const float4*)(smem + (rl + 1) * STG_PITCH + c8 * 32), b1 = *(const float4*)(smem + (rl + 1) * STG_PITCH + c8 * 32 + 16);
+                    const int W2 = 2 * p.psW, H2 = 2 * p.psH;
+                    const int t = fast_div(m, W2), wf = m - t * W2;
+                    const int b = fast_div(t, H2), hf = t - b * H2;
+                    bf16_t* o = (bf16_t*)p.out + (((size_t)b * p.psH + (hf >> 1)) * p.psW + (wf >> 1)) * p.ldo + 2 * (hf & 1);
+                    const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) *(uint32_t*)(o + 4 * (n + r)) = pack_bf16x2(va[r], vb[r]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < (64 * (BN / 8)) / 256; ++it) {
             const int c = tid + it * 256;
@@ -427,6 +482,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                 const float4 hi = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
                 epilogue8(p, m, n, lo, hi, bz);
             }
+        }
         }
         if (ps + 1 < NPASS) __syncthreads();
     }

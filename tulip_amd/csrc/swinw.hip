@@ -190,6 +190,8 @@ struct SwinWArgs {
     unsigned long long* prof;             // optional: s_memtime stamps [workgroup][wave][16] at the phase boundaries
     int B, H, W, sh, sw, masked;
     float eps, scale;
+    // split form (two workgroups per window, MODE bit 4): fc2 partial sums [window][half][thread][2] f32x4, arrival tickets [window]
+    float* xws; unsigned* tick; unsigned xws_bytes;
 };
 #define TULIP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -230,9 +232,8 @@ struct TokMap {
     }
 };
 template <int G>
-__device__ __forceinline__ TokMap make_map(int B, int H, int W, int sh, int sw) {
+__device__ __forceinline__ TokMap make_map(int B, int H, int W, int sh, int sw, int blk = (int)blockIdx.x) {
     const int nWx = W >> 3, nWy = H >> 1, gpr = nWx / G;
-    int blk = blockIdx.x;
     TokMap m;
     m.b = blk / (nWy * gpr);
     blk -= m.b * nWy * gpr;
@@ -249,6 +250,16 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     constexpr int WARM = MODE & 3;
     constexpr bool SAVE = !(MODE & 4);
     constexpr bool HGRAD = (MODE & 8) != 0;     // round 4 (TULIP_BLOCK_FC1_GRAD): the fc1_pre buffer receives bf16(gelu'(h)) instead of h
+    // SPLIT (round 4, C = 384 with one window per workgroup: 128 workgroups on 256 CUs at batch 8, each streaming the block's
+    // 3.5 MB of weights at the per-CU L1 rate): TWO workgroups per window.  Both run the attention half (norm1 .. norm2: a third
+    // of the stream) redundantly -- workgroup 0 of the pair writes what it saves -- and each takes HALF of the hidden channels of
+    // the MLP: fc1 / GELU for 768 of them, fc2 over that half of its k range.  The two fc2 partial sums meet through memory:
+    // each workgroup publishes its 16 x 384 fp32 partial (write-through stores, drained; guide recipe R1 in its ticket form),
+    // draws a ticket, and the LAST arriver adds its partner's partial to its own, applies bias / DropPath / residual and
+    // writes the block output; the first arriver just leaves.  No workgroup ever waits for another.  a + b == b + a: the
+    // output does not depend on the order of arrival.
+    constexpr bool SPLIT = (MODE & 16) != 0;
+    static_assert(!SPLIT || (C == 384 && G == 1 && (HGRAD || !SAVE)), "split form: C = 384, one window per workgroup pair");
     using Z = Geo<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
@@ -258,7 +269,9 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     float2* const STAT = (float2*)(smem + Z::OFF_STAT);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
     unsigned char* const ldsV = smem + Z::OFF_V + wid * 1024;
-    const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw);
+    const int half = SPLIT ? (int)(blockIdx.x & 1) : 0, wblk = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const bool sv = SAVE && (!SPLIT || half == 0);          // the tensors both workgroups of a pair hold: saved by the first
+    const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw, wblk);
     const float s0 = a.ds0 ? a.ds0[tm.b] : 1.0f, s1v = a.ds1 ? a.ds1[tm.b] : 1.0f;
 
     // loads in flight per wave: 12 with 6 waves per CU, 6-8 with 12 waves or 4 windows (register budget 168 / 256)
@@ -306,13 +319,13 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                     q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 }
                 const float rs = rsqrtf(group_sum<16>(q) * (1.0f / C) + a.eps);
-                if (SAVE && t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
+                if (sv && t == 0) { a.mean1[row] = mu; a.rstd1[row] = rs; }
 #pragma unroll
                 for (int j = 0; j < C / 64; ++j) {
                     const int c = 4 * t + 64 * j;
                     const bf16x4 pk = pack4((xv[p][j].x - mu) * rs * ga[j].x + be[j].x, (xv[p][j].y - mu) * rs * ga[j].y + be[j].y,
                                             (xv[p][j].z - mu) * rs * ga[j].z + be[j].z, (xv[p][j].w - mu) * rs * ga[j].w + be[j].w);
-                    if constexpr (SAVE) store_late((bf16x4*)(a.xn1 + row * C + c), pk);
+                    if (sv) store_late((bf16x4*)(a.xn1 + row * C + c), pk);
                     put4<T>(XN, tt, c, pk);
                 }
             }
@@ -355,7 +368,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 qkvp[i][g] = pack4(acc[i][g][0] + bqi[0], acc[i][g][1] + bqi[1], acc[i][g][2] + bqi[2], acc[i][g][3] + bqi[3]);
-                if (SAVE && (i & 1))      // two adjacent tiles: one 16-byte store per lane (common.h)
+                if (sv && (i & 1))        // two adjacent tiles: one 16-byte store per lane (common.h)
                     store_bf16_tile_pair<true>(a.qkv + rows[g] * (3 * C) + n - 16 - 4 * gq, qkvp[i - 1][g], qkvp[i][g], gq);
             }
         }
@@ -407,7 +420,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             opp[dc] = pack4(o[0], o[1], o[2], o[3]);
             put4<T>(XO, 16 * g + t, 32 * wid + 16 * dc + 4 * gq, opp[dc]);
         }
-        if constexpr (SAVE) store_bf16_tile_pair<true>(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
+        if (sv) store_bf16_tile_pair<true>(a.o + rows[g] * C + 32 * wid, opp[0], opp[1], gq);
     }
     TULIP_STAMP(5);
     __syncthreads();
@@ -416,7 +429,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     // ---- proj Linear + DropPath + residual (tulip.py:318,344): this wave's 32 output channels; then norm2 (:347)
     WStream<4, KS, D + 1> w1a;                      // fc1, first 64 of this wave's 128 hidden channels
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w1a.wt[i] = wtile_ptr(a.w1, 8 * wid + i, C, lane);
+    for (int i = 0; i < 4; ++i) w1a.wt[i] = wtile_ptr(a.w1, SPLIT ? 48 * half + 4 * wid + i : 8 * wid + i, C, lane);
     f32x4 ga2[2], be2[2];
     {
         f32x4 acc[2][G];
@@ -433,7 +446,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             for (int i = 0; i < 2; ++i) {
                 const int c0 = 32 * wid + 16 * i + 4 * gq;
                 x1v[i][g] = x1v[i][g] + s0 * (acc[i][g] + bp[i]);
-                if constexpr (SAVE) store_late((float4*)(a.x1 + rows[g] * C + c0), make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]));
+                if (sv) store_late((float4*)(a.x1 + rows[g] * C + c0), make_float4(x1v[i][g][0], x1v[i][g][1], x1v[i][g][2], x1v[i][g][3]));
                 sm += (x1v[i][g][0] + x1v[i][g][1]) + (x1v[i][g][2] + x1v[i][g][3]);
             }
             // statistics of this wave's 32 channels of token t: (mean, sum of squared deviations)
@@ -463,7 +476,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 #pragma unroll
         for (int w = 0; w < NWV; ++w) { const float d = st[w].x - mu; m2 += st[w].y + 32.0f * d * d; }
         const float rs = rsqrtf(m2 * (1.0f / C) + a.eps);
-        if (SAVE && wid == 0 && gq == 0) { a.mean2[rows[g]] = mu; a.rstd2[rows[g]] = rs; }
+        if (sv && wid == 0 && gq == 0) { a.mean2[rows[g]] = mu; a.rstd2[rows[g]] = rs; }
         bf16x4 pk2[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -472,7 +485,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                            (x1v[i][g][2] - mu) * rs * ga2[i][2] + be2[i][2], (x1v[i][g][3] - mu) * rs * ga2[i][3] + be2[i][3]);
             put4<T>(XN, 16 * g + t, c0, pk2[i]);
         }
-        if constexpr (SAVE) store_bf16_tile_pair<true>(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
+        if (sv) store_bf16_tile_pair<true>(a.xn2 + rows[g] * C + 32 * wid, pk2[0], pk2[1], gq);
     }
     f32x4 b1v[D == 2 ? 2 : 1][4];
     if constexpr (D == 2) {
@@ -489,14 +502,17 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     WStream<4, KS, D + 1> w1b;
 #pragma unroll
     for (int i = 0; i < 4; ++i) w1b.wt[i] = wtile_ptr(a.w1, 8 * wid + 4 + i, C, lane);
-    WStream<2, 4 * KS, 3 * D> w2s;
+    constexpr int KS2 = SPLIT ? 2 * KS : 4 * KS;    // k steps of fc2 in this workgroup (split form: its half of the hidden channels)
+    WStream<2, KS2, 3 * D> w2s;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w2s.wt[i] = wtile_ptr(a.w2, 2 * wid + i, HID, lane);
+    for (int i = 0; i < 2; ++i) w2s.wt[i] = wtile_ptr(a.w2, 2 * wid + i, HID, lane) + (SPLIT ? (size_t)half * KS2 * 512 : 0);
     auto fc1_out = [&](const f32x4 (&acc)[4][G], int ch) {
         bf16x4 hprev[G], gprev[G];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
+            // nl: the channel's k index of fc2 inside this workgroup; n: the hidden channel
+            const int nl = SPLIT ? 64 * wid + 16 * i + 4 * gq : 128 * wid + 64 * ch + 16 * i + 4 * gq;
+            const int n = SPLIT ? 768 * half + nl : nl;
             f32x4 bb;
             if constexpr (D == 2) bb = b1v[ch][i]; else bb = ld4(a.b1 + n);
 #pragma unroll
@@ -513,9 +529,9 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                     g01 = gelu_exact2(h01); g23 = gelu_exact2(h23);
                 }
                 const bf16x4 gp = pack4(g01.x, g01.y, g23.x, g23.y);
-                put4<T>(GB, 16 * g + t, n, gp);
+                put4<T>(GB, 16 * g + t, nl, gp);
                 if (i & 1) {    // two adjacent tiles: one 16-byte store per lane (common.h)
-                    const size_t off = rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1);
+                    const size_t off = rows[g] * HID + (n - 16 - 4 * gq);
                     if constexpr (SAVE) {
                         store_bf16_tile_pair<true>(a.h + off, hprev[g], hp, gq);
                         store_bf16_tile_pair<true>(a.g + off, gprev[g], gp, gq);
@@ -530,12 +546,17 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
         f32x4 acc[4][G];
         zero(acc);
         w1a.template run<G, T>(acc, XN, t, gq);
-        w1b.start();
-        fc1_out(acc, 0);
-        zero(acc);
-        w1b.template run<G, T>(acc, XN, t, gq);
-        w2s.start();
-        fc1_out(acc, 1);
+        if constexpr (SPLIT) {
+            w2s.start();
+            fc1_out(acc, 0);
+        } else {
+            w1b.start();
+            fc1_out(acc, 0);
+            zero(acc);
+            w1b.template run<G, T>(acc, XN, t, gq);
+            w2s.start();
+            fc1_out(acc, 1);
+        }
     }
     f32x4 b2v[2];
 #pragma unroll
@@ -550,6 +571,28 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
         zero(acc);
         w2s.template run<G, T>(acc, GB, t, gq);
         TULIP_STAMP(14);
+        if constexpr (SPLIT) {
+            typedef unsigned u32x4_x __attribute__((ext_vector_type(4)));
+            // (descriptor from wave-uniform kernel arguments; every per-lane part in the offset)
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xws, 0, (int)a.xws_bytes, 0x00020000);
+            const unsigned mine = (unsigned)(((wblk * 2 + half) * 2) * Z::NT + tid) * 16u;
+            const unsigned other = (unsigned)(((wblk * 2 + (half ^ 1)) * 2) * Z::NT + tid) * 16u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)     // write-through (sc1) stores: no release fence, no L2 write-back
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_x, acc[i][0]), rsrc, mine + i * (Z::NT * 16), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains
+            __syncthreads();
+            unsigned* flag = (unsigned*)STAT;                          // (the statistics exchange is long over)
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tick + wblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (flag[0] == 0u) return;                                 // first of the pair: the partner finishes the block
+            if (tid == 0) __hip_atomic_store(a.tick + wblk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4_x o = __builtin_amdgcn_raw_buffer_load_b128(rsrc, other + i * (Z::NT * 16), 0, 16);
+                acc[i][0] += __builtin_bit_cast(f32x4, o);
+            }
+        }
         bf16x4 ob[2][G];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -569,6 +612,19 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
     TULIP_STAMP(15);
 }
 
+// two workgroups per window (swinw_fwd_kernel, SPLIT): the training form with gelu'(h) handed over, or the inference form
+int launch_fwd_split(const SwinWArgs& a, hipStream_t stream) {
+    const int windows = a.B * (a.H / 2) * (a.W / 8);
+    const int warm = (a.prof || !swinw_warm) ? 0 : 1;
+    const dim3 grid(2 * windows), block(Geo<384, 1>::NT);
+    if (!a.qkv) {
+        if (warm) hipLaunchKernelGGL((swinw_fwd_kernel<384, 1, 21>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((swinw_fwd_kernel<384, 1, 20>), grid, block, 0, stream, a);
+    } else if (warm) hipLaunchKernelGGL((swinw_fwd_kernel<384, 1, 25>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((swinw_fwd_kernel<384, 1, 24>), grid, block, 0, stream, a);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
 template <int C, int G>
 int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
@@ -609,6 +665,7 @@ struct SwinWBwdArgs {
     float *lnpart1, *lnpart2, *biaspart;         // [workgroups][2C], [workgroups][2C], [workgroups][NH*256]
     int B, H, W, sh, sw, masked;
     float scale;
+    float* xws; unsigned* tick; unsigned xws_bytes;     // split form (BMODE bit 3): as SwinWArgs
 };
 
 template <int C, int G>
@@ -688,6 +745,12 @@ template <int C, int G, int BMODE>
 __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinWBwdArgs a) {
     constexpr int WARM = BMODE & 3;
     constexpr bool HGRAD = (BMODE & 4) != 0;
+    // SPLIT (round 4; the forward's MODE bit 4): two workgroups per window.  The MLP half comes first here: each workgroup takes
+    // half of the hidden channels (fc2', GELU', and its half of fc1's contraction), publishes its 16 x 384 fp32 partial of
+    // d(xn2) and draws a ticket; the LAST arriver adds its partner's partial and runs the rest of the block (norm2' ... norm1')
+    // alone, the first one leaves.  Nobody waits; a + b == b + a.
+    constexpr bool SPLIT = (BMODE & 8) != 0;
+    static_assert(!SPLIT || (C == 384 && G == 1 && HGRAD), "split form: C = 384, one window per workgroup pair, gelu'(h) handed over");
     using Z = GeoB<C, G>;
     constexpr int T = Z::T, KS = Z::KS, NWV = Z::NWV, HID = Z::HID, NH = Z::NH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Z::SMEM];
@@ -696,14 +759,15 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     unsigned char* const DQ = smem + Z::OFF_BIG;
     float2* const STAT = (float2*)(smem + Z::OFF_STAT);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
-    const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw);
+    const int half = SPLIT ? (int)(blockIdx.x & 1) : 0, wblk = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const TokMap tm = make_map<G>(a.B, a.H, a.W, a.sh, a.sw, wblk);
     const float s0 = a.ds0 ? a.ds0[tm.b] : 1.0f, s1v = a.ds1 ? a.ds1[tm.b] : 1.0f;
 
     constexpr int D = (C == 192 && G == 2) ? 2 : 1;       // loads in flight per wave, as in the forward
     // the first weight stream (fc2^T, first 64 of this wave's 128 hidden channels) starts before anything else
     WStream<4, KS, D + 1> w2a;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w2a.wt[i] = wtile_ptr(a.w2t, 8 * wid + i, C, lane);
+    for (int i = 0; i < 4; ++i) w2a.wt[i] = wtile_ptr(a.w2t, SPLIT ? 48 * half + 4 * wid + i : 8 * wid + i, C, lane);
     w2a.start();
     WeightWarm<WARM> warm;                          // the four transposed weights into this XCD's L2, in order of use
     warm.init(wid, lane, smem + Z::OFF_WARM);
@@ -731,7 +795,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
                 for (int j = 0; j < C / 64; ++j) {
                     const int c = 4 * t + 64 * j;
                     const bf16x4 pk = pack4(v[p][j].x * s1v, v[p][j].y * s1v, v[p][j].z * s1v, v[p][j].w * s1v);
-                    store_late((bf16x4*)(a.dyb_m + rowp[p] * C + c), pk);
+                    if (!SPLIT || half == 0) store_late((bf16x4*)(a.dyb_m + rowp[p] * C + c), pk);
                     put4<T>(DY, tt, c, pk);
                 }
             }
@@ -754,21 +818,24 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     WStream<4, KS, D + 1> w2b;
 #pragma unroll
     for (int i = 0; i < 4; ++i) w2b.wt[i] = wtile_ptr(a.w2t, 8 * wid + 4 + i, C, lane);
-    WStream<2, 4 * KS, 3 * D> w1s;                  // fc1^T: this wave's 32 channels of d(xn2)
+    constexpr int KS1 = SPLIT ? 2 * KS : 4 * KS;    // k steps of fc1' in this workgroup (split form: its half of the hidden channels)
+    WStream<2, KS1, 3 * D> w1s;                     // fc1^T: this wave's 32 channels of d(xn2)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w1s.wt[i] = wtile_ptr(a.w1t, 2 * wid + i, HID, lane);
+    for (int i = 0; i < 2; ++i) w1s.wt[i] = wtile_ptr(a.w1t, 2 * wid + i, HID, lane) + (SPLIT ? (size_t)half * KS1 * 512 : 0);
     auto dh_out = [&](const f32x4 (&acc)[4][G], const bf16x4 (&hv)[4][G], int ch) {
         bf16x4 dprev[G];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = 128 * wid + 64 * ch + 16 * i + 4 * gq;
+            // nl: the channel's k index of fc1' inside this workgroup; n: the hidden channel
+            const int nl = SPLIT ? 64 * wid + 16 * i + 4 * gq : 128 * wid + 64 * ch + 16 * i + 4 * gq;
+            const int n = SPLIT ? 768 * half + nl : nl;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 f32x2 d01 = {bf2f((bf16_t)hv[i][g][0]), bf2f((bf16_t)hv[i][g][1])}, d23 = {bf2f((bf16_t)hv[i][g][2]), bf2f((bf16_t)hv[i][g][3])};
                 if constexpr (!HGRAD) { d01 = gelu_exact_grad2(d01); d23 = gelu_exact_grad2(d23); }    // HGRAD: the forward left gelu'(h) there
                 const bf16x4 dp = pack4(acc[i][g][0] * d01.x, acc[i][g][1] * d01.y, acc[i][g][2] * d23.x, acc[i][g][3] * d23.y);
-                put4<T>(DH, 16 * g + t, n, dp);
-                if (i & 1) store_bf16_tile_pair<true>(a.dh + rows[g] * HID + 128 * wid + 64 * ch + 16 * (i - 1), dprev[g], dp, gq);
+                put4<T>(DH, 16 * g + t, nl, dp);
+                if (i & 1) store_bf16_tile_pair<true>(a.dh + rows[g] * HID + (n - 16 - 4 * gq), dprev[g], dp, gq);
                 else dprev[g] = dp;
             }
         }
@@ -777,7 +844,8 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int g = 0; g < G; ++g) hv[i][g] = ld_saved((const bf16x4*)(a.h + rows[g] * HID + 128 * wid + 64 * ch + 16 * i + 4 * gq));
+            for (int g = 0; g < G; ++g)
+                hv[i][g] = ld_saved((const bf16x4*)(a.h + rows[g] * HID + (SPLIT ? 768 * half + 64 * wid : 128 * wid + 64 * ch) + 16 * i + 4 * gq));
     };
     {
         // (the activation loads stay BEHIND the GEMM they follow: vmcnt retires in order, so a strided HBM load issued
@@ -786,14 +854,20 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         bf16x4 hv[4][G];
         zero(acc);
         w2a.template run<G, T>(acc, DY, t, gq);
-        w2b.start();
-        load_h(hv, 0);
-        dh_out(acc, hv, 0);
-        zero(acc);
-        w2b.template run<G, T>(acc, DY, t, gq);
-        w1s.start();
-        load_h(hv, 1);
-        dh_out(acc, hv, 1);
+        if constexpr (SPLIT) {
+            w1s.start();
+            load_h(hv, 0);
+            dh_out(acc, hv, 0);
+        } else {
+            w2b.start();
+            load_h(hv, 0);
+            dh_out(acc, hv, 0);
+            zero(acc);
+            w2b.template run<G, T>(acc, DY, t, gq);
+            w1s.start();
+            load_h(hv, 1);
+            dh_out(acc, hv, 1);
+        }
     }
     f32x4 xv[2][G], gam[2], dyv[2][G];
     float mu[G], rs[G];
@@ -808,6 +882,28 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         f32x4 xh[2][G];
         zero(dx1);
         w1s.template run<G, T>(dx1, DH, t, gq);
+        if constexpr (SPLIT) {
+            typedef unsigned u32x4_x __attribute__((ext_vector_type(4)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xws, 0, (int)a.xws_bytes, 0x00020000);
+            const unsigned mine = (unsigned)(((wblk * 2 + half) * 2) * Z::NT + tid) * 16u;
+            const unsigned other = (unsigned)(((wblk * 2 + (half ^ 1)) * 2) * Z::NT + tid) * 16u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)     // write-through (sc1) stores, drained by every wave (guide recipe R1, ticket form)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_x, dx1[i][0]), rsrc, mine + i * (Z::NT * 16), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = (unsigned*)STAT;
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tick + wblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (flag[0] == 0u) return;                                 // first of the pair: the partner runs the rest of the block
+            if (tid == 0) __hip_atomic_store(a.tick + wblk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4_x o = __builtin_amdgcn_raw_buffer_load_b128(rsrc, other + i * (Z::NT * 16), 0, 16);
+                dx1[i][0] += __builtin_bit_cast(f32x4, o);
+            }
+            __syncthreads();                                           // (flag word = STAT[0]: read by all before norm2' writes it)
+        }
         wps.start();
         // what norm2' needs: x1 slice, row statistics, gamma; and dy for the residual
 #pragma unroll
@@ -821,7 +917,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) { mu[g] = a.mean2[rows[g]]; rs[g] = a.rstd2[rows[g]]; }
-        ln_bwd_part1<C, G, T>(dx1, xh, xv, mu, rs, gam, a.lnpart2 + (size_t)blockIdx.x * 2 * C, STAT, wid, t, gq);
+        ln_bwd_part1<C, G, T>(dx1, xh, xv, mu, rs, gam, a.lnpart2 + (size_t)wblk * 2 * C, STAT, wid, t, gq);
         __syncthreads();
         ln_bwd_part2<C, G, T, NWV>(dx1, xh, rs, STAT, t);
         // d(x1) = dy + norm2'(d(xn2))  (residual, tulip.py:351); its bf16 copy * s_attn feeds proj' and proj's wgrad
@@ -943,7 +1039,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             }
         }
         // dense relative-position-bias gradient of this head, summed over the workgroup's windows: [NH][16 q][16 k]
-        *(float4*)(a.biaspart + (size_t)blockIdx.x * (NH * 256) + wid * 256 + t * 16 + gq * 4) =
+        *(float4*)(a.biaspart + (size_t)wblk * (NH * 256) + wid * 256 + t * 16 + gq * 4) =
             make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
     }
     __syncthreads();
@@ -961,7 +1057,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) { mu[g] = a.mean1[rows[g]]; rs[g] = a.rstd1[rows[g]]; }
-        ln_bwd_part1<C, G, T>(acc, xh, xv, mu, rs, gam, a.lnpart1 + (size_t)blockIdx.x * 2 * C, STAT, wid, t, gq);
+        ln_bwd_part1<C, G, T>(acc, xh, xv, mu, rs, gam, a.lnpart1 + (size_t)wblk * 2 * C, STAT, wid, t, gq);
         __syncthreads();
         ln_bwd_part2<C, G, T, NWV>(acc, xh, rs, STAT, t);
         const float cs = a.dx_scale ? a.dx_scale[tm.b] : 1.0f;
@@ -983,6 +1079,14 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
     }
 }
 
+int launch_bwd_split(const SwinWBwdArgs& a, hipStream_t stream) {
+    const int windows = a.B * (a.H / 2) * (a.W / 8);
+    const dim3 grid(2 * windows), block(GeoB<384, 1>::NT);
+    if (swinw_warm) hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 13>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 12>), grid, block, 0, stream, a);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
 template <int C, int G>
 int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
@@ -1079,15 +1183,33 @@ extern "C" int tulip_swinw_supported(int C, int H, int W) {
     return (C == 192 || C == 384) && H > 0 && !(H & 1) && W > 0 && !(W & 15);
 }
 
-static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, unsigned long long* prof, hipStream_t stream);
+static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, unsigned long long* prof, void* exchange,
+                          size_t exchange_bytes, hipStream_t stream);
 extern "C" int tulip_swinw_block_fwd(const tulip_swin96_desc* d, int C, void* out_bf16, hipStream_t stream) {
-    return swinw_fwd_impl(d, C, out_bf16, nullptr, stream);
+    return swinw_fwd_impl(d, C, out_bf16, nullptr, nullptr, 0, stream);
 }
 extern "C" int tulip_swinw_block_fwd_profiled(const tulip_swin96_desc* d, int C, void* out_bf16, uint64_t* stamps,
                                               hipStream_t stream) {
-    return swinw_fwd_impl(d, C, out_bf16, (unsigned long long*)stamps, stream);
+    return swinw_fwd_impl(d, C, out_bf16, (unsigned long long*)stamps, nullptr, 0, stream);
 }
-static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, unsigned long long* prof, hipStream_t stream) {
+// bytes of the exchange buffer of the split form (two workgroups per window), 0 where that form does not exist: per window two
+// 16 x C fp32 partial tiles in accumulator order, then one arrival ticket per window (zero before the first launch; the
+// kernels leave it zero)
+extern "C" int tulip_swinw_split_bytes(int C, int B, int H, int W) {
+    if (C != 384 || B <= 0 || !tulip_swinw_supported(C, H, W) || wide_g(C, B, H, W) != 1) return 0;
+    const int windows = B * (H / 2) * (W / 8);          // (< TULIP_SWINW_G1_BELOW * 2)
+    return windows * (2 * 2 * Geo<384, 1>::NT * 16) + windows * 4;
+}
+extern "C" int tulip_swinw_block_fwd_split(const tulip_swin96_desc* d, int C, void* out_bf16, void* exchange, size_t exchange_bytes,
+                                           uint64_t* stamps, hipStream_t stream) {
+    if (!d || !exchange) return TULIP_ERR_ARG;
+    const size_t need = (size_t)tulip_swinw_split_bytes(C, d->B, d->H, d->W);
+    if (need == 0 || exchange_bytes < need || ((uintptr_t)exchange & 15)) return TULIP_ERR_ARG;
+    if (d->qkv && !(d->masked & TULIP_BLOCK_FC1_GRAD)) return TULIP_ERR_ARG;         // training form: with gelu'(h) handed over only
+    return swinw_fwd_impl(d, C, out_bf16, (unsigned long long*)stamps, exchange, exchange_bytes, stream);
+}
+static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, unsigned long long* prof, void* exchange,
+                          size_t exchange_bytes, hipStream_t stream) {
     if (!d || d->B <= 0 || !tulip_swinw_supported(C, d->H, d->W) || d->shift_h < 0 || d->shift_h >= d->H ||
         d->shift_w < 0 || d->shift_w >= d->W)
         return TULIP_ERR_ARG;
@@ -1112,6 +1234,14 @@ static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, uns
     }
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
+    a.xws = nullptr; a.tick = nullptr; a.xws_bytes = 0;
+    if (exchange) {
+        const size_t windows = (size_t)d->B * (d->H / 2) * (d->W / 8);
+        a.xws = (float*)exchange;
+        a.xws_bytes = (unsigned)(windows * (2 * 2 * Geo<384, 1>::NT * 16));
+        a.tick = (unsigned*)((unsigned char*)exchange + a.xws_bytes);
+        return launch_fwd_split(a, stream);
+    }
     if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_fwd<192, 4>(a, stream) : launch_fwd<192, 2>(a, stream);
     return wide_g(C, d->B, d->H, d->W) == 1 ? launch_fwd<384, 1>(a, stream) : launch_fwd<384, 2>(a, stream);
 }
@@ -1121,7 +1251,19 @@ extern "C" int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W) {
     return B * (H / 2) * (W / (8 * wide_g(C, B, H, W)));
 }
 
+static int swinw_bwd_impl(const tulip_swin96_bwd_desc* d, int C, void* exchange, hipStream_t stream);
 extern "C" int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream) {
+    return swinw_bwd_impl(d, C, nullptr, stream);
+}
+extern "C" int tulip_swinw_block_bwd_split(const tulip_swin96_bwd_desc* d, int C, void* exchange, size_t exchange_bytes,
+                                           hipStream_t stream) {
+    if (!d || !exchange) return TULIP_ERR_ARG;
+    const size_t need = (size_t)tulip_swinw_split_bytes(C, d->B, d->H, d->W);
+    if (need == 0 || exchange_bytes < need || ((uintptr_t)exchange & 15)) return TULIP_ERR_ARG;
+    if (!(d->masked & TULIP_BLOCK_FC1_GRAD)) return TULIP_ERR_ARG;
+    return swinw_bwd_impl(d, C, exchange, stream);
+}
+static int swinw_bwd_impl(const tulip_swin96_bwd_desc* d, int C, void* exchange, hipStream_t stream) {
     if (!d || d->B <= 0 || !tulip_swinw_supported(C, d->H, d->W) || d->shift_h < 0 || d->shift_h >= d->H ||
         d->shift_w < 0 || d->shift_w >= d->W)
         return TULIP_ERR_ARG;
@@ -1139,6 +1281,14 @@ extern "C" int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipS
     a.lnpart1 = d->norm1_partials; a.lnpart2 = d->norm2_partials; a.biaspart = d->bias_partials;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.scale = 0.17677669529663687f;
+    a.xws = nullptr; a.tick = nullptr; a.xws_bytes = 0;
+    if (exchange) {
+        const size_t windows = (size_t)d->B * (d->H / 2) * (d->W / 8);
+        a.xws = (float*)exchange;
+        a.xws_bytes = (unsigned)(windows * (2 * 2 * GeoB<384, 1>::NT * 16));
+        a.tick = (unsigned*)((unsigned char*)exchange + a.xws_bytes);
+        return launch_bwd_split(a, stream);
+    }
     if (C == 192) return wide_g4(C, d->B, d->H, d->W) ? launch_bwd<192, 4>(a, stream) : launch_bwd<192, 2>(a, stream);
     return wide_g(C, d->B, d->H, d->W) == 1 ? launch_bwd<384, 1>(a, stream) : launch_bwd<384, 2>(a, stream);
 }

@@ -534,6 +534,11 @@ class TulipEngine:
         hg = self._hgrad96(sp) or (B is not None and self._hgrad_wide(sp, B))
         return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0) | (4 if hg else 0)
 
+    # two workgroups per window for the C = 384 blocks where one workgroup owns one window (csrc/swinw.hip, SPLIT)
+    split_wide = os.environ.get("TULIP_SWINW_SPLIT", "1") != "0"
+    # the backward's split form is 5.6 us faster per launch in isolation (50.9 -> 45.3 us) and 34 us SLOWER per step: the half of the
+    # chip its 128 workgroups leave free is where the side queue's weight gradients run (profiles/README.md); off
+    split_wide_bwd = os.environ.get("TULIP_SWINW_SPLIT_BWD", "0") != "0"
     fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
     fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
     # C = 192 always; C = 384 (stage 2: 3.5 MB of weights per block) from 128 windows per launch up (batch 8 at the KITTI
@@ -596,7 +601,14 @@ class TulipEngine:
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
             if wide:
                 self._join_pack(p)                 # the fragment-major weight copies being rewritten beside the forward
-            launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **kw)) if wide else ops.swin96_block_fwd
+            xkw = {}
+            if wide and self.split_wide and (self._no_save or self._hgrad_wide(sp, B)):
+                # C = 384 with one window per workgroup: two workgroups per window (tulip_swinw_block_fwd_split)
+                nb = ops.swinw_split_bytes(C, B, sp.H, sp.W)
+                if nb:
+                    P.scratch("xchg." + p, (nb + 3) // 4)
+                    xkw["exchange"] = P.bufs["xchg." + p]
+            launch = (lambda **kw: ops.swinw_block_fwd(C, out_bf16=out_bf16, **xkw, **kw)) if wide else ops.swin96_block_fwd
             wf = W_.p16p if wide else W_.p16           # the wide kernel streams fragment-major copies of the weights
             # forward without a backward behind it (run_forward(with_loss=False): eval / MC-dropout inference): the kernels'
             # inference form -- none of the activations a backward would read is written (90 % of the C = 96 kernel's traffic)
@@ -1198,7 +1210,13 @@ class TulipEngine:
             R = ops.swinw_bwd_partial_rows(C, B, sp.H, sp.W) if wide else ops.swin96_bwd_partial_rows(B, sp.H, sp.W)
             ln1, ln2 = P.scratch("lnp." + p + ".1", R * 2 * C), P.scratch("lnp." + p + ".2", R * 2 * C)
             apart = P.scratch("apart." + p, R * nh * 256)
-            launch = (lambda **kw: ops.swinw_block_bwd(C, **kw)) if wide else ops.swin96_block_bwd
+            xkw = {}
+            if wide and self.split_wide_bwd and self._hgrad_wide(sp, B):
+                nb = ops.swinw_split_bytes(C, B, sp.H, sp.W)       # two workgroups per window (tulip_swinw_block_bwd_split)
+                if nb:
+                    P.scratch("xchg." + p, (nb + 3) // 4)
+                    xkw["exchange"] = P.bufs["xchg." + p]
+            launch = (lambda **kw: ops.swinw_block_bwd(C, **xkw, **kw)) if wide else ops.swin96_block_bwd
             wt = W_.p16t if wide else W_.p16          # the wide kernel streams fragment-major TRANSPOSED weights
             lean = (not wide) and self._recomp96(sp)
             extra = dict(b_qkv=W_.p32(p + ".attn.qkv.bias"), b_fc1=W_.p32(p + ".mlp.fc1.bias"),

@@ -395,20 +395,31 @@ def swinw_supported(C, H, W) -> bool:
     return bool(_lib.load().tulip_swinw_supported(C, H, W))
 
 
-def swinw_block_fwd(C, out_bf16=None, stamps=None, **kw):
+def swinw_block_fwd(C, out_bf16=None, stamps=None, exchange=None, **kw):
     """tulip_swinw_block_fwd (C = 192 / 384): keyword arguments are the fields of tulip_swin96_desc.
-    stamps (int64 device tensor): the profiled twin, per-wave shader-clock stamps at the phase boundaries."""
+    stamps (int64 device tensor): the profiled twin, per-wave shader-clock stamps at the phase boundaries.
+    exchange (zeroed uint8 device tensor of swinw_split_bytes): tulip_swinw_block_fwd_split, two workgroups per window."""
     d = _lib.Swin96Desc()
     for name, _t in _lib.Swin96Desc._fields_:
         v = kw.pop(name, None)
         setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
     if kw:
         raise TypeError(f"unknown fields {sorted(kw)}")
+    if exchange is not None:
+        check(_lib.load().tulip_swinw_block_fwd_split(ctypes.byref(d), C, _p(out_bf16), _p(exchange),
+                                                      exchange.numel() * exchange.element_size(), _p(stamps), _stream()),
+              "tulip_swinw_block_fwd_split")
+        return
     if stamps is not None:
         check(_lib.load().tulip_swinw_block_fwd_profiled(ctypes.byref(d), C, _p(out_bf16), _p(stamps), _stream()),
               "tulip_swinw_block_fwd_profiled")
         return
     check(_lib.load().tulip_swinw_block_fwd(ctypes.byref(d), C, _p(out_bf16), _stream()), "tulip_swinw_block_fwd")
+
+
+def swinw_split_bytes(C, B, H, W) -> int:
+    """tulip_swinw_split_bytes: size of the exchange buffer of the two-workgroups-per-window form, 0 where it does not exist."""
+    return _lib.load().tulip_swinw_split_bytes(C, B, H, W)
 
 
 def stamp_realtime(dst) -> None:
@@ -430,14 +441,19 @@ def swinw_bwd_partial_rows(C, B, H, W) -> int:
     return _lib.load().tulip_swinw_bwd_partial_rows(C, B, H, W)
 
 
-def swinw_block_bwd(C, **kw):
-    """tulip_swinw_block_bwd: fields of tulip_swin96_bwd_desc; w_* are the TRANSPOSED bf16 weights."""
+def swinw_block_bwd(C, exchange=None, **kw):
+    """tulip_swinw_block_bwd: fields of tulip_swin96_bwd_desc; w_* are the TRANSPOSED bf16 weights.
+    exchange: tulip_swinw_block_bwd_split (see swinw_block_fwd)."""
     d = _lib.Swin96BwdDesc()
     for name, _t in _lib.Swin96BwdDesc._fields_:
         v = kw.pop(name, None)
         setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked") else v)
     if kw:
         raise TypeError(f"unknown fields {sorted(kw)}")
+    if exchange is not None:
+        check(_lib.load().tulip_swinw_block_bwd_split(ctypes.byref(d), C, _p(exchange), exchange.numel() * exchange.element_size(),
+                                                      _stream()), "tulip_swinw_block_bwd_split")
+        return
     check(_lib.load().tulip_swinw_block_bwd(ctypes.byref(d), C, _stream()), "tulip_swinw_block_bwd")
 
 
