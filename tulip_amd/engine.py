@@ -1553,6 +1553,10 @@ class TulipEngine:
 
     def _module_sequence(self, P: Plan, key, fn):
         graphs = P.__dict__.setdefault("_module_graphs", {})
+        # what the captured launch sequence depends on besides the caller's key: the fuse switches, the DropPath seed (a launch
+        # argument) and the number of draw slots
+        key = key + (self.fuse_wide, self.fuse_wide_bwd, self.fuse_block96, self.fuse_block96_bwd, self.split_wide, self.split_wide_bwd,
+                     self.fc1_grad_wide, self.fuse_tail_fwd, self.fuse_tail_bwd, int(self._drop_seed), int(self.n_drop_slots))
         ent = graphs.get(key)
         if not self.graph_module or ent is None:
             fn()
@@ -1570,6 +1574,8 @@ class TulipEngine:
             cur.wait_stream(cap)
             graphs[key] = ent
         ent.replay()
+        if key[0] == "fwd":
+            self.params.shadow_dirty = False     # the replayed sequence rebuilt the bf16 shadow and the packed copies
 
     def _module_forward(self, P: Plan):
         train = bool(self.model.training)

@@ -110,6 +110,7 @@ class Trainer:
                            and os.environ.get("TULIP_FUSE_ADAMW", "1") != "0")
         self._adam_mask = None
         self._adam_blocks = None
+        self._adam_ctx, self._adam_fused = None, frozenset()
         self.fused_adamw_params = 0
         self._fuse_adamw_skip = tuple(x for x in os.environ.get("TULIP_FUSE_ADAMW_SKIP", "").split(",") if x)   # dev: name prefixes
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
@@ -156,6 +157,12 @@ class Trainer:
 
     def _fwd_bwd(self, hook, update: bool = True, apply_adamw: bool = False):
         eng, P = self.eng, self.P
+        # the fused-AdamW plan points at THIS trainer's gradient / moment / mask buffers: a second Trainer on the same model
+        # (another batch size, a rebuild) must not leave its own on the engine for this one's launches or captures
+        if getattr(self, "_adam_ctx", None) is not None:
+            eng.adam_fused, eng.adam_ctx = self._adam_fused, self._adam_ctx
+        elif eng.adam_probe is None:
+            eng.adam_fused, eng.adam_ctx = frozenset(), None
         # (the flat gradient buffer is cleared by the fused AdamW right after it consumed it)
         eng.draw_drop_scales(P, self.model.training, self.inject_drop_u)
         eng.run_forward(P, pack_on_side=self.pack_at_step_start, defer_loss_final=True)
@@ -246,9 +253,18 @@ class Trainer:
                 put(self.g, n, sd["grad"][n])
         self.t, self.micro, self.lr = int(sd["step"]), int(sd["micro"]), float(sd["lr"])
         self.betas, self.eps, self.wd = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
+        # DropPath stream.  Same rank as the one that saved (or a checkpoint without a rank): the saved seed -- the resume then
+        # continues the uninterrupted run's draws.  Another rank: the reference seeds rank r with seed + r (main_lidar_upsampling.py:
+        # 155); when this engine's own seed sits at exactly that distance from the saved one the convention holds and the own seed
+        # IS the shifted one -- otherwise (one manual_seed everywhere, unseeded runs, a sub-group that this process is not a member
+        # of: get_rank() == -1) the engine keeps the seed it was built with.
         my_rank = dist.get_rank(self.process_group) if dist.is_initialized() else 0
-        seed = int(sd["drop_seed"]) - int(sd.get("rank", 0)) + my_rank      # ranks stay decorrelated after a resume
-        if seed != int(self.eng._drop_seed):
+        saved_rank, own = sd.get("rank"), int(self.eng._drop_seed)
+        if saved_rank is None or my_rank == int(saved_rank):
+            seed = int(sd["drop_seed"])
+        else:
+            seed = own
+        if seed != own:
             self.eng._drop_seed = seed
             self._segments = None          # the seed is a launch argument baked into the captured graphs: re-capture
         self.eng._drop_counter.fill_(int(sd["drop_counter"]))
@@ -265,6 +281,8 @@ class Trainer:
         gbase = self.g.data_ptr()
         by_off = {W.offset[n]: n for n in W.names}
         fused, mask, count = set(), W.decay_mask.clone(), 0
+        cand, rejected_modules = [], set()
+        module_of = lambda n: n.rsplit(".", 1)[0]
         for ptr, cnt in eligible.items():
             a = (ptr - gbase) // 4
             names, o = [], a
@@ -274,14 +292,23 @@ class Trainer:
             whole = bool(names) and W.offset[names[-1]] + W.numel[names[-1]] <= a + cnt <= o
             if (not whole or any(n.startswith("skip_connection_layers.") for n in names)
                     or any(n.startswith(x) for n in names for x in self._fuse_adamw_skip)):
+                rejected_modules.update(module_of(n) for n in names)
+                continue
+            cand.append((ptr, a, cnt, names))
+        for ptr, a, cnt, names in cand:
+            # a token-split Linear is stepped by its fold launch only when weight AND bias are fused (TulipEngine._issue_pending):
+            # a tensor whose partner of the same module was left out stays with the end-of-step launch too -- masking it here
+            # would leave it stepped by nobody
+            if any(module_of(n) in rejected_modules for n in names):
                 continue
             fused.add(ptr)
             mask[a // 64:(a + cnt + 63) // 64] |= 2
             count += sum(W.numel[n] for n in names)
         if fused:
-            self.eng.adam_fused = frozenset(fused)
+            self._adam_fused = frozenset(fused)
             self._adam_mask = mask
-            self.eng.adam_ctx = ops.adamw_ref(self.hyper, self.g, W.flat, self.m, self.v, W.shadow, decay_mask64=mask)
+            self._adam_ctx = ops.adamw_ref(self.hyper, self.g, W.flat, self.m, self.v, W.shadow, decay_mask64=mask)
+            self.eng.adam_fused, self.eng.adam_ctx = self._adam_fused, self._adam_ctx
             self.fused_adamw_params = count
             left = torch.nonzero((mask[:(W.total + 63) // 64] & 2) == 0).flatten().to(torch.int32)
             if 0 < left.numel() * 64 <= W.total // 4:       # (a long list gains nothing over the scan)
