@@ -16,12 +16,14 @@ lo, hi = bench.synthetic(a, 0, dev); tr.load_batch(lo, hi)
 for _ in range(3): tr.step()
 names = ("swin96_block_fwd", "swin96_block_bwd", "swinw_block_fwd", "swinw_block_bwd", "gemm", "tail_fwd", "tail_bwd", "layernorm_fwd",
          "layernorm_bwd", "layernorm_bwd_splitk", "splitk_resid_ln", "patch_embed_fwd", "patch_embed_bwd", "window_attn_fwd",
-         "window_attn_bwd")
+         "window_attn_bwd", "wgrad_group", "reduce_rows_multi", "tail_wgrad")
 real = {n: getattr(ops, n) for n in names}
 rec = []
 def wrap(n):
     def f(*a, **kw):
         tag = n + (f" C={a[0]}" if n.startswith("swinw") else "") + (f" {a[2]}x{a[3]}x{a[4]} s{kw.get('splits', 1)}" if n == "gemm" else "")
+        if n == "wgrad_group":
+            tag += f" #{sum(1 for t, _ in rec if t.startswith('wgrad_group'))}"
         rec.append((tag, lambda: real[n](*a, **kw)))
         real[n](*a, **kw)
     return f
