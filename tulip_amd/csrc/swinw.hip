@@ -531,7 +531,8 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
                 const bf16x4 gp = pack4(g01.x, g01.y, g23.x, g23.y);
                 put4<T>(GB, 16 * g + t, nl, gp);
                 if (i & 1) {    // two adjacent tiles: one 16-byte store per lane (common.h)
-                    const size_t off = rows[g] * HID + (n - 16 - 4 * gq);
+                    // (uniform part spelled out: with the lane's 4 gq added and subtracted again the C = 192 kernel spilled 16 bytes)
+                    const size_t off = rows[g] * HID + (SPLIT ? 768 * half + 64 * wid : 128 * wid + 64 * ch) + 16 * (i - 1);
                     if constexpr (SAVE) {
                         store_bf16_tile_pair<true>(a.h + off, hprev[g], hp, gq);
                         store_bf16_tile_pair<true>(a.g + off, gprev[g], gp, gq);
