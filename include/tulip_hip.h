@@ -521,13 +521,36 @@ int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t str
 int tulip_swinw_block_bwd_split(const tulip_swin96_bwd_desc* d, int C, void* exchange, size_t exchange_bytes, hipStream_t stream);
 int tulip_pack_bf16_multi(const tulip_pack_item* items, int n, hipStream_t stream);
 
+/* The same block at the DEEP widths, C = 768 (stage 3) and C = 1536 (stage 4 of tulip_large) -- replaces, per direction, the 15 / 16
+ * launch sequence tulip_layernorm_fwd -> tulip_gemm_bf16 -> tulip_window_attn_fwd -> ... of tulip.py:338-352 -- as a chain of SLICED
+ * launches (csrc/swind.hip): eight workgroups per group of 1-2 windows, workgroup (group, slice) on XCD `slice`, every CU streaming
+ * one eighth of a fragment-major weight matrix; the slicing alternates between heads / hidden channels and output channels, so no
+ * launch holds a partial sum.  Window wh x ww = 2 x 8 or the 1 x 16 backup window (tulip.py:284-287).  Descriptors, saved tensors and
+ * weight copies (fragment-major; backward: of the transposes) are those of tulip_swinw_block_fwd / _bwd.
+ * Forward, `phases` bits: 1 norm1 + qkv + attention (by heads) -> attn_out; 2 proj + residual (by output channels) -> x1;
+ * 4 norm2 + fc1 + GELU (by hidden channels) -> fc1_act; 8 fc2 + residual -> x_out (+ out_bf16).  The training form needs
+ * TULIP_BLOCK_FC1_GRAD in d->masked (the fc1_pre buffer carries gelu'(h)); the inference form is xn1, qkv, xn2, fc1_pre and the
+ * four statistics NULL -- attn_out, x1 and fc1_act pass from launch to launch and must always be given.
+ * Backward, `phases` bits: 1 fc2' + GELU' (by hidden channels): d->dx (read only) -> d_out_mlp, d_fc1_pre; 2 fc1' -> d_norm_out =
+ * fp32 d(norm2 output) [M][C]; the caller then runs tulip_layernorm_bwd_splitk(d_norm_out, 1, x1, mean2, rstd2, ...) (norm2',
+ * residual, d_out_attn); 4 proj' + attention' (by heads): d_out_attn -> d_qkv, bias_partials [tulip_swind_groups][heads * 256];
+ * 8 qkv' -> d_norm_out = fp32 d(norm1 output); the caller runs tulip_layernorm_bwd_splitk again (norm1', residual).  The
+ * descriptor's norm partials, dx_bf16, x_in, x1 and statistics fields are not read by these launches.
+ * stamps (optional): s_memtime per wave at the phase boundaries, [launch 0..3][workgroup][wave][16]. */
+int tulip_swind_supported(int C, int H, int W, int wh, int ww);
+int tulip_swind_groups(int C, int B, int H, int W, int wh, int ww);
+int tulip_swind_block_fwd(const tulip_swin96_desc* d, int C, int wh, int ww, void* out_bf16, int phases, uint64_t* stamps,
+                          hipStream_t stream);
+int tulip_swind_block_bwd(const tulip_swin96_bwd_desc* d, int C, int wh, int ww, float* d_norm_out, int phases, uint64_t* stamps,
+                          hipStream_t stream);
+
 /* library self-description */
 /* diagnostics: *dst = the 100 MHz constant device clock (s_memrealtime) when the stream reaches this point; capturable
  * (tools/step_stamps.py time-lines a captured training step with it, no tracer attached) */
 int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream);
 /* Layout version of the structs and signatures in this header (round 3: tulip_wgrad_item, tulip_reduce_region and tulip_adamw_ref grew
  * fields, entry points were added): a caller built against another version must not bind. */
-#define TULIP_ABI_VERSION 3
+#define TULIP_ABI_VERSION 4
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);
 

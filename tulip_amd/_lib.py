@@ -61,7 +61,7 @@ class PackItem(ctypes.Structure):
 
 
 REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 64
-ABI_VERSION = 3      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
+ABI_VERSION = 4      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -81,6 +81,10 @@ SIGNATURES = {
     "tulip_gemm_set_touch": [I],
     "tulip_swinw_block_bwd": [P, I, P],
     "tulip_swinw_block_bwd_split": [P, I, P, ctypes.c_size_t, P],
+    "tulip_swind_supported": [I, I, I, I, I],
+    "tulip_swind_groups": [I, I, I, I, I, I],
+    "tulip_swind_block_fwd": [P, I, I, I, P, I, P, P],
+    "tulip_swind_block_bwd": [P, I, I, I, P, I, P, P],
     "tulip_pack_bf16_multi": [P, I, P],
     "tulip_layernorm_fwd": [P, P, P, P, P, P, I, I, F, I, I, I, I, P],
     "tulip_layernorm_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P],

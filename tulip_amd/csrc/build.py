@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "tail.hip", "prep.hip", "evalpost.hip", "swin96.hip", "expand.hip", "swinw.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "tail.hip", "prep.hip", "evalpost.hip", "swin96.hip", "expand.hip", "swinw.hip", "swind.hip"]
 LIB = os.path.join(PKG, "libtulip_hip.so")
 ARCH = "gfx950"
 
@@ -15,7 +15,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "swin_stream.h"),
                                                        os.path.join(ROOT, "include", "tulip_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -411,12 +411,12 @@ class TulipEngine:
         self._graphs.clear()
         self.params = FlatParams(self.model, device)
         by_width: Dict[int, List[str]] = {}
-        if self.fuse_wide or self.fuse_wide_bwd:
+        if self.fuse_wide or self.fuse_wide_bwd or self.fuse_deep:
             for sp in self.blocks:
-                if self._fusable_wide(sp):
+                if self._fusable_wide(sp) or self._fusable_deep(sp):
                     by_width.setdefault(sp.C, []).extend(sp.prefix + suffix for suffix in (
                         ".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"))
-        self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd)
+        self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd or self.fuse_deep)
         # every width that CAN run fused keeps its fragment-major copies fresh from the start: a Trainer's captured AdamW
         # bakes in the pack launch for the widths active at capture time, so a width first activated by a later plan
         # (GraphedForward at another batch size) would otherwise stream stale weights after every replayed step
@@ -441,7 +441,8 @@ class TulipEngine:
         if B not in self.plans:
             self.plans[B] = Plan(self, B)
             # block widths this batch size runs fused: their weight copies are maintained from now on
-            widths = {sp.C for sp in self.blocks if (self.fuse_wide or self.fuse_wide_bwd) and self._fusable_wide(sp, B)}
+            widths = {sp.C for sp in self.blocks if ((self.fuse_wide or self.fuse_wide_bwd) and self._fusable_wide(sp, B))
+                      or self._fusable_deep(sp, B)}
             if not widths <= self.params.pk_active:
                 self.params.pk_active |= widths
                 if not self.params.shadow_dirty:
@@ -531,7 +532,7 @@ class TulipEngine:
         """`masked` argument of the attention / block kernels: bit 0 shifted-window mask, bit 1 fp8 scores, bit 2 (fused
         blocks, TULIP_BLOCK_FC1_GRAD; B = the plan's batch size for the wide ones) the fc1_pre buffer carries gelu'(h) from
         the forward to the backward."""
-        hg = self._hgrad96(sp) or (B is not None and self._hgrad_wide(sp, B))
+        hg = self._hgrad96(sp) or (B is not None and (self._hgrad_wide(sp, B) or self._fusable_deep(sp, B)))
         return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0) | (4 if hg else 0)
 
     # two workgroups per window for the C = 384 blocks where one workgroup owns one window (csrc/swinw.hip, SPLIT)
@@ -558,8 +559,22 @@ class TulipEngine:
             ok = B * (sp.H // 2) * (sp.W // 8) >= self.wide_min_windows
         return ok
 
+    # round 5: the deep stages (C = 768 / 1536: stage 3, and stage 4 of tulip_large) as four sliced launches per block and direction
+    # (csrc/swind.hip; + the two LayerNorm backward launches) instead of the 15 / 16-launch sequences.  TULIP_FUSE_DEEP=0: the sequences;
+    # TULIP_FUSE_DEEP_MAX_WINDOWS: above that many windows per launch the GEMM sequence runs (its tiles fill the chip there)
+    fuse_deep = os.environ.get("TULIP_FUSE_DEEP", "1") != "0"
+    deep_max_windows = int(os.environ.get("TULIP_FUSE_DEEP_MAX_WINDOWS", "1000000"))
+
+    def _fusable_deep(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
+        ok = (self.fuse_deep and sp.C in (768, 1536) and sp.nh * 32 == sp.C and self.hidden(sp.C) == 4 * sp.C
+              and tuple(sp.win) in ((2, 8), (1, 16)) and sp.H % sp.win[0] == 0 and sp.W % sp.win[1] == 0)
+        if ok and B is not None:
+            ok = B * (sp.H // sp.win[0]) * (sp.W // sp.win[1]) <= self.deep_max_windows
+        return ok
+
     def _fused_bwd(self, sp: BlockSpec, B: int) -> bool:
-        return (self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
+        return ((self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
+                or self._fusable_deep(sp, B))
 
     fuse_splitk_ln = os.environ.get("TULIP_FUSE_SPLITK_LN", "1") != "0"
     fuse_tail_bwd = os.environ.get("TULIP_FUSE_TAIL_BWD", "1") != "0"      # head backward without the d(expand) tensor
@@ -567,7 +582,8 @@ class TulipEngine:
     _tail_fused = False
 
     def _unfused(self, sp: BlockSpec, B: int) -> bool:
-        return not ((self.fuse_wide and self._fusable_wide(sp, B)) or (self.fuse_block96 and self._fusable96(sp)))
+        return not ((self.fuse_wide and self._fusable_wide(sp, B)) or (self.fuse_block96 and self._fusable96(sp))
+                    or self._fusable_deep(sp, B))
 
     def _gemm_resid_ln(self, A, Wt, M, N, K, *, lda, ldb, bias, out, aux, rowscale, tok, ln, out2=None):
         """Linear + DropPath residual (EPI_RESID_F32) followed by a LayerNorm of its output rows, ln = (gamma, beta, xn, mean,
@@ -597,6 +613,28 @@ class TulipEngine:
         B, C, nh = P.B, sp.C, sp.nh
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
         wide = self.fuse_wide and self._fusable_wide(sp, B)
+        if self._fusable_deep(sp, B):
+            # four sliced launches (csrc/swind.hip: by heads, by output channels, by hidden channels, by output channels); same
+            # tensors as the sequence
+            self._join_pack(p)
+            keep = (".o", ".x1", ".g")              # pass from launch to launch: written in the inference form too
+            sv = (lambda k: P[p + k] if k in keep else None) if self._no_save else (lambda k: P[p + k])
+            wf = W_.p16p
+            ops.swind_block_fwd(
+                C, sp.win, out_bf16=out_bf16,
+                x_in=xin, x1=sv(".x1"), x_out=xout, xn1=sv(".xn1"), qkv=sv(".qkv"), attn_out=sv(".o"),
+                xn2=sv(".xn2"), fc1_pre=sv(".h"), fc1_act=sv(".g"), mean1=sv(".mean1"),
+                rstd1=sv(".rstd1"), mean2=sv(".mean2"), rstd2=sv(".rstd2"),
+                w_qkv=wf(p + ".attn.qkv.weight"), w_proj=wf(p + ".attn.proj.weight"),
+                w_fc1=wf(p + ".mlp.fc1.weight"), w_fc2=wf(p + ".mlp.fc2.weight"),
+                b_qkv=W_.p32(p + ".attn.qkv.bias"), b_proj=W_.p32(p + ".attn.proj.bias"),
+                b_fc1=W_.p32(p + ".mlp.fc1.bias"), b_fc2=W_.p32(p + ".mlp.fc2.bias"),
+                norm1_weight=W_.p32(p + ".norm1.weight"), norm1_bias=W_.p32(p + ".norm1.bias"),
+                norm2_weight=W_.p32(p + ".norm2.weight"), norm2_bias=W_.p32(p + ".norm2.bias"),
+                bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
+                drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=B, H=sp.H, W=sp.W,
+                shift_h=sp.sft[0], shift_w=sp.sft[1], masked=self._mask_arg(sp, B), eps=self.eps)
+            return
         if wide or (self.fuse_block96 and self._fusable96(sp)):
             # the whole block in one launch (csrc/swin96.hip, csrc/swinw.hip); writes the same tensors as the sequence below
             if wide:
@@ -1199,6 +1237,42 @@ class TulipEngine:
         M, Hd, tok = B * sp.H * sp.W, self.hidden(sp.C), sp.H * sp.W
         dxn, dO, dh, dqkv = P["t.dxn"], P["t.do"], P[p + ".dh"], P[p + ".dqkv"]
         dyb = P[p + ".dyb_m"]
+        if self._fusable_deep(sp, B):
+            # csrc/swind.hip: fc2' + GELU' (by hidden channels) -> fc1' (by output channels) -> norm2' -> proj' + attention' (by heads)
+            # -> qkv' (by output channels) -> norm1'; the LayerNorm backward launches are the sequence's own, fed one fp32 "slab"
+            dn = P.scratch("deep.dxn", max(P.B * q.H * q.W * q.C for q in self.blocks if self._fusable_deep(q, P.B)))
+            R = ops.swind_groups(C, B, sp.H, sp.W, sp.win)
+            apart = P.scratch("apart." + p, R * nh * 256)
+            wt = W_.p16t
+            desc = dict(
+                dx=dx, x_in=xin, x1=P[p + ".x1"], qkv=P[p + ".qkv"], fc1_pre=P[p + ".h"], mean1=P[p + ".mean1"],
+                rstd1=P[p + ".rstd1"], mean2=P[p + ".mean2"], rstd2=P[p + ".rstd2"],
+                w_qkv=wt(p + ".attn.qkv.weight"), w_proj=wt(p + ".attn.proj.weight"),
+                w_fc1=wt(p + ".mlp.fc1.weight"), w_fc2=wt(p + ".mlp.fc2.weight"),
+                norm1_weight=W_.p32(p + ".norm1.weight"), norm2_weight=W_.p32(p + ".norm2.weight"),
+                bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
+                drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), d_out_mlp=dyb, d_fc1_pre=dh,
+                d_out_attn=P[p + ".dyb_a"], d_qkv=dqkv, bias_partials=apart, B=B, H=sp.H, W=sp.W, shift_h=sp.sft[0],
+                shift_w=sp.sft[1], masked=self._mask_arg(sp, B))
+            ops.swind_block_bwd(C, sp.win, dn, phases=3, **desc)
+            self._release_deferred()
+            self._wgrad(dyb, C, P[p + ".g"], Hd, C, Hd, M, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"))
+            self._wgrad(dh, Hd, P[p + ".xn2"], C, Hd, C, M, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"))
+            self._ln_bwd(P, None, P[p + ".x1"], P[p + ".mean2"], P[p + ".rstd2"], W_.p32(p + ".norm2.weight"), dx, dx, M, C,
+                         G(p + ".norm2.weight"), G(p + ".norm2.bias"), p + ".2", cast=(P[p + ".dyb_a"], self._ds(P, sp, 0), tok),
+                         slabs=(dn, 1))
+            ops.swind_block_bwd(C, sp.win, dn, phases=12, **desc)
+            self._wgrad(P[p + ".dyb_a"], C, P[p + ".o"], C, C, C, M, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"))
+            self._fold_bias_table(P, p, apart, R, nh, G(p + ".attn.relative_position_bias_table"))
+            self._ln_bwd(P, None, xin, P[p + ".mean1"], P[p + ".rstd1"], W_.p32(p + ".norm1.weight"), dx, dx, M, C,
+                         G(p + ".norm1.weight"), G(p + ".norm1.bias"), p + ".1", cast=next_cast, slabs=(dn, 1))
+            self._wgrad(dqkv, 3 * C, P[p + ".xn1"], C, 3 * C, C, M, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"))
+            if self._lagged_hook is not None:
+                fn, self._lagged_hook = self._lagged_hook, None
+                fn()
+            if self.flush_per_block or sp.prefix in self.flush_after:
+                self._flush_wgrads()
+            return
         if self._fused_bwd(sp, B):
             # the whole data-gradient chain of the block in one launch (csrc/swin96.hip, csrc/swinw.hip); the weight
             # gradients and the folds of its per-workgroup partial rows run beside the chain exactly as for the unfused

@@ -457,6 +457,40 @@ def swinw_block_bwd(C, exchange=None, **kw):
     check(_lib.load().tulip_swinw_block_bwd(ctypes.byref(d), C, _stream()), "tulip_swinw_block_bwd")
 
 
+def swind_supported(C, H, W, win) -> bool:
+    return bool(_lib.load().tulip_swind_supported(C, H, W, int(win[0]), int(win[1])))
+
+
+def swind_groups(C, B, H, W, win) -> int:
+    """tulip_swind_groups: window groups of a deep-stage block launch = partial rows of its backward."""
+    return _lib.load().tulip_swind_groups(C, B, H, W, int(win[0]), int(win[1]))
+
+
+def swind_block_fwd(C, win, out_bf16=None, phases=15, stamps=None, **kw):
+    """tulip_swind_block_fwd (C = 768 / 1536): keyword arguments are the fields of tulip_swin96_desc; w_* fragment-major copies."""
+    d = _lib.Swin96Desc()
+    for name, _t in _lib.Swin96Desc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    check(_lib.load().tulip_swind_block_fwd(ctypes.byref(d), C, int(win[0]), int(win[1]), _p(out_bf16), phases, _p(stamps),
+                                            _stream()), "tulip_swind_block_fwd")
+
+
+def swind_block_bwd(C, win, d_norm_out, phases=15, stamps=None, **kw):
+    """tulip_swind_block_bwd: fields of tulip_swin96_bwd_desc; w_* fragment-major copies of the TRANSPOSED weights; d_norm_out:
+    fp32 [M][C] scratch that phases 2 / 8 fill for tulip_layernorm_bwd_splitk."""
+    d = _lib.Swin96BwdDesc()
+    for name, _t in _lib.Swin96BwdDesc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    check(_lib.load().tulip_swind_block_bwd(ctypes.byref(d), C, int(win[0]), int(win[1]), _p(d_norm_out), phases, _p(stamps),
+                                            _stream()), "tulip_swind_block_bwd")
+
+
 def pack_items(entries):
     """[(src address, dst address, rows, cols, transpose)] -> ctypes array for pack_bf16_multi (build once, launch often)."""
     return ((_lib.PackItem * max(len(entries), 1))(*[_lib.PackItem(_p(s), _p(d), r, c, int(t)) for s, d, r, c, t in entries]),
