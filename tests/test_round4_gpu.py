@@ -41,7 +41,7 @@ def _grads_vs_oracle_banded(cfg, sd, lo, hi, B):
     _, _, _, ol = O.tulip_loss_and_grads(sd, cfg, lo, hi, lowp=True)
     assert abs(P.losses[0].item() - oloss.item()) <= 1e-3 * oloss.item()
     W_ = eng.params
-    worst, worst_band, worst_ratio = 0.0, 0.0, 0.0
+    worst, worst_band, worst_ratio, ratios = 0.0, 0.0, 0.0, []
     for n in W_.names:
         g = g1[W_.offset[n]:W_.offset[n] + W_.numel[n]].view(W_.shape[n])
         e, band = rel_l2(g, og[n]), rel_l2(ol[n], og[n])
@@ -50,6 +50,13 @@ def _grads_vs_oracle_banded(cfg, sd, lo, hi, B):
             continue
         assert e <= max(2e-2, 1.5 * band), (n, e, band)
         worst, worst_band, worst_ratio = max(worst, e), max(worst_band, band), max(worst_ratio, e / max(band, 1e-9))
+        ratios.append(e / max(band, 1e-9))
+    # the band is sized for the worst tensor; the TYPICAL tensor must sit where the oracle's own rounding model sits (a systematic
+    # bias of the HIP path would move every ratio, not just the largest)
+    med = float(np.median(ratios))
+    print(f"error / (oracle bf16 model vs fp32): median {med:.3f}, 90th percentile {float(np.percentile(ratios, 90)):.3f}, "
+          f"max {worst_ratio:.3f}")
+    assert med <= 1.25, med
     assert rel_l2(g2 * 2, g1) <= 4e-3              # linear in the upstream loss scale
     return worst, worst_band, eng
 
