@@ -162,7 +162,7 @@ def kernel_rooflines(trainer, reps=5):
         rec.append(("gemm", name, lambda: real["gemm"](A, B, M, N, K, **kw), f, by, by))
         real["gemm"](A, B, M, N, K, **kw)
 
-    def wgrad_group(items, extra, ws, ws_bytes, fold=True, adam=None):
+    def wgrad_group(items, extra, ws, ws_bytes, fold=True, adam=None, small_tiles=False):
         items = list(items)
         f = by = slab = 0.0
         tiles, deep = 0, True
@@ -179,12 +179,12 @@ def kernel_rooflines(trainer, reps=5):
                 by += 22.0 * it.Nw * it.Kw
             slab += 2.0 * it.Mtok * (it.Nw + it.Kw) + 4.0 * (it.Nw * it.Kw + it.Nw) * eff      # what the launch writes: slabs
         ksub = 4 if (tiles <= 400 and deep) else 1
-        big = all(ops.wgrad_tiles(it.Nw, it.Kw) != -(-it.Nw // 64) * -(-it.Kw // 96) and it.Mtok % 32 == 0 for it in items)
+        big = all(ops.wgrad_tiles(it.Nw, it.Kw, small_tiles) != -(-it.Nw // 64) * -(-it.Kw // 96) and it.Mtok % 32 == 0 for it in items)
         # the weight gradients of a stage leave as ONE grouped launch; timed without its fold (the `fold` family)
         rec.append(("wgrad", "wgrad_group_kernel (192x192 / 384x96 / 96x384 tiles)" if big
                     else f"gemm_group_kernel<64, true, true, {ksub}>",
-                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False, adam=adam), f, by, slab))
-        real["wgrad_group"](items, extra, ws, ws_bytes, fold, adam)
+                    lambda: real["wgrad_group"](items, [], ws, ws_bytes, fold=False, adam=adam, small_tiles=small_tiles), f, by, slab))
+        real["wgrad_group"](items, extra, ws, ws_bytes, fold, adam, small_tiles)
 
     def block(name, fam, bwd, C_of):
         def f(*a, **kw):
@@ -841,6 +841,18 @@ def main():
         out["config"]["grad_allreduce_dtype"] = grad_dtype
     # a repeat after a failed attempt (spawn_ranks' ladder): say so in the line itself
     attempts = json.loads(os.environ.get("TULIP_BENCH_ATTEMPTS", "[]"))
+    # what the timed step WAS, readable without opening `comm`: one captured graph (N = 1), graph segments cut at the bucket
+    # points with each bucket's last side group as a detached graph (the N > 1 default), the same without the detached graphs
+    # (first rung of the retry ladder), or eager launches (last rung / --no-graph)
+    segs = len(trainer._segments[True]) if getattr(trainer, "_segments", None) else 0
+    dets = len(getattr(trainer, "_det_graphs", {}))
+    out["config"]["step_structure"] = {
+        "form": ("eager" if not trainer.use_graph else "one_graph" if segs <= 1 and not dets else
+                 "segments+detached_buckets" if dets else "segments"),
+        "graph_segments": segs, "detached_bucket_graphs": dets,
+        "optimizer": ("in_weight_gradient_write_out" if world == 1 and getattr(trainer, "fuse_adamw", False) else
+                      "per_bucket" if getattr(trainer, "bucket_adamw", False) else "end_of_step"),
+        "ladder_rung": len(attempts), "after_failed": [a.get("attempt", a) if isinstance(a, dict) else a for a in attempts]}
     if attempts or fallback:
         out["graph_path_failed"] = True
         out["attempts"] = attempts

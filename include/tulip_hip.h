@@ -8,8 +8,9 @@
  * Conventions
  *   - plain pointers + sizes; every buffer is owned by the caller and lives in device memory.
  *   - bf16 tensors are uint16_t (raw bits), row-major, innermost dimension contiguous.
- *   - every call is asynchronous on `stream`, allocates nothing, keeps no global state, performs
- *     no synchronisation and is legal under HIP-graph capture.
+ *   - every call is asynchronous on `stream`, allocates nothing, keeps no global state (the library has no mutable
+ *     globals, no setters and reads no environment variable: measurement switches are per-call flag bits), performs
+ *     no synchronisation, is re-entrant and is legal under HIP-graph capture.
  *   - return value: 0 on success, TULIP_ERR_ARG (-1) for an unsupported argument combination,
  *     -(1000 + hipError_t) if the launch failed.  Nothing throws, nothing exits.
  *   - "stream" tensors (the residual stream) are fp32 (B,H,W,C); GEMM operands are bf16 with
@@ -53,7 +54,18 @@ typedef struct ihipStream_t* hipStream_t;
  * applies the epilogue.  workspace may be NULL when splits == 1.
  * Weight-gradient form (a_trans=1, epi SPLIT_F32 or F32): if out2 != NULL it additionally receives
  * the row sums of opA, i.e. sum over tokens of dY = the bias gradient, as fp32 [splits][M] (SPLIT) or
- * [M] (F32, += when accumulate) -- computed by one extra MFMA per fragment against an all-ones operand. */
+ * [M] (F32, += when accumulate) -- computed by one extra MFMA per fragment against an all-ones operand.
+ * `accumulate` is a flag word: TULIP_GEMM_ACCUMULATE (bit 0, the 0 / 1 of earlier versions); TULIP_GEMM_NO_TOUCH: skip the
+ * split first touch of the cold [96][k range] weight panel that the M-tile workgroups of an N panel perform before their k
+ * loops (forward / data-gradient form); TULIP_GEMM_CHECKED: the bounds-checked kernels even where whole tiles allow the
+ * unchecked ones.  The last two are measurement / bit-compare switches: results are identical either way. */
+#define TULIP_GEMM_ACCUMULATE 1
+#define TULIP_GEMM_NO_TOUCH 0x100
+#define TULIP_GEMM_CHECKED 0x200
+/* the 192 x 192 loader-wave kernel of the mid-size shapes (M >= 1024, >= 160 such tiles, K range a multiple of 64): never /
+ * wherever it fits (A/B measurements and the bit-compare test; the two kernels sum k in the same order per output element) */
+#define TULIP_GEMM_NO_MID 0x400
+#define TULIP_GEMM_MID 0x800
 int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,
                     int epi, const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                     const float* rowscale, int rows_per_sample, int accumulate, int psH, int psW, int splits,
@@ -77,11 +89,15 @@ int tulip_reduce_rows_multi(const tulip_reduce_region* regions, int n, hipStream
  * nn.Linear, tulip.py:298,318,195,198):  dW[Nw][Kw] += dY[Mtok][Nw]^T . X[Mtok][Kw],  db[Nw] += sum_tokens dY.
  * One grouped GEMM launch covers all items (token dimension cut `splits` ways into fp32 slabs in `workspace`, or
  * accumulated in place when splits == 1), one tulip_reduce_rows_multi launch folds the slabs -- and the `extra`
- * regions (LayerNorm / bias-table partial rows of the same block) ride along in that launch.  fold = 0 skips the
- * second launch and leaves the slabs in the workspace (profiling the GEMM alone).  A launch is sized by its caller to
+ * regions (LayerNorm / bias-table partial rows of the same block) ride along in that launch.  `fold` is a flag word:
+ * without TULIP_WGRAD_FOLD (bit 0, the 0 / 1 of earlier versions) the second launch is skipped and the slabs stay in the
+ * workspace; TULIP_WGRAD_SMALL_TILES forces the 64 x 96 tile everywhere (A/B measurements; tulip_wgrad_tiles takes the
+ * same word).  A launch is sized by its caller to
  * about one workgroup per CU in total (`splits`), so the slab traffic is per LAUNCH, not per linear: the engine puts a
  * whole stage (two Swin blocks + boundary linears, up to 12 items) into one. */
 #define TULIP_WGRAD_GROUP_MAX 16
+#define TULIP_WGRAD_FOLD 1
+#define TULIP_WGRAD_SMALL_TILES 0x100
 typedef struct tulip_wgrad_item {
     const void* dY; const void* X; float* dW; float* db;
     int ldy; int ldx; int Nw; int Kw; int Mtok; int splits;
@@ -117,12 +133,13 @@ int tulip_wgrad_group_regions(const tulip_wgrad_item* items, int n, void* worksp
 
 /* Workgroup tiles per token split the grouped launch uses for a [Nw][Kw] weight gradient (192 x 192 per workgroup where
  * both dimensions are multiples of 192, 384 x 96 / 96 x 384 for the 96-wide stage, else 64 x 96): what a caller sizes
- * `splits` with.  tulip_wgrad_set_mode(0) forces the 64 x 96 tile everywhere (A/B measurements); default 1. */
-int tulip_wgrad_tiles(int Nw, int Kw);
-int tulip_wgrad_set_mode(int mode);
-/* Profiling: a device buffer of 4 x uint64 per workgroup of the next large-tile launches (shader-clock stamps: start, end
- * of the pipeline prologue, end of the k-loop, end of the write-out), or NULL to stop. */
-int tulip_wgrad_set_profile(void* stamps);
+ * `splits` with.  flags: the `fold` word of the launch it is sized for (TULIP_WGRAD_SMALL_TILES matters). */
+int tulip_wgrad_tiles(int Nw, int Kw, int flags);
+/* Profiling twin (tools/wgrad_phases.py): the grouped launch alone -- no fold, no optimizer step -- writing 4 x uint64 per
+ * workgroup of a large-tile launch into `stamps` (shader clock: start, end of the pipeline prologue, end of the k loop, end
+ * of the write-out). */
+int tulip_wgrad_group_profiled(const tulip_wgrad_item* items, int n, void* workspace, int64_t workspace_bytes, int flags,
+                               void* stamps, hipStream_t stream);
 
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);
@@ -220,6 +237,9 @@ int tulip_patch_embed_bwd_blocks(int ntok);
  * of the fc1 pre-activation h itself -- the derivative is all the backward wants from h (autograd of tulip.py:196), and the
  * forward has erf and the Gaussian at hand.  Forward and backward of a block must agree on it. */
 #define TULIP_BLOCK_FC1_GRAD 4
+/* bit 3, tulip_swinw_block_fwd / _bwd (+ split forms) only: skip the L2 warm-up at the head of the launch (below; measurement
+ * and the bit-compare test only, results are identical either way) */
+#define TULIP_BLOCK_NO_WARM 8
 int tulip_window_attn_fwd(const uint16_t* qkv, const float* bias_table, const int32_t* rel_index, uint16_t* out, int B,
                           int H, int W, int C, int nh, int wh, int ww, int sh, int sw, int masked, hipStream_t stream);
 /* dqkv from dout.  d(bias) leaves as R = tulip_window_attn_bwd_partial_rows(...) partial rows per head:
@@ -506,13 +526,8 @@ int tulip_swinw_block_fwd_split(const tulip_swin96_desc* d, int C, void* out_bf1
 int tulip_swinw_bwd_partial_rows(int C, int B, int H, int W);
 /* Launches of at most 256 workgroups (the whole grid resident at once) start by spreading the block's weights over the
  * L2 of each XCD (every wave touches a few KiB nobody else touches): in a training step the weights are cold, and the
- * per-wave streams would otherwise run at miss latency (tools/cold_probe.py).  on = 0 switches that off (measurement
- * only; results are identical either way).  Process-wide, not re-entrant against concurrent launches. */
-int tulip_swinw_set_warm(int on);
-/* The same first touch in tulip_gemm_bf16 (forward / data-gradient form: the M-tile workgroups of an N panel split the
- * cold [96][k range] weight panel between them before their k loops start).  on = 0 switches it off (measurement and the
- * bit-compare test only; results are identical either way).  Process-wide. */
-int tulip_gemm_set_touch(int on);
+ * per-wave streams would otherwise run at miss latency (tools/cold_probe.py).  TULIP_BLOCK_NO_WARM in d->masked switches
+ * that off for one launch.  (tulip_gemm_bf16 has the same first touch of its weight panel: TULIP_GEMM_NO_TOUCH.) */
 int tulip_swinw_block_bwd(const tulip_swin96_bwd_desc* d, int C, hipStream_t stream);
 /* split form of the backward (see tulip_swinw_block_fwd_split; the same exchange buffer may serve both directions of a block):
  * the MLP half's hidden channels are halved between the two workgroups of a window, the partial sums of d(norm2 output) meet in
@@ -550,7 +565,7 @@ int tulip_swind_block_bwd(const tulip_swin96_bwd_desc* d, int C, int wh, int ww,
 int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream);
 /* Layout version of the structs and signatures in this header (round 3: tulip_wgrad_item, tulip_reduce_region and tulip_adamw_ref grew
  * fields, entry points were added): a caller built against another version must not bind. */
-#define TULIP_ABI_VERSION 4
+#define TULIP_ABI_VERSION 5
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);
 

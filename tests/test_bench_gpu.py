@@ -24,6 +24,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["config"]["step_structure"]["form"] == "one_graph"
+    assert d["config"]["step_structure"]["optimizer"] == "in_weight_gradient_write_out"
     assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3      # whole-job img/s of batch 8
     assert d["step_ms_min"] <= d["step_ms_median"] <= 1.5 * d["ms_per_step"]
     ro = d["roofline"]

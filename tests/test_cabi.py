@@ -24,7 +24,7 @@ def test_library_builds_and_loads():
     path = build(force=False, verbose=False)
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.tulip_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.tulip_abi_version() == _lib.ABI_VERSION == 5
     assert lib.tulip_build_arch() == b"gfx950"
 
 

@@ -141,6 +141,9 @@ def test_bench_self_spawns_its_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["steps"] == 3 and d["warmup"] == 2 and d["value"] > 0
+    ss = d["config"]["step_structure"]          # what the timed step was, without opening `comm`
+    assert ss["form"] == "segments+detached_buckets" and ss["graph_segments"] >= 3 and ss["detached_bucket_graphs"] >= 3
+    assert ss["ladder_rung"] == 0 and ss["after_failed"] == []
     c = d["comm"]
     assert c["world_size_rccl"] == 2 and c["launcher"] == "bench.py spawn_ranks"
     assert c["collective_smoke"]["bucket"]["bytes"] == 66 << 20 and c["collective_smoke"]["bucket"]["busbw_GBps"] > 0
@@ -155,7 +158,6 @@ def test_gemm_panel_touch_changes_no_bit():
     torch.manual_seed(3)
     outs = {}
     for on in (True, False):
-        ops.gemm_set_touch(on)
         res = []
         for (M, N, K, bt) in [(512, 768, 768, False), (512, 768, 3072, False), (2048, 384, 1536, True), (32768, 96, 288, True),
                               (4096, 192, 192, False), (77, 96, 64, False)]:
@@ -166,13 +168,12 @@ def test_gemm_panel_touch_changes_no_bit():
             o16 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
             o32 = torch.zeros(M, N, device=DEV)
             ws = torch.zeros(8 * M * N, device=DEV)
-            ops.gemm(A, Wt, M, N, K, lda=K, ldb=N if bt else K, b_trans=bt, epi=EPI_BF16, bias=bias, out=o16, ldo=N)
+            ops.gemm(A, Wt, M, N, K, lda=K, ldb=N if bt else K, b_trans=bt, epi=EPI_BF16, bias=bias, out=o16, ldo=N, touch=on)
             ops.gemm(A, Wt, M, N, K, lda=K, ldb=N if bt else K, b_trans=bt, epi=EPI_F32, out=o32, ldo=N, splits=4,
-                     workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4)
+                     workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4, touch=on)
             torch.cuda.synchronize()
             res += [o16.clone(), o32.clone()]
         outs[on] = res
-    ops.gemm_set_touch(True)
     for a, b in zip(outs[True], outs[False]):
         assert torch.isfinite(a.float()).all() and a.float().abs().max() > 0
         assert torch.equal(a, b)

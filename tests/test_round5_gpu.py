@@ -114,3 +114,79 @@ def test_durlar_large_b8_train_step_vs_oracle():
     print(f"DurLAR tulip_large B=8 train mode: worst per-tensor gradient error vs fp32 oracle {worst:.3e}; error / (oracle bf16 model "
           f"vs fp32): median {med:.3f}, 90th percentile {float(np.percentile(ratios, 90)):.3f}, max {max(ratios):.3f}")
     assert med <= 1.25, med
+
+
+def test_foreign_optimizer_step_reaches_a_graphed_forward():
+    """the reference's calling convention -- model(lo, hi), loss.backward(), a torch optimizer's step()
+    (engine_upsampling.py:77-80, misc.py:295-305) -- writes the fp32 parameters AFTER the module forward has rebuilt the bf16
+    shadow.  A GraphedForward (or Trainer) that already exists and runs next (eval once per epoch) must see the stepped weights,
+    on the replayed module path as on the eager one: the module path leaves the shadow marked stale."""
+    from tulip_amd.infer import GraphedForward
+    cfg = O.tiny_config()
+    sd = O.key_seeded_state_dict(cfg, seed=5)
+    lo, hi = O.synthetic_batch(cfg, 2, seed=77)
+    lo, hi = lo.to(DEV), hi.to(DEV)
+    m = build(cfg, sd, train=True)
+    gf = GraphedForward(m, 2)
+    before = gf(lo).clone()
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-3)
+    for it in range(4):                       # call 1 eager, call 2 captures, calls 3-4 replay
+        pred, loss, _ = m(lo, hi)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        assert m.engine().params.shadow_dirty, it
+        m.eval()
+        got = gf(lo).clone()                  # the existing graph, no weights_changed() call
+        m.engine().params.refresh_shadow()
+        want = gf(lo).clone()                 # ... against a shadow rebuilt by hand from the stepped parameters
+        m.train()
+        assert torch.equal(got, want), it
+        assert not torch.equal(got, before), it
+        before = got
+
+
+def test_module_gradients_survive_and_accumulate_across_backward_calls():
+    """The autograd bridge hands out views of a buffer a captured graph writes (no 108-MB copy per step):
+    autograd keeps such a view as `.grad`, so (a) a second backward without zero_grad must ACCUMULATE (the reference's accum_iter
+    loop, engine_upsampling.py:91-99) -- it writes the other buffer; (b) gradients a caller kept alive from two calls force the
+    private buffer + copy; (c) with zero_grad(set_to_none) between steps the first buffer is reused.  Every call eager, captured
+    and replayed (calls 1 / 2 / 3+ of a key)."""
+    cfg = O.tiny_config()
+    sd = O.key_seeded_state_dict(cfg, seed=9)
+    lo, hi = O.synthetic_batch(cfg, 2, seed=31)
+    lo, hi = lo.to(DEV), hi.to(DEV)
+    m = build(cfg, sd, train=False)
+    params = [p for p in m.parameters()]
+
+    def backward_once():
+        _, loss, _ = m(lo, hi)
+        loss.backward()
+        torch.cuda.synchronize()
+
+    backward_once()
+    g1 = [p.grad.clone() for p in params]
+    assert all(torch.isfinite(g).all() for g in g1) and sum(g.abs().sum().item() for g in g1) > 0
+    for rep in range(2, 6):                                   # (a): .grad holds buffer 0, calls 2.. write buffer 1
+        backward_once()
+        for p, g in zip(params, g1):
+            assert torch.allclose(p.grad, rep * g, rtol=1e-5, atol=1e-7), rep
+    kept = [p.grad for p in params]                           # (b): the caller keeps these alive (they alias buffer 0) ...
+    for p in params:
+        p.grad = None
+    backward_once()                                           # ... this one takes buffer 1 ...
+    kept2 = [p.grad for p in params]
+    for p in params:
+        p.grad = None
+    backward_once()                                           # ... and this one must not touch either
+    for p, k, k2, g in zip(params, kept, kept2, g1):
+        assert torch.allclose(k, 5 * g, rtol=1e-5, atol=1e-7) and torch.equal(k2, g) and torch.equal(p.grad, g)
+    del kept, kept2, k, k2                                    # (the loop variables alias the two buffers too)
+    P = m.engine().plan(2)
+    for it in range(4):                                       # (c): the training loop's pattern
+        for p in params:
+            p.grad = None
+        backward_once()
+        assert params[0].grad.untyped_storage().data_ptr() == P._mod_gbufs[0].untyped_storage().data_ptr()
+        for p, g in zip(params, g1):
+            assert torch.equal(p.grad, g)

@@ -33,6 +33,7 @@ def _model(kind, rows, cols, seed):
             if p.ndim == 1 or "relative_position_bias_table" in n:
                 p.add_(0.2 * torch.randn_like(p))
     eng = m.engine()
+    eng.deep_min_windows, eng.deep_max_windows = 1, 1 << 30     # (the engine's window-count gate is a speed choice: every size here)
     eng.bind(torch.device(DEV, torch.cuda.current_device()))
     eng.params.refresh_shadow()
     return m, eng

@@ -213,7 +213,7 @@ def test_l2_warm_up_changes_no_bit(stage, B):
     p = sp.prefix
     res = {}
     for warm in (0, 1):
-        ops.swinw_set_warm(warm)
+        eng.no_warm = not warm           # TULIP_BLOCK_NO_WARM in the launch descriptor (per call: the library has no switches)
         out = torch.empty(M, sp.C, device=DEV)
         eng._block_fwd(P, sp, xin, out)
         dx = torch.randn(M, sp.C, device=DEV, generator=torch.Generator(DEV).manual_seed(5))
@@ -225,7 +225,7 @@ def test_l2_warm_up_changes_no_bit(stage, B):
         torch.cuda.synchronize()
         res[warm] = [out.clone(), dx.clone(), gflat.clone()] + [P[p + s].clone() for s in
                                                                (".xn1", ".qkv", ".o", ".xn2", ".h", ".g", ".dh", ".dqkv")]
-    ops.swinw_set_warm(1)
+    eng.no_warm = False
     for a, b in zip(res[0], res[1]):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)
 

@@ -27,6 +27,7 @@ def main():
     m = f(img_size=(a.rows, a.cols), target_img_size=(4 * a.rows, a.cols), patch_size=(1, 4), in_chans=1, window_size=[2, 8],
           pixel_shuffle=True, circular_padding=True, log_transform=True, patch_unmerging=True).to(dev).train()
     eng = m.engine()
+    eng.deep_min_windows, eng.deep_max_windows = 1, 1 << 30     # (measure the sliced form at every size, whatever the engine's gate)
     eng.bind(dev)
     eng.params.refresh_shadow()
     B = a.batch

@@ -14,8 +14,10 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 ws = torch.empty((Engine.WS_ELEMS + (1 << 20)), device=dev)
 
+SMALL = False      # TULIP_WGRAD_SMALL_TILES on the launches below (mode 0)
+
 def run(items, fold):
-    ops.wgrad_group(items, [], ws, ws.numel() * 4, fold=fold)
+    ops.wgrad_group(items, [], ws, ws.numel() * 4, fold=fold, small_tiles=SMALL)
 
 def timeit(items, fold, reps):
     run(items, fold); run(items, fold)
@@ -38,18 +40,17 @@ for B in a.batch:
         fl = sum(2.0 * tok * Nw * Kw for Nw, Kw in shapes)
         line = f"B={B:3d} C={C:3d} tok={tok:6d}"
         for mode in a.modes:
-            ops.wgrad_set_mode(mode)
+            SMALL = not (mode & 1)
             items, nwg, slab = [], 0, 0
-            gt = sum(ops.wgrad_tiles(Nw, Kw) for Nw, Kw in shapes) if mode & 1 else 0
+            gt = sum(ops.wgrad_tiles(Nw, Kw, SMALL) for Nw, Kw in shapes) if mode & 1 else 0
             sps = [Engine._splits(Nw, Kw, tok, group_tiles=gt) for Nw, Kw in shapes]
             while sum((Nw * Kw + Nw) * sp * 4 for (Nw, Kw), sp in zip(shapes, sps) if sp > 1) > ws.numel() * 4:
                 sps = [max(1, sp // 2) for sp in sps]       # (the engine starts a second launch instead)
             for (Nw, Kw), (dY, X, dW, db), sp in zip(shapes, bufs, sps):
-                nwg += ops.wgrad_tiles(Nw, Kw) * sp
+                nwg += ops.wgrad_tiles(Nw, Kw, SMALL) * sp
                 slab += Nw * Kw * 4 * sp if sp > 1 else 0
                 items.append(ops.wgrad_item(dY, Nw, X, Kw, Nw, Kw, tok, dW, db, sp))
             t0 = timeit(items, False, a.reps)
             t1 = timeit(items, True, a.reps)
             line += f" | mode {mode:#x}: {nwg:5d} wg, slabs {slab / 1e6:6.1f} MB, gemm {t0:7.1f} us ({fl / t0 / 1e6:6.1f} TF/s), +fold {t1:7.1f} us"
         print(line, flush=True)
-ops.wgrad_set_mode(1)

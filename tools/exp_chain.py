@@ -42,7 +42,7 @@ def no_side(eng):
 def no_folds(eng):
     from tulip_amd import ops
     real = ops.wgrad_group
-    ops.wgrad_group = lambda items, extra, ws, ws_bytes, fold=True, adam=None: real(items, [], ws, ws_bytes, fold=False, adam=adam)
+    ops.wgrad_group = lambda items, extra, ws, ws_bytes, fold=True, adam=None, small_tiles=False: real(items, [], ws, ws_bytes, fold=False, adam=adam, small_tiles=small_tiles)
     ops.reduce_rows_multi = lambda *a, **k: None
 
 

@@ -1,4 +1,4 @@
-"""Phase stamps of the large-tile weight-gradient kernel (tulip_wgrad_set_profile): per workgroup, s_memtime at start /
+"""Phase stamps of the large-tile weight-gradient kernel (tulip_wgrad_group_profiled): per workgroup, s_memtime at start /
 end of prologue / end of k-loop / end of write-out, for the grouped launch of one block.  The counters of different
 XCDs have different bases: only differences inside a workgroup mean something; the tick is about the shader clock
 (prologue + k-loop + write-out of the slowest workgroup ~ the kernel's duration x 1.7 GHz)."""
@@ -33,10 +33,8 @@ for B in a.batch:
         for _ in range(3):
             ops.wgrad_group(items, [], ws, ws.numel() * 4, fold=False)
         stamps = torch.zeros(nwg, 4, dtype=torch.int64, device=dev)
-        ops.wgrad_set_profile(stamps)
-        ops.wgrad_group(items, [], ws, ws.numel() * 4, fold=False)
+        ops.wgrad_group_profiled(items, ws, ws.numel() * 4, stamps)
         torch.cuda.synchronize()
-        ops.wgrad_set_profile(None)
         s = stamps.cpu().double()
         rel = s
         ksteps = [tok // sp // 32 for sp in sps]

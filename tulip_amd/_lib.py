@@ -61,7 +61,8 @@ class PackItem(ctypes.Structure):
 
 
 REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 64
-ABI_VERSION = 4      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
+GEMM_NO_TOUCH, GEMM_CHECKED, GEMM_NO_MID, GEMM_MID, WGRAD_SMALL_TILES, BLOCK_NO_WARM = 0x100, 0x200, 0x400, 0x800, 0x100, 8     # per-call flag bits (tulip_hip.h)
+ABI_VERSION = 5      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -77,8 +78,6 @@ SIGNATURES = {
     "tulip_swinw_split_bytes": [I, I, I, I],
     "tulip_swinw_block_fwd_split": [P, I, P, P, ctypes.c_size_t, P, P],
     "tulip_swinw_bwd_partial_rows": [I, I, I, I],
-    "tulip_swinw_set_warm": [I],
-    "tulip_gemm_set_touch": [I],
     "tulip_swinw_block_bwd": [P, I, P],
     "tulip_swinw_block_bwd_split": [P, I, P, ctypes.c_size_t, P],
     "tulip_swind_supported": [I, I, I, I, I],
@@ -106,11 +105,10 @@ SIGNATURES = {
     "tulip_reduce_rows_multi": [P, I, P],
     "tulip_reduce_rows_multi_adamw": [P, I, P, P],
     "tulip_wgrad_group": [P, I, P, I, P, L, I, P],
-    "tulip_wgrad_tiles": [I, I],
+    "tulip_wgrad_tiles": [I, I, I],
     "tulip_wgrad_group_regions": [P, I, P, P, I],
     "tulip_wgrad_group_adamw": [P, I, P, I, P, L, I, P, P],
-    "tulip_wgrad_set_mode": [I],
-    "tulip_wgrad_set_profile": [P],
+    "tulip_wgrad_group_profiled": [P, I, P, L, I, P, P],
     "tulip_gemm_effective_splits": [I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_cast_bf16_f32": [P, P, L, P],

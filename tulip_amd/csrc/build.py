@@ -20,15 +20,26 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+ASAN_LIB = os.path.join(PKG, "libtulip_hip_asan.so")
+
+
+def build(force: bool = False, verbose: bool = True, asan: bool = False) -> str:
+    """asan=True (`--asan`): the AddressSanitizer build, libtulip_hip_asan.so -- host code AND kernels instrumented
+    (`-fsanitize=address -shared-libsan`, device side needs the xnack+ target; INTEGRATION.md, "Sanitizer build")."""
+    if asan:
+        return _build(ASAN_LIB, "_asan", ["-fsanitize=address", "-shared-libsan", "-g", "-O1"], f"{ARCH}:xnack+", verbose)
     if not force and not _stale():
         return LIB
+    return _build(LIB, "", ["-O3"], ARCH, verbose)
+
+
+def _build(LIB: str, suffix: str, flags, ARCH: str, verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(HERE, s.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+        o = os.path.join(HERE, s.replace(".hip", suffix + ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", *flags, "-std=c++17", "-fPIC", "-Wno-unused-value",
                "-I", os.path.join(ROOT, "include"), "-I", HERE, "-c", os.path.join(HERE, s), "-o", o]
         cmd += os.environ.get("TULIP_HIPCC_FLAGS", "").split()      # dev: e.g. -DTULIP_GEMM_WSK=0 for an A/B build
         if verbose:
@@ -46,6 +57,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if failed:
         raise RuntimeError("hipcc failed")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if suffix == "_asan":
+        cmd += ["-fsanitize=address", "-shared-libsan"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -53,4 +66,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, asan="--asan" in sys.argv))

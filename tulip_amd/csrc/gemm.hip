@@ -54,15 +54,22 @@ struct GemmArgs {
     int rows_per_sample;
     int accumulate;
     int psH, psW;
-    int touch;   // first touch of the cold weight panel split between the M-tile workgroups (tulip_gemm_set_touch)
+    int touch;   // first touch of the cold weight panel split between the M-tile workgroups (off: TULIP_GEMM_NO_TOUCH)
+    int checked; // the bounds-checked kernels even for whole-tile shapes (TULIP_GEMM_CHECKED: bit-compare tests)
+    int mid;     // the 192 x 192 kernel for mid-size shapes: 1 = by the launcher's rule, 0 = never (TULIP_GEMM_NO_MID), 2 = wherever it fits (TULIP_GEMM_MID)
+    int vec_ok;  // the vectorised PixelShuffle / inverse-shuffle write-outs may be used: pitches and bases aligned for their 16-B / 4-B stores
 };
 
-int gemm_touch_on = 1;
-int gemm_full_on = getenv("TULIP_GEMM_FULL") ? atoi(getenv("TULIP_GEMM_FULL")) : 1;     // dev switch: 0 = the bounds-checked kernels everywhere
 
 // launch heuristics (compile-time; mirrored by bench.py's kernel-name bookkeeping)
 #define TULIP_GEMM_MID_TILES 512    // taller tiles only while the launch still has this many of them (two rounds of the chip)
 #define TULIP_GEMM_KSUB_GRID 400    // 128-deep k stages for grids up to this many workgroups
+#ifndef TULIP_GEMM_MID_MIN
+#define TULIP_GEMM_MID_MIN 160      // 192 x 192 tiles (x K splits) a launch needs for the mid-size kernel
+#endif
+#ifndef TULIP_GEMM_MID_MIN_M
+#define TULIP_GEMM_MID_MIN_M 1024
+#endif
 #ifndef TULIP_WGRAD_RING
 #define TULIP_WGRAD_RING 3
 #endif
@@ -420,7 +427,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
         __syncthreads();
-        if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_PIXSHUF2_F32 && (p.N & 31) == 0) {                        // (uniform)
+        if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_PIXSHUF2_F32 && (p.N & 31) == 0 && p.vec_ok) {                        // (uniform)
             // PixelShuffle(2) write-out, vectorised: an item is (row, sub-position q = 2i + j, 8 output channels) -- its eight values
             // sit 16 B apart in the staged row (columns 4c + q) and leave as ONE 16-byte bf16 store (+ two fp32 ones) into the fine
             // token (2h + i, 2w + j); epilogue8's form of it is eight scattered 2-byte stores per thread
@@ -450,7 +457,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
                     if (p.out2) *(uint4*)((bf16_t*)p.out2 + tok * p.ldo2 + cb) = pack8(v);
                 }
             }
-        } else if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_UNSHUF2_BF16 && !p.bias && (p.M & 1) == 0) {     // (uniform)
+        } else if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_UNSHUF2_BF16 && !p.bias && (p.M & 1) == 0 && p.vec_ok) {     // (uniform)
             // inverse shuffle: fine tokens 2w, 2w + 1 of one row (staged rows rl, rl + 1) are neighbours in the coarse token's
             // channel quadruple -- an item is (row pair, 8 columns): eight 4-byte stores instead of sixteen 2-byte ones
 #pragma unroll
@@ -832,6 +839,232 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgradGroup G) {
     }
 }
 
+// ---- forward / data-gradient GEMM, mid-size shapes (round 5) -----------------------------------------------------------
+// C[M][N] = A[M][K] . opB^T for M = 1 024 .. 16 384, N, K = 384 .. 6 144 (the deep stage at batch 64, stages 3-4 of tulip_large at
+// the 2048-wide grids): the 64 / 128 x 96 tiles of gemm_tile fetch every operand element N / 96 resp. M / BM times through a CU
+// whose address unit moves ~20 B/clk of 64-byte row pieces and read 7 fragments from LDS for 12 MFMAs.  Here the weight-gradient
+// kernel's shape: 192 x 192 outputs per workgroup, eight waves -- waves 0-3 own one 96 x 96 tile each (36 accumulator
+// fragments, 12 fragment reads for 36 MFMAs per 32 k), waves 4-7 only move operands: global -> a register ring of three
+// 64-deep stages (128-byte row pieces, one cache line per 8 lanes) -> double-buffered 32-deep LDS tiles.  A is k-fast
+// ([M][K]); B is k-fast ([N][K]: forward, y = x W^T) or k-slow ([K][N]: data gradient, dx = dy W; the k-slow LDS layout and
+// transpose reads of wgrad_tile).  Rows beyond M / N are clamped in the loads and dropped in the write-out; the K range of a
+// workgroup is a multiple of 64.  Write-out: every wave stages 32 rows of its tile at a time and runs epilogue8 on 8-column
+// chunks (all the epilogues of gemm_tile, split-K slabs included).
+constexpr int MID_A_BYTES = 192 * 64;                     // one 32-deep k-fast operand tile: [192 rows][64 B], 16-B chunks swizzled
+template <bool B_T>
+struct MidGeo {
+    static constexpr int B_BYTES = B_T ? 2 * WG_SUB : MID_A_BYTES;
+    static constexpr int STAGE = MID_A_BYTES + B_BYTES;   // one 32-deep LDS stage
+    static constexpr int STG = 4 * 32 * WG_STG_PITCH;     // write-out staging (after the k loop, same memory)
+    static constexpr int LDS = 2 * STAGE > STG ? 2 * STAGE : STG;
+};
+#ifndef TULIP_GEMM_MID_RING
+#define TULIP_GEMM_MID_RING 3
+#endif
+template <bool B_T>
+__device__ __forceinline__ void gemm_mid_tile(const GemmArgs& p, const int bx, const int by, const int bz,
+                                              unsigned char* __restrict__ smem) {
+    using Z = MidGeo<B_T>;
+    constexpr int STAGE = Z::STAGE;
+    constexpr int NR = TULIP_GEMM_MID_RING;
+    const int wid8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool loader = wid8 >= 4;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = wid8 & 3;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = by * 192, n0 = bx * 192;
+    const int kbeg = bz * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nt = (kend - kbeg) >> 5;                  // 32-deep steps: even (the launcher's condition)
+    const int ns = nt >> 1;                             // 64-deep register stages
+    if (ns <= 0) return;
+
+    if (loader) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        // A (and a k-fast B): a stage is [192 rows][128 B]; slot i of a thread = chunk (tid + 256 i): row = c >> 3, 16-B piece
+        // kc = c & 7 for slots 0-2 and (c & 7) ^ 4 for slots 3-5 -- 8 lanes still cover one 128-byte line, and every thread holds
+        // three chunks of EACH 32-deep half: half h is slots 0-2 for the lanes whose piece index has bit 2 == h, slots 3-5 for
+        // the others (a select per register, full-lane LDS writes).  k-slow B: a stage is [64 k][384 B], chunk c: k = c / 24 --
+        // slots 0-2 are k < 32, slots 3-5 the second half for every lane.
+        const bool lowhalf = ((tid & 7) < 4);
+        unsigned goffA[6], goffB[6];
+        int loffA[6], loffB[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 3, kc = (c & 7) ^ (i >= 3 ? 4 : 0);
+            const int ra = min(m0 + row, p.M - 1);
+            goffA[i] = (unsigned)ra * (unsigned)p.lda * 2u + (unsigned)kc * 16u;
+            loffA[i] = row * 64 + (((kc & 3) ^ swz4(row)) << 4);
+            if constexpr (!B_T) {
+                const int rb = min(n0 + row, p.N - 1);
+                goffB[i] = (unsigned)rb * (unsigned)p.ldb * 2u + (unsigned)kc * 16u;
+                loffB[i] = MID_A_BYTES + loffA[i];
+            } else {
+                const int k = c / 24, mc = c - k * 24;
+                const int sub = mc / 12, mcs = mc - sub * 12;
+                const int col = min(n0 + mc * 8, p.N - 8);
+                goffB[i] = (unsigned)k * (unsigned)p.ldb * 2u + (unsigned)col * 2u;
+                const int kk = k & 31;
+                loffB[i] = MID_A_BYTES + sub * WG_SUB + kk * T_PITCH + ((((mcs >> 1) ^ (((kk >> 3) & 1) << 2))) << 5) + ((mcs & 1) << 4);
+            }
+        }
+        const unsigned char* baseA = (const unsigned char*)(p.A + kbeg);
+        const unsigned char* baseB = B_T ? (const unsigned char*)(p.B + (size_t)kbeg * p.ldb) : (const unsigned char*)(p.B + kbeg);
+        u32x4_t ra[NR][6], rb[NR][6];
+        auto issue = [&](auto R, int s) {
+            constexpr int r = decltype(R)::value;
+            const unsigned char* a = baseA + (size_t)s * 128;
+            const unsigned char* b = B_T ? baseB + (size_t)s * 128 * p.ldb : baseB + (size_t)s * 128;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ra[r][i] = *(const u32x4_t*)(a + goffA[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rb[r][i] = *(const u32x4_t*)(b + goffB[i]);
+        };
+        // half h of register stage r -> the 32-deep LDS stage at dst
+        auto stash = [&](auto R, int h, unsigned char* dst) {
+            constexpr int r = decltype(R)::value;
+            const bool first = lowhalf == (h == 0);           // this lane's chunks of half h sit in slots 0-2 (else 3-5)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const u32x4_t v = first ? ra[r][i] : ra[r][i + 3];
+                *(u32x4_t*)(dst + (first ? loffA[i] : loffA[i + 3])) = v;
+            }
+            if constexpr (!B_T) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x4_t v = first ? rb[r][i] : rb[r][i + 3];
+                    *(u32x4_t*)(dst + (first ? loffB[i] : loffB[i + 3])) = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x4_t v = h == 0 ? rb[r][i] : rb[r][i + 3];
+                    *(u32x4_t*)(dst + (h == 0 ? loffB[i] : loffB[i + 3])) = v;
+                }
+            }
+        };
+        // (loads are issued unconditionally: past the end they re-read the last stage into a slot nobody stashes)
+        static_for<NR>([&](auto R) { issue(R, min((int)decltype(R)::value, ns - 1)); });
+        stash(std::integral_constant<int, 0>{}, 0, smem);
+        __syncthreads();
+        stash(std::integral_constant<int, 0>{}, 1, smem + STAGE);
+        __syncthreads();
+        // stage s (steps 2s, 2s+1): its ring slot is free (both halves went to LDS during stage s-1): refill it with stage
+        // s + NR; the halves of stage s + 1 go into the LDS buffers whose fragments the compute waves read one step earlier
+        auto stage = [&](auto R, int s) {
+            constexpr int r = decltype(R)::value;
+            issue(R, min(s + NR, ns - 1));
+            if (s + 1 < ns) stash(std::integral_constant<int, (r + 1) % NR>{}, 0, smem);
+            __syncthreads();
+            if (s + 1 < ns) stash(std::integral_constant<int, (r + 1) % NR>{}, 1, smem + STAGE);
+            __syncthreads();
+        };
+        for (int s = 0; s < ns; s += NR)
+            static_for<NR>([&](auto R) { if (s + decltype(R)::value < ns) stage(R, s + decltype(R)::value); });
+        return;
+    }
+
+    f32x4 acc[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, li = lane & 15;
+    const bool active = m0 + wm * 96 < p.M && n0 + wn * 96 < p.N;      // wave-uniform
+    bf16x8 fa[2][6], fb[6];
+    // k-fast fragment f of a 96-row operand block starting at row r0: rows r0 + 16 f + li, k slots 8 g .. 8 g + 7
+    auto readN = [&](const unsigned char* tile, int r0, int f) {
+        const int row = r0 + f * 16 + li;
+        return *(const bf16x8*)(tile + row * 64 + ((g ^ swz4(row)) << 4));
+    };
+    const int fbase = (g * 8 + (li >> 2)) * T_PITCH + ((li & 3) << 3), fsw = (g & 1) << 7;
+    auto readT = [&](const unsigned char* sub, int f) {
+        const unsigned char* a = sub + fbase + ((f << 5) ^ fsw);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(a + 4 * T_PITCH));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto readB = [&](const unsigned char* stage, int f) {
+        if constexpr (B_T) return readT(stage + MID_A_BYTES + wn * WG_SUB, f);
+        else return readN(stage + MID_A_BYTES, wn * 96, f);
+    };
+    auto readA = [&](auto S, const unsigned char* stage) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) fa[decltype(S)::value][f] = readN(stage, wm * 96, f);
+    };
+    __syncthreads();
+    if (active) {
+        readA(std::integral_constant<int, 0>{}, smem);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) fb[f] = readB(smem, f);
+    }
+    __syncthreads();
+    // step t: the A fragments of step t + 1 are requested first, then the 36 MFMAs of step t run; each B fragment of step t + 1
+    // is read right behind the last MFMA that uses its predecessor (wgrad_tile's schedule: one barrier per step)
+    auto step = [&](auto R, int t) {
+        constexpr int r = decltype(R)::value;
+        const unsigned char* nxt = smem + ((t & 1) ^ 1) * STAGE;
+        if (active) {
+            const bool more = t + 1 < nt;
+            if (more) readA(std::integral_constant<int, (r + 1) & 1>{}, nxt);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+#pragma unroll
+                for (int i = 3; i < 6; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[r & 1][i], acc[i][j], 0, 0, 0);
+                if (more) fb[j] = readB(nxt, j);
+            }
+        }
+        __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 2)
+        static_for<2>([&](auto R) { step(R, t + decltype(R)::value); });
+
+    if (!active) return;
+    unsigned char* wst = smem + wid * (32 * WG_STG_PITCH);
+    // (ps through static_for: a loop the compiler declines to unroll would index the accumulators dynamically, i.e. keep all 36 in
+    // scratch; the item loop inside stays rolled -- it only reads the staged rows -- so the epilogue switch exists three times, not 18)
+    static_for<3>([&](auto PS) {
+        constexpr int ps = decltype(PS)::value;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                *(f32x4*)(wst + (ii * 16 + li) * WG_STG_PITCH + (j * 16 + g * 4) * 4) = acc[ps * 2 + ii][j];
+        // (a wave reads back only what it wrote: no barrier)
+#pragma unroll 1
+        for (int it = 0; it < 6; ++it) {
+            const int c = lane + it * 64;
+            const int rl = c / 12, c8 = c - rl * 12;
+            const int m = m0 + wm * 96 + ps * 32 + rl, n = n0 + wn * 96 + c8 * 8;
+            if (m < p.M && n < p.N) {
+                const float4 lo = *(const float4*)(wst + rl * WG_STG_PITCH + c8 * 32);
+                const float4 hi = *(const float4*)(wst + rl * WG_STG_PITCH + c8 * 32 + 16);
+                epilogue8(p, m, n, lo, hi, bz);
+            }
+        }
+    });
+}
+template <bool B_T>
+__global__ __launch_bounds__(512) void gemm_mid_kernel(const GemmArgs p, const int gx, const int gy) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MidGeo<B_T>::LDS];
+    // workgroup b runs on XCD b % 8: each XCD gets a contiguous run of tiles in (K split, row block, column block) order, so the
+    // tiles that share a block of A rows read it through one L2
+    int b = blockIdx.x;
+    const int nb8 = (int)gridDim.x & ~7;
+    if (b < nb8) b = (b & 7) * (nb8 >> 3) + (b >> 3);
+    const int tiles = gx * gy;
+    const int bz = b / tiles;
+    b -= bz * tiles;
+    const int by = b / gx;
+    gemm_mid_tile<B_T>(p, b - by * gx, by, bz, smem);
+}
+
 // split-K for the ordinary epilogues: the GEMM wrote raw fp32 partial slabs [splits][M][N]; fold them
 // and apply the fused epilogue (bias / GELU / residual / ...) once.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, const float* __restrict__ slabs,
@@ -848,6 +1081,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, 
 
 template <bool A_T, bool B_T>
 int launch(const GemmArgs& p, int splits, hipStream_t stream) {
+    if constexpr (!A_T) {
+        // the 192 x 192 loader-wave kernel: whole 64-deep stages, at least TULIP_GEMM_MID_MIN tiles (a launch of fewer leaves most
+        // of the chip idle whatever the tile does) of a matrix tall enough to be worth it; p.mid: 1 = by this rule, 2 = forced, 0 = never
+        const int gx = (p.N + 191) / 192, gy = (p.M + 191) / 192;
+        const bool fits = p.kchunk % 64 == 0 && p.K % p.kchunk == 0 && p.N >= 96 && p.M >= 96 &&
+                          p.epi != TULIP_EPI_PIXSHUF2_F32 && p.epi != TULIP_EPI_UNSHUF2_BF16;
+        if (fits && (p.mid == 2 || (p.mid == 1 && p.M >= TULIP_GEMM_MID_MIN_M && gx * gy * splits >= TULIP_GEMM_MID_MIN))) {
+            hipLaunchKernelGGL((gemm_mid_kernel<B_T>), dim3(gx * gy * splits), dim3(512), 0, stream, p, gx, gy);
+            TULIP_CHECK_LAUNCH();
+            return TULIP_OK;
+        }
+    }
     // BM=64 (with 128-deep k stages: 4 sub-tiles of loads in flight per thread) when BM=128 would leave
     // most of the 256 CUs idle -- the small-M / large-K GEMMs of the deep stages are load-latency bound
     const int gn = (p.N + BN - 1) / BN;
@@ -866,7 +1111,7 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
         // 128-deep k stages (80-150 KB LDS, 1-2 workgroups/CU) pay while the grid is at most ~1.5 waves of the chip
         const bool deep = (int)(grid.x * grid.y * grid.z) <= TULIP_GEMM_KSUB_GRID && p.kchunk >= 256;
         const int bks = deep ? 128 : 32;
-        const bool full = gemm_full_on && !A_T && p.M % 64 == 0 && p.N % BN == 0 && p.kchunk % bks == 0 && p.K % p.kchunk == 0;
+        const bool full = !p.checked && !A_T && p.M % 64 == 0 && p.N % BN == 0 && p.kchunk % bks == 0 && p.K % p.kchunk == 0;
         if constexpr (!A_T) {
             if (full) {
                 if (deep) hipLaunchKernelGGL((gemm_kernel_full<64, B_T, 4>), grid, dim3(256), 0, stream, p);
@@ -880,7 +1125,7 @@ int launch(const GemmArgs& p, int splits, hipStream_t stream) {
         else
             hipLaunchKernelGGL((gemm_kernel<64, A_T, B_T, 1>), grid, dim3(256), 0, stream, p);
     } else {
-        const bool full = gemm_full_on && !A_T && p.M % bm == 0 && p.N % BN == 0 && p.kchunk % 32 == 0 && p.K % p.kchunk == 0;
+        const bool full = !p.checked && !A_T && p.M % bm == 0 && p.N % BN == 0 && p.kchunk % 32 == 0 && p.K % p.kchunk == 0;
         dim3 grid(gn, (p.M + bm - 1) / bm, splits);
         if constexpr (!A_T) {
             if (full) {
@@ -932,7 +1177,12 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     splits = (K + kchunk - 1) / kchunk;
     p.epi = epi; p.bias = bias; p.out = out; p.ldo = ldo; p.out2 = out2; p.ldo2 = ldo2;
     p.aux = aux; p.ldaux = ldaux; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-    p.accumulate = accumulate; p.psH = psH; p.psW = psW; p.touch = gemm_touch_on;
+    p.accumulate = accumulate & TULIP_GEMM_ACCUMULATE; p.psH = psH; p.psW = psW;
+    p.touch = (accumulate & TULIP_GEMM_NO_TOUCH) ? 0 : 1; p.checked = (accumulate & TULIP_GEMM_CHECKED) ? 1 : 0;
+    p.mid = (accumulate & TULIP_GEMM_MID) ? 2 : (accumulate & TULIP_GEMM_NO_MID) ? 0 : 1;
+    // (any pitch is accepted for these epilogues: the scattered 2-byte form takes what the vector stores cannot)
+    p.vec_ok = epi == TULIP_EPI_PIXSHUF2_F32 ? ((ldo2 & 7) == 0 && ((uintptr_t)out2 & 15) == 0 && ((uintptr_t)out & 15) == 0)
+             : epi == TULIP_EPI_UNSHUF2_BF16 ? ((ldo & 1) == 0 && ((uintptr_t)out & 3) == 0) : 0;
     GemmArgs q = p;  // what the GEMM kernel itself does
     const bool fold = splits > 1 && !raw_split;
     if (fold) {
@@ -957,9 +1207,8 @@ extern "C" int tulip_reduce_rows_multi_adamw(const tulip_reduce_region* regions,
 
 // tile shape of the large-tile weight-gradient kernel for a [Nw][Kw] gradient: 0 = 192 x 192, 1 = 384 x 96, 2 = 96 x 384,
 // -1 = none (the 64 x 96 tile of gemm_group_kernel)
-static int g_wgrad_mode = 1;
-static int wgrad_shape(int Nw, int Kw) {
-    if (!(g_wgrad_mode & 1)) return -1;
+static int wgrad_shape(int Nw, int Kw, int flags) {
+    if (flags & TULIP_WGRAD_SMALL_TILES) return -1;
     if (Nw % 192 == 0 && Kw % 192 == 0) return 0;
     if (Kw == 96 && Nw % 96 == 0) return 1;
     if (Nw == 96 && Kw % 96 == 0) return 2;
@@ -971,21 +1220,19 @@ static void wgrad_tile_grid(int shape, int Nw, int Kw, int* gx, int* gy) {
     *gx = (Kw + tn - 1) / tn;
     *gy = (Nw + tm - 1) / tm;
 }
-extern "C" int tulip_wgrad_set_mode(int mode) { g_wgrad_mode = mode; return TULIP_OK; }
-static void* g_wgrad_prof = nullptr;
-extern "C" int tulip_wgrad_set_profile(void* stamps) { g_wgrad_prof = stamps; return TULIP_OK; }
-extern "C" int tulip_wgrad_tiles(int Nw, int Kw) {
+extern "C" int tulip_wgrad_tiles(int Nw, int Kw, int flags) {
     int gx, gy;
-    wgrad_tile_grid(wgrad_shape(Nw, Kw), Nw, Kw, &gx, &gy);
+    wgrad_tile_grid(wgrad_shape(Nw, Kw, flags), Nw, Kw, &gx, &gy);
     return gx * gy;
 }
 
 static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
-                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, hipStream_t stream);
+                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, void* prof,
+                            hipStream_t stream);
 
 extern "C" int tulip_wgrad_group(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
                                  void* workspace, int64_t workspace_bytes, int fold, hipStream_t stream) {
-    return wgrad_group_impl(items, n, extra, n_extra, workspace, workspace_bytes, fold, nullptr, stream);
+    return wgrad_group_impl(items, n, extra, n_extra, workspace, workspace_bytes, fold, nullptr, nullptr, stream);
 }
 
 extern "C" int tulip_wgrad_group_adamw(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
@@ -993,18 +1240,25 @@ extern "C" int tulip_wgrad_group_adamw(const tulip_wgrad_item* items, int n, con
                                        hipStream_t stream) {
     if (adam && (!adam->hyper || !adam->grad || !adam->param || !adam->exp_avg || !adam->exp_avg_sq || !adam->param_bf16))
         return TULIP_ERR_ARG;
-    return wgrad_group_impl(items, n, extra, n_extra, workspace, workspace_bytes, fold, adam, stream);
+    return wgrad_group_impl(items, n, extra, n_extra, workspace, workspace_bytes, fold, adam, nullptr, stream);
+}
+
+// dev (tools/wgrad_phases.py): the grouped launch alone (no fold, no optimizer step) with 4 shader-clock stamps per workgroup
+extern "C" int tulip_wgrad_group_profiled(const tulip_wgrad_item* items, int n, void* workspace, int64_t workspace_bytes, int flags,
+                                          void* stamps, hipStream_t stream) {
+    return wgrad_group_impl(items, n, nullptr, 0, workspace, workspace_bytes, flags & ~TULIP_WGRAD_FOLD, nullptr, stamps, stream);
 }
 
 static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_reduce_region* extra, int n_extra,
-                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, hipStream_t stream) {
+                            void* workspace, int64_t workspace_bytes, int fold, const tulip_adamw_ref* adam, void* prof,
+                            hipStream_t stream) {
     if (n < 0 || n > GROUP_MAX || n_extra < 0 || n + n + n_extra > TULIP_REDUCE_REGIONS_MAX || (n && !items) ||
         (n_extra && !extra))
         return TULIP_ERR_ARG;
     bool big = true;
     for (int i = 0; i < n; ++i)
         if (items[i].Nw > 0 && items[i].Kw > 0 && items[i].Mtok > 0 &&
-            (wgrad_shape(items[i].Nw, items[i].Kw) < 0 || (items[i].Mtok & 31)))
+            (wgrad_shape(items[i].Nw, items[i].Kw, fold) < 0 || (items[i].Mtok & 31)))
             big = false;
     WgradGroup G;
     tulip_reduce_region folds[TULIP_REDUCE_REGIONS_MAX];
@@ -1026,7 +1280,7 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
         p.A = (const bf16_t*)it.dY; p.B = (const bf16_t*)it.X; p.lda = it.ldy; p.ldb = it.ldx;
         p.M = it.Nw; p.N = it.Kw; p.K = it.Mtok; p.kchunk = kchunk;
         p.bias = nullptr; p.ldo = it.Kw; p.ldo2 = 0; p.aux = nullptr; p.ldaux = 0; p.rowscale = nullptr;
-        p.rows_per_sample = 1; p.psH = 0; p.psW = 0; p.touch = 0;
+        p.rows_per_sample = 1; p.psH = 0; p.psW = 0; p.touch = 0; p.checked = 0; p.mid = 0; p.vec_ok = 0;
         if (splits > 1) {
             const int64_t nw = (int64_t)it.Nw * it.Kw, need = (nw + (it.db ? it.Nw : 0)) * splits;
             if (!ws || (ws_used + need) * 4 > workspace_bytes) return TULIP_ERR_ARG;
@@ -1043,7 +1297,7 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
             // reserved_ = 1: apply AdamW to this (un-split, large-tile, written-not-accumulated) weight gradient in the write-out
             if (it.reserved_ == 1 && adam && big && it.overwrite) p.accumulate |= 2;
         }
-        G.shape[G.n] = big ? wgrad_shape(it.Nw, it.Kw) : -1;
+        G.shape[G.n] = big ? wgrad_shape(it.Nw, it.Kw, fold) : -1;
         wgrad_tile_grid(G.shape[G.n], it.Nw, it.Kw, &G.gx[G.n], &G.gy[G.n]);
         G.first[G.n + 1] = G.first[G.n] + G.gx[G.n] * G.gy[G.n] * splits;
         deep = deep && kchunk >= 256;
@@ -1055,7 +1309,7 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
             G.adam = adam ? AdamRef{adam->hyper, adam->grad, adam->param, adam->exp_avg, adam->exp_avg_sq, (bf16_t*)adam->param_bf16,
                                     adam->decay_mask64}
                           : AdamRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-            for (int i = 0; i < G.n; ++i) G.g[i].aux = g_wgrad_prof;
+            for (int i = 0; i < G.n; ++i) G.g[i].aux = prof;
             hipLaunchKernelGGL(wgrad_group_kernel, dim3(blocks), dim3(512), 0, stream, G);
         } else {
             GemmGroup S;
@@ -1069,7 +1323,7 @@ static int wgrad_group_impl(const tulip_wgrad_item* items, int n, const tulip_re
         }
         TULIP_CHECK_LAUNCH();
     }
-    if (!fold) return TULIP_OK;
+    if (!(fold & TULIP_WGRAD_FOLD)) return TULIP_OK;
     for (int i = 0; i < n_extra; ++i) folds[nf++] = extra[i];
     return nf ? tulip_reduce_rows_multi_adamw(folds, nf, adam, stream) : TULIP_OK;
 }
@@ -1099,7 +1353,4 @@ extern "C" int tulip_wgrad_group_regions(const tulip_wgrad_item* items, int n, v
     return nf;
 }
 
-extern "C" int tulip_gemm_set_touch(int on) {
-    gemm_touch_on = on ? 1 : 0;
-    return TULIP_OK;
-}
+

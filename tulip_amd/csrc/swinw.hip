@@ -35,6 +35,15 @@
 #include "tulip_hip.h"
 
 #include "swin_stream.h"
+// arrival tickets of the two-workgroups-per-window forms: the partial sums are published with write-through (sc1) stores that
+// every wave drains (s_waitcnt vmcnt(0) + barrier) before the ticket is drawn, and the last arriver reads its partner's with sc1
+// loads behind the ticket -- exactly the lines that cross the XCD boundary, nothing else.  Drawing the ticket acq_rel instead
+// (-DTULIP_TICKET_ORDER=__ATOMIC_ACQ_REL: correct by the HIP memory model alone) makes the compiler write back and invalidate the
+// whole L2 around it, with the block's saved activations dirty in it: +11 us per batch-8 step over four launches (same-box A/B,
+// three pairs, profiles/r5_ab_ticket.txt) -- measured, not taken.  A sequence cut short re-zeroes the tickets (Plan.reset_exchange).
+#ifndef TULIP_TICKET_ORDER
+#define TULIP_TICKET_ORDER __ATOMIC_RELAXED
+#endif
 
 namespace {
 
@@ -100,7 +109,6 @@ struct SwinWArgs {
 };
 #define TULIP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-int swinw_warm = 1;      // tulip_swinw_set_warm: the L2 warm-up at the head of the launches (measurement switch)
 
 template <int C, int G>
 struct Geo {
@@ -489,7 +497,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains
             __syncthreads();
             unsigned* flag = (unsigned*)STAT;                          // (the statistics exchange is long over)
-            if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tick + wblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tick + wblk, 1u, TULIP_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (flag[0] == 0u) return;                                 // first of the pair: the partner finishes the block
             if (tid == 0) __hip_atomic_store(a.tick + wblk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
@@ -521,7 +529,7 @@ __global__ __launch_bounds__((Geo<C, G>::NT)) void swinw_fwd_kernel(const SwinWA
 // two workgroups per window (swinw_fwd_kernel, SPLIT): the training form with gelu'(h) handed over, or the inference form
 int launch_fwd_split(const SwinWArgs& a, hipStream_t stream) {
     const int windows = a.B * (a.H / 2) * (a.W / 8);
-    const int warm = (a.prof || !swinw_warm) ? 0 : 1;
+    const int warm = (a.prof || (a.masked & TULIP_BLOCK_NO_WARM)) ? 0 : 1;
     const dim3 grid(2 * windows), block(Geo<384, 1>::NT);
     if (!a.qkv) {
         if (warm) hipLaunchKernelGGL((swinw_fwd_kernel<384, 1, 21>), grid, block, 0, stream, a);
@@ -535,7 +543,7 @@ template <int C, int G>
 int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
     // the workgroups that are resident first warm their XCD's L2 with the block's weights (WeightWarm)
-    const int warm = (a.prof || !swinw_warm || blocks < 8) ? 0 : (blocks <= 256 ? 1 : 2);
+    const int warm = (a.prof || (a.masked & TULIP_BLOCK_NO_WARM) || blocks < 8) ? 0 : (blocks <= 256 ? 1 : 2);
     const dim3 grid(blocks), block(Geo<C, G>::NT);
     if (a.qkv && (a.masked & TULIP_BLOCK_FC1_GRAD)) {       // training form, gelu'(h) handed to the backward
         if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 9>), grid, block, 0, stream, a);
@@ -799,7 +807,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             unsigned* flag = (unsigned*)STAT;
-            if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tick + wblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tick + wblk, 1u, TULIP_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (flag[0] == 0u) return;                                 // first of the pair: the partner runs the rest of the block
             if (tid == 0) __hip_atomic_store(a.tick + wblk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -988,7 +996,7 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 int launch_bwd_split(const SwinWBwdArgs& a, hipStream_t stream) {
     const int windows = a.B * (a.H / 2) * (a.W / 8);
     const dim3 grid(2 * windows), block(GeoB<384, 1>::NT);
-    if (swinw_warm) hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 13>), grid, block, 0, stream, a);
+    if (!(a.masked & TULIP_BLOCK_NO_WARM)) hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 13>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 12>), grid, block, 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
@@ -996,7 +1004,8 @@ int launch_bwd_split(const SwinWBwdArgs& a, hipStream_t stream) {
 template <int C, int G>
 int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
     const int blocks = a.B * (a.H / 2) * (a.W / (8 * G));
-    const int warm = (blocks <= 256 && blocks >= 8 && swinw_warm) ? 1 : (blocks > 256 && swinw_warm) ? 2 : 0;
+    const bool warm_on = !(a.masked & TULIP_BLOCK_NO_WARM);
+    const int warm = (blocks <= 256 && blocks >= 8 && warm_on) ? 1 : (blocks > 256 && warm_on) ? 2 : 0;
     const dim3 grid(blocks), block(GeoB<C, G>::NT);
     if (a.masked & TULIP_BLOCK_FC1_GRAD) {      // the fc1_pre buffer holds gelu'(h) (bit 2 of the template's mode)
         if (warm == 1) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 5>), grid, block, 0, stream, a);
@@ -1083,7 +1092,6 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const TrList L) {
 
 }  // namespace
 
-extern "C" int tulip_swinw_set_warm(int on) { swinw_warm = on ? 1 : 0; return TULIP_OK; }
 
 extern "C" int tulip_swinw_supported(int C, int H, int W) {
     return (C == 192 || C == 384) && H > 0 && !(H & 1) && W > 0 && !(W & 15);

@@ -158,11 +158,21 @@ class FlatParams:
         slots = getattr(self, "_slots", None)
         if slots is None or self._slots_model is not model:
             mods = dict(model.named_modules())
-            slots = []
+            slots, edges, seen = [], [], set()
             for n in self.names:
                 mn, _, pn = n.rpartition(".")
                 slots.append((mods[mn]._parameters, pn, self.base32 + 4 * self.offset[n]))
-            self._slots, self._slots_model = slots, model
+                # ... and every parent -> child edge on the way to the owning module: `model.x = other_module` leaves the OLD
+                # module's parameter dict intact, so the dicts alone would not notice the replacement
+                while mn and mn not in seen:
+                    seen.add(mn)
+                    par, _, child = mn.rpartition(".")
+                    edges.append((mods[par]._modules, child, mods[mn]))
+                    mn = par
+            self._slots, self._slot_edges, self._slots_model = slots, edges, model
+        for d, k, m in self._slot_edges:
+            if d.get(k) is not m:
+                return None
         out = []
         for d, k, ptr in slots:
             p = d.get(k)
@@ -329,6 +339,14 @@ class Plan:
             self.bufs[name] = t
         return t.data_ptr()
 
+    def reset_exchange(self):
+        """Zero the pair-exchange areas (partial sums + arrival tickets of the two-workgroups-per-window launches, csrc/swinw.hip):
+        the kernels re-zero a ticket when its second arriver passes, so only a launch sequence that was cut short (a failed
+        capture, a faulted step) can leave one non-zero -- whoever catches that calls this before the next launch."""
+        for k, t in self.bufs.items():
+            if k.startswith("xchg."):
+                t.zero_()
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
@@ -337,8 +355,9 @@ class TulipEngine:
     def __init__(self, model):
         self.model = model
         self.device = None
-        ops.wgrad_set_mode(int(os.environ.get("TULIP_WGRAD_TILES", "1")))
-        ops.swinw_set_warm(os.environ.get("TULIP_SWINW_WARM", "1") != "0")      # A/B switch (tools/cold_probe.py)
+        # A/B switches, carried per launch (the library keeps no state): the 64 x 96 weight-gradient tile everywhere; no L2 warm-up
+        self.wgrad_small_tiles = os.environ.get("TULIP_WGRAD_TILES", "1") == "0"
+        self.no_warm = os.environ.get("TULIP_SWINW_WARM", "1") == "0"            # (tools/cold_probe.py)
         self.params: Optional[FlatParams] = None
         self.plans: Dict[int, Plan] = {}
         m = model
@@ -533,7 +552,7 @@ class TulipEngine:
         blocks, TULIP_BLOCK_FC1_GRAD; B = the plan's batch size for the wide ones) the fc1_pre buffer carries gelu'(h) from
         the forward to the backward."""
         hg = self._hgrad96(sp) or (B is not None and (self._hgrad_wide(sp, B) or self._fusable_deep(sp, B)))
-        return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0) | (4 if hg else 0)
+        return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0) | (4 if hg else 0) | (8 if self.no_warm else 0)
 
     # two workgroups per window for the C = 384 blocks where one workgroup owns one window (csrc/swinw.hip, SPLIT)
     split_wide = os.environ.get("TULIP_SWINW_SPLIT", "1") != "0"
@@ -560,16 +579,20 @@ class TulipEngine:
         return ok
 
     # round 5: the deep stages (C = 768 / 1536: stage 3, and stage 4 of tulip_large) as four sliced launches per block and direction
-    # (csrc/swind.hip; + the two LayerNorm backward launches) instead of the 15 / 16-launch sequences.  TULIP_FUSE_DEEP=0: the sequences;
-    # TULIP_FUSE_DEEP_MAX_WINDOWS: above that many windows per launch the GEMM sequence runs (its tiles fill the chip there)
+    # (csrc/swind.hip; + the two LayerNorm backward launches) instead of the 15 / 16-launch sequences.  TULIP_FUSE_DEEP=0: the sequences.
+    # The sliced form puts 8 workgroups on each group of windows, so it wants 32-64 windows per launch (256-512 workgroups); isolated,
+    # forward / backward against the sequence (profiles/r5_bench_deep_shapes.txt): C = 768 with 32 windows 0.66 / 0.81, 64: 0.72 / 0.82,
+    # 128: 1.10 / 1.05, 256 (batch 64): 1.32 / 1.18; C = 1536 with 16 windows (half the chip) 1.0 / 1.14, 32: 0.77 / 0.77 -- outside
+    # [TULIP_FUSE_DEEP_MIN_WINDOWS, TULIP_FUSE_DEEP_MAX_WINDOWS] the GEMM sequence runs (its tiles fill the chip there)
     fuse_deep = os.environ.get("TULIP_FUSE_DEEP", "1") != "0"
-    deep_max_windows = int(os.environ.get("TULIP_FUSE_DEEP_MAX_WINDOWS", "1000000"))
+    deep_min_windows = int(os.environ.get("TULIP_FUSE_DEEP_MIN_WINDOWS", "32"))
+    deep_max_windows = int(os.environ.get("TULIP_FUSE_DEEP_MAX_WINDOWS", "64"))
 
     def _fusable_deep(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
         ok = (self.fuse_deep and sp.C in (768, 1536) and sp.nh * 32 == sp.C and self.hidden(sp.C) == 4 * sp.C
               and tuple(sp.win) in ((2, 8), (1, 16)) and sp.H % sp.win[0] == 0 and sp.W % sp.win[1] == 0)
         if ok and B is not None:
-            ok = B * (sp.H // sp.win[0]) * (sp.W // sp.win[1]) <= self.deep_max_windows
+            ok = self.deep_min_windows <= B * (sp.H // sp.win[0]) * (sp.W // sp.win[1]) <= self.deep_max_windows
         return ok
 
     def _fused_bwd(self, sp: BlockSpec, B: int) -> bool:
@@ -1056,10 +1079,10 @@ class TulipEngine:
             gmax = self.wgrad_group_max
             cand = items[:gmax]
             # (the large-tile kernel also needs whole 32-token k-steps: same test as tulip_wgrad_group, csrc/gemm.hip)
-            big = all(ops.wgrad_tiles(a[4], a[5]) != ((a[4] + 63) // 64) * ((a[5] + 95) // 96) and a[6] % 32 == 0 for a in cand)
+            big = all(ops.wgrad_tiles(a[4], a[5], self.wgrad_small_tiles) != ((a[4] + 63) // 64) * ((a[5] + 95) // 96) and a[6] % 32 == 0 for a in cand)
             # large tiles run one workgroup per CU: the token splits of a launch are sized so that the whole group is
             # about one round of the chip
-            group_tiles = sum(ops.wgrad_tiles(a[4], a[5]) for a in cand) if big else 0
+            group_tiles = sum(ops.wgrad_tiles(a[4], a[5], self.wgrad_small_tiles) for a in cand) if big else 0
             while items and len(grp) < gmax:
                 dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias = items[0]
                 sp = self._splits(Nw, Kw, Mtok, group_tiles=group_tiles, ctas=self.wgrad_ctas if full_chip else self._group_ctas(group_tiles))
@@ -1083,11 +1106,11 @@ class TulipEngine:
             room = _lib.REDUCE_REGIONS_MAX - 2 * len(grp)
             if late and not items and len(regions) <= room:
                 # one group, folded in ONE launch behind the late event together with everything else of this flush
-                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False, adam=self._adam_arg())
+                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False, adam=self._adam_arg(), small_tiles=self.wgrad_small_tiles)
                 regions = ops.wgrad_group_regions(grp, ws) + regions
                 break
             extra, regions = regions[:room], regions[room:]
-            ops.wgrad_group(grp, extra, ws, ws_bytes, adam=self._adam_arg())
+            ops.wgrad_group(grp, extra, ws, ws_bytes, adam=self._adam_arg(), small_tiles=self.wgrad_small_tiles)
         for ev in late:
             torch.cuda.current_stream().wait_event(ev)
         while regions:
@@ -1630,7 +1653,8 @@ class TulipEngine:
         # what the captured launch sequence depends on besides the caller's key: the fuse switches, the DropPath seed (a launch
         # argument) and the number of draw slots
         key = key + (self.fuse_wide, self.fuse_wide_bwd, self.fuse_block96, self.fuse_block96_bwd, self.split_wide, self.split_wide_bwd,
-                     self.fc1_grad_wide, self.fuse_tail_fwd, self.fuse_tail_bwd, int(self._drop_seed), int(self.n_drop_slots))
+                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd,
+                     int(self._drop_seed), int(self.n_drop_slots))
         ent = graphs.get(key)
         if not self.graph_module or ent is None:
             fn()
@@ -1642,14 +1666,16 @@ class TulipEngine:
             cap.wait_stream(cur)
             with torch.cuda.stream(cap):
                 ent = torch.cuda.CUDAGraph()
-                ent.capture_begin(capture_error_mode="thread_local")
-                fn()
-                ent.capture_end()
+                try:
+                    ent.capture_begin(capture_error_mode="thread_local")
+                    fn()
+                    ent.capture_end()
+                except BaseException:
+                    P.reset_exchange()
+                    raise
             cur.wait_stream(cap)
             graphs[key] = ent
         ent.replay()
-        if key[0] == "fwd":
-            self.params.shadow_dirty = False     # the replayed sequence rebuilt the bf16 shadow and the packed copies
 
     def _module_forward(self, P: Plan):
         train = bool(self.model.training)
@@ -1659,23 +1685,40 @@ class TulipEngine:
             self.draw_drop_scales(P, train)      # of the sequence (and of its graph)
             self.run_forward(P)
         self._module_sequence(P, ("fwd", train, self.attn_fp8), seq)
+        # the caller's optimizer owns the weights on this path and steps them AFTER this call: whoever reads the bf16 shadow /
+        # packed copies next (a Trainer, a GraphedForward, the next module forward) must rebuild them
+        self.params.shadow_dirty = True
         P.generation += 1
 
     def _module_backward(self, P: Plan, dloss):
+        """The flat gradient of one module backward, in a buffer autograd may keep: `.grad` of a parameter whose gradient was None
+        becomes (a view of) what this returns, so a buffer that a captured graph writes may be handed out only while nothing
+        else refers to it.  Two such buffers alternate -- with `optimizer.zero_grad()` between steps (set_to_none, the reference's
+        loop, engine_upsampling.py:98-99) the one handed out two calls ago is free again, and during gradient accumulation `.grad`
+        keeps holding the first one while every later call writes the second; a buffer is free when its storage has no user but
+        the plan (one reference count read, no walk over the parameters).  Both taken (the caller kept gradients of two calls
+        alive): a third, private buffer and a copy out of it -- what every call paid before (108 MB copied per step)."""
         W_ = self.params
-        if not hasattr(P, "_mod_gflat"):
-            P._mod_gflat = torch.zeros(W_.total, dtype=torch.float32, device=self.device)
+        if not hasattr(P, "_mod_gbufs"):
+            P._mod_gbufs = [torch.zeros(W_.total, dtype=torch.float32, device=self.device) for _ in range(2)]
             P._mod_gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+            P._mod_gidle = _storage_users(P._mod_gbufs[0])
         if dloss is None:
             P._mod_gscale.fill_(1.0)
         else:
             P._mod_gscale.copy_(dloss.detach().reshape(1))
+        which = next((i for i, b in enumerate(P._mod_gbufs[:2]) if _storage_users(b) <= P._mod_gidle), None)
+        if which is None:
+            if len(P._mod_gbufs) == 2:
+                P._mod_gbufs.append(torch.zeros(W_.total, dtype=torch.float32, device=self.device))
+            which = 2
+        g = P._mod_gbufs[which]
         over = self.overwrite_supported(P.B)      # every gradient element has one producer: nothing to clear between calls
         if not over:
-            P._mod_gflat.zero_()
-        self._module_sequence(P, ("bwd", self.attn_fp8),
-                              lambda: self.run_backward(P, P._mod_gflat, gscale_dev=P._mod_gscale, gscale=1.0, overwrite=over))
-        return P._mod_gflat.clone()               # (autograd may keep the returned tensors as .grad: never the static buffer)
+            g.zero_()
+        self._module_sequence(P, ("bwd", self.attn_fp8, which),
+                              lambda: self.run_backward(P, g, gscale_dev=P._mod_gscale, gscale=1.0, overwrite=over))
+        return g.clone() if which == 2 else g
 
     def autograd_forward(self, x, target, mc_drop: bool):
         self.bind(x.device)
@@ -1686,6 +1729,7 @@ class TulipEngine:
         if mc_drop or target is None:
             self.draw_drop_scales(P, self.model.training)
             self.run_forward(P, with_loss=False)
+            self.params.shadow_dirty = True
             return P.pred.clone()
         P.target.copy_(target.reshape(P.target.shape).float())
         params = self._cur_params if self._cur_params is not None else self.params.current_params(self.model)
@@ -1693,8 +1737,13 @@ class TulipEngine:
         if not need_grad:
             self.draw_drop_scales(P, self.model.training)
             self.run_forward(P)
+            self.params.shadow_dirty = True
             return P.pred.clone(), P.losses[0].clone(), P.losses[1].clone()
         return _TulipFn.apply(self, P, *params)            # (flat-buffer order: _TulipFn.backward returns the gradients in it)
+
+
+def _storage_users(t: torch.Tensor) -> int:
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
 
 
 class _TulipFn(torch.autograd.Function):

@@ -34,10 +34,13 @@ def _chk(t: torch.Tensor, dtype, name: str):
 
 def gemm(A, B, M, N, K, *, lda, ldb, a_trans=False, b_trans=False, epi=EPI_BF16, bias=None, out=None, ldo=None,
          out2=None, ldo2=0, aux=None, ldaux=0, rowscale=None, rows_per_sample=1, accumulate=False, psH=0, psW=0,
-         splits=1, workspace=None, workspace_bytes=0):
+         splits=1, workspace=None, workspace_bytes=0, touch=True, checked=False, mid=None):
     """C[M,N] = opA . opB^T with a fused epilogue (see include/tulip_hip.h).  A/B/out may be views
-    with an element offset (row strides passed as lda/ldb/ldo)."""
+    with an element offset (row strides passed as lda/ldb/ldo).  touch=False / checked=True: TULIP_GEMM_NO_TOUCH /
+    TULIP_GEMM_CHECKED (measurement and bit-compare switches, per call)."""
     lib = _lib.load()
+    accumulate = int(bool(accumulate)) | (0 if touch else _lib.GEMM_NO_TOUCH) | (_lib.GEMM_CHECKED if checked else 0)
+    accumulate |= 0 if mid is None else (_lib.GEMM_MID if mid else _lib.GEMM_NO_MID)     # the 192 x 192 mid-size kernel: forced / never
     rc = lib.tulip_gemm_bf16(_p(A), lda, int(a_trans), _p(B), ldb, int(b_trans), M, N, K, epi, _p(bias), _p(out),
                              ldo if ldo is not None else N, _p(out2), ldo2, _p(aux), ldaux, _p(rowscale),
                              rows_per_sample, int(accumulate), psH, psW, splits, _p(workspace), workspace_bytes,
@@ -117,26 +120,26 @@ def reduce_rows_multi(regions, adam=None):
               "tulip_reduce_rows_multi_adamw")
 
 
-def wgrad_tiles(Nw, Kw):
+def wgrad_tiles(Nw, Kw, small_tiles=False):
     """Workgroup tiles per token split of a [Nw][Kw] weight gradient in the grouped launch (tulip_wgrad_tiles)."""
-    return _lib.load().tulip_wgrad_tiles(Nw, Kw)
+    return _lib.load().tulip_wgrad_tiles(Nw, Kw, _lib.WGRAD_SMALL_TILES if small_tiles else 0)
 
 
-def wgrad_set_mode(mode):
-    """1 (default): large weight-gradient tiles where the shape allows; 0: the 64 x 96 tile everywhere."""
-    _lib.load().tulip_wgrad_set_mode(int(mode))
+def wgrad_group_profiled(items, workspace, workspace_bytes, stamps, small_tiles=False):
+    """tulip_wgrad_group_profiled: the grouped launch alone; stamps = int64 device tensor [workgroups, 4] (phase stamps)."""
+    ia = (_lib.WgradItem * max(len(items), 1))(*items)
+    check(_lib.load().tulip_wgrad_group_profiled(ia, len(items), _p(workspace), workspace_bytes,
+                                                 _lib.WGRAD_SMALL_TILES if small_tiles else 0, _p(stamps), _stream()),
+          "tulip_wgrad_group_profiled")
 
 
-def wgrad_set_profile(stamps):
-    """int64 device tensor [workgroups, 4] receiving the large-tile kernel's phase stamps, or None."""
-    _lib.load().tulip_wgrad_set_profile(_p(stamps))
-
-
-def wgrad_group(items, extra, workspace, workspace_bytes, fold=True, adam=None):
+def wgrad_group(items, extra, workspace, workspace_bytes, fold=True, adam=None, small_tiles=False):
     """tulip_wgrad_group: grouped weight-gradient GEMM + one fold launch that also carries the `extra` regions.
-    adam (ops.adamw_ref): items built with adamw=True take their optimizer step in the write-out (tulip_wgrad_group_adamw)."""
+    adam (ops.adamw_ref): items built with adamw=True take their optimizer step in the write-out (tulip_wgrad_group_adamw).
+    small_tiles: TULIP_WGRAD_SMALL_TILES (the 64 x 96 tile everywhere; A/B measurements)."""
     ia = (_lib.WgradItem * max(len(items), 1))(*items)
     ea = (_lib.ReduceRegion * max(len(extra), 1))(*extra)
+    fold = int(bool(fold)) | (_lib.WGRAD_SMALL_TILES if small_tiles else 0)
     if adam is None:
         check(_lib.load().tulip_wgrad_group(ia, len(items), ea, len(extra), _p(workspace), workspace_bytes, int(fold),
                                             _stream()), "tulip_wgrad_group")
@@ -425,16 +428,6 @@ def swinw_split_bytes(C, B, H, W) -> int:
 def stamp_realtime(dst) -> None:
     """tulip_stamp_realtime: dst (int64 device tensor element) = the 100 MHz device clock at this point of the stream."""
     check(_lib.load().tulip_stamp_realtime(_p(dst), _stream()), "tulip_stamp_realtime")
-
-
-def swinw_set_warm(on) -> None:
-    """tulip_swinw_set_warm: the L2 warm-up at the head of the single-wave fused-block launches (measurement switch)."""
-    check(_lib.load().tulip_swinw_set_warm(int(bool(on))), "tulip_swinw_set_warm")
-
-
-def gemm_set_touch(on):
-    """tulip_gemm_set_touch: the split first touch of the cold weight panel in tulip_gemm_bf16 (measurement switch)."""
-    check(_lib.load().tulip_gemm_set_touch(int(bool(on))), "tulip_gemm_set_touch")
 
 
 def swinw_bwd_partial_rows(C, B, H, W) -> int:

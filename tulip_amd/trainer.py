@@ -493,9 +493,14 @@ class Trainer:
             self.eng._drop_counter.copy_(keep_c)
             del keep_g
             torch.cuda.synchronize()
-            self._segments = {True: self._capture(True)}
-            if self.accum_iter > 1:
-                self._segments[False] = self._capture(False)
+            try:
+                self._segments = {True: self._capture(True)}
+                if self.accum_iter > 1:
+                    self._segments[False] = self._capture(False)
+            except BaseException:
+                self._segments = None
+                self.P.reset_exchange()       # a launch sequence cut short may have left an arrival ticket half-counted
+                raise
         for graph, tag in self._segments[update]:
             self.progress = (self.t, f"segment:{tag}")
             if tag == "adamw":
