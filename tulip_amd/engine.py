@@ -947,7 +947,24 @@ class TulipEngine:
             if s > 1:
                 ops.gemm(A, B, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, **kw)
                 return
+        # round 5: the narrow-output / deep-K shapes of the mid-size stages (fc2 forward, the fc1 / qkv data gradients: N = C,
+        # K = 3C .. 4C at M >= 4096 -- the deep stage at batch 64, stage 3 of tulip_large at 32 x 2048) run 330-410 TFLOP/s on
+        # gemm_tile's tiles; the 192 x 192 loader-wave kernel (csrc/gemm.hip, gemm_mid_tile) with the K split that fills the chip
+        # takes them at 450-680 isolated (profiles/r5_gemm_big.txt).  In the step that is worth 0.4 % on DurLAR tulip_large, nothing
+        # at batch 64 and -0.7 % at M = 2048 (four slabs to fold; profiles/r5_ab_mid_gemm.txt): M >= 4096 only.  Wide outputs over
+        # K = 768 stay where they are (485-710 TFLOP/s already; a 192 x 192 tile's fixed cost is not repaid by 24 k-steps).
+        if self.mid_gemm and M >= 4096 and K >= 1536 and K >= 2 * N and K % 128 == 0 and kw.get("epi") not in (EPI_PIXSHUF2_F32, EPI_UNSHUF2_BF16) \
+                and not kw.get("a_trans"):
+            tiles = ((M + 191) // 192) * ((N + 191) // 192)
+            s = max(1, min(256 // tiles, K // 768, (self.WS_ELEMS * 4) // (M * N * 4)))
+            while s > 1 and K % (64 * s):
+                s -= 1
+            if tiles * s >= 128:
+                ops.gemm(A, B, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, mid=True, **kw)
+                return
         ops.gemm(A, B, M, N, K, **kw)
+
+    mid_gemm = os.environ.get("TULIP_GEMM_MID", "1") != "0"
 
     # Side launches per STAGE, not per block (default since the side queue, not the chain, ends the backward): a grouped
     # weight-gradient launch is one round of the chip whatever it holds, so its slabs are ~one 147-KB tile per workgroup --
