@@ -11,8 +11,14 @@
  *   - every call is asynchronous on `stream`, allocates nothing, keeps no global state (the library has no mutable
  *     globals, no setters and reads no environment variable: measurement switches are per-call flag bits), performs
  *     no synchronisation, is re-entrant and is legal under HIP-graph capture.
- *   - return value: 0 on success, TULIP_ERR_ARG (-1) for an unsupported argument combination,
- *     -(1000 + hipError_t) if the launch failed.  Nothing throws, nothing exits.
+ *   - return value: 0 on success, TULIP_ERR_ARG (-1) for an unsupported argument combination, TULIP_ERR_NOT_BUILT (-3)
+ *     for a form that exists only in the development build (below), -(1000 + hipError_t) if the launch failed.
+ *     Nothing throws, nothing exits.
+ *   - TWO builds of one symbol set: libtulip_hip.so carries what a training / inference step launches; libtulip_hip_dev.so
+ *     (-DTULIP_DEV_VARIANTS=1; tulip_dev_variants() == 1) additionally the forms that were built, bit-tested and measured but
+ *     are not on the path -- the *_profiled twins (in-kernel clock stamps), the recomputing C = 96 backward (qkv = fc1_pre = NULL
+ *     with the other saved tensors given), tulip_swinw_block_bwd_split, and tulip_swinw_block_fwd / _bwd in their training
+ *     forms WITHOUT TULIP_BLOCK_FC1_GRAD.  The product library answers those calls with TULIP_ERR_NOT_BUILT.
  *   - "stream" tensors (the residual stream) are fp32 (B,H,W,C); GEMM operands are bf16 with
  *     fp32 accumulation (the autocast contract of engine_upsampling.py:77, bf16 instead of fp16).
  */
@@ -568,6 +574,7 @@ int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream);
 #define TULIP_ABI_VERSION 5
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);
+int tulip_dev_variants(void);      /* 1: the development build (see the conventions at the top) */
 
 #ifdef __cplusplus
 }

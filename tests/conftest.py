@@ -19,6 +19,15 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture
+def dev_lib():
+    """The launches of the test go to libtulip_hip_dev.so (-DTULIP_DEV_VARIANTS=1): the kernel forms no step launches -- the
+    recomputing C = 96 backward, the backward's split form, the profiled twins -- live only there."""
+    from tulip_amd import _lib
+    with _lib.dev_library():
+        yield
+
+
 def describe_flat_diff(eng, a, b, limit=8):
     """Where two flat parameter buffers differ: per parameter (or 'padding'), count and max |difference|."""
     a, b = a.detach().cpu(), b.detach().cpu()

@@ -57,8 +57,26 @@ def test_pure_host_entry_points():
     assert 1 <= r <= 2048 // 3 + 1
 
 
+def test_the_two_builds_export_one_symbol_set():
+    """libtulip_hip.so ships what a step launches; libtulip_hip_dev.so (-DTULIP_DEV_VARIANTS=1) additionally the built-tested-off
+    kernel forms and the profiled twins.  Same header, same symbols; the product library answers the
+    development-only calls with TULIP_ERR_NOT_BUILT (no launch, so this is checked here without a GPU)."""
+    import ctypes
+    lib = _lib.load()
+    assert lib.tulip_dev_variants() == 0
+    with _lib.dev_library() as dev:
+        assert dev.tulip_dev_variants() == 1 and dev.tulip_abi_version() == _lib.ABI_VERSION
+        for name in _header_functions():
+            assert hasattr(dev, name), name
+        assert _lib.load() is dev
+    assert _lib.load() is lib
+    assert os.path.getsize(_lib.DEV_LIB_PATH) > os.path.getsize(_lib.LIB_PATH)
+    it = (_lib.WgradItem * 1)()
+    assert lib.tulip_wgrad_group_profiled(it, 0, None, 0, 0, None, None) == -3          # TULIP_ERR_NOT_BUILT
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     try:
         _lib.load()

@@ -240,7 +240,7 @@ def test_bench_chooses_its_exchange_from_the_measured_bandwidth():
 
 
 @pytest.mark.parametrize("shifted,fp8", [(False, False), (True, False), (True, True)])
-def test_swin96_recomputing_backward_equals_the_read_back_form_bit_for_bit(shifted, fp8):
+def test_swin96_recomputing_backward_equals_the_read_back_form_bit_for_bit(shifted, fp8, dev_lib):
     """Round 4: tulip_swin96_block_fwd without qkv / fc1_pre (2.1 instead of 3.5 KB written per token) and
     tulip_swin96_block_bwd in its recomputation form (qkv = fc1_pre = NULL: norm1 -> qkv and norm2 -> fc1 recomputed from x / x1,
     the statistics and the weights in LDS) against the round-3 form that saves and reads both (tulip.py:338-352 and its
@@ -395,7 +395,7 @@ def test_swin96_gelu_grad_handoff(shifted):
 
 # ---- the split form of the C = 384 block: two workgroups per window (tulip_swinw_block_fwd_split / _bwd_split) ----------------
 @pytest.mark.parametrize("shifted,B", [(False, 2), (True, 2), (True, 8)])
-def test_swinw_split_form_matches_the_one_workgroup_form(shifted, B):
+def test_swinw_split_form_matches_the_one_workgroup_form(shifted, B, dev_lib):
     """C = 384 where a workgroup owns one window (stage 2 below 256 windows): with two workgroups per window every tensor of the
     attention half and the fc1 / GELU outputs are the SAME BITS (same code, same operands), the block output differs only by the
     fc2 sum being formed as two halves; the backward's split form likewise (d(fc1_pre) the same bits, everything behind the

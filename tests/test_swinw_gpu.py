@@ -116,12 +116,12 @@ def _forward(stage, shifted, B, fp8):
 
 
 @pytest.mark.parametrize("stage,shifted,B", CASES)
-def test_wide_block_backward(stage, shifted, B):
+def test_wide_block_backward(stage, shifted, B, dev_lib):      # (the fused backward reading h itself: development build)
     _backward(stage, shifted, B, False)
 
 
 @pytest.mark.parametrize("stage,shifted,B", [(1, True, 2), (2, False, 2), (2, True, 16)])
-def test_wide_block_backward_fp8_scores(stage, shifted, B):
+def test_wide_block_backward_fp8_scores(stage, shifted, B, dev_lib):
     """engine.attn_fp8: the backward differentiates the function the forward ran (dS times the e4m3-rounded q, k)."""
     _backward(stage, shifted, B, True)
 

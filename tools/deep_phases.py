@@ -2,6 +2,8 @@
 python tools/deep_phases.py [--model base] [--rows 16] [--cols 1024] [--batch 8] [--stage 3] [--cold]
 Stamps: 0 start | 1 prologue done (LayerNorm / operand rows in LDS) | 2 barrier | 3 GEMM done | 4 end (by-heads launches: k-half
 exchange barrier) | 5 end of the attention phase (by-heads launches)."""
+import os as _os
+_os.environ.setdefault("TULIP_HIP_DEV", "1")     # the profiled twins live in libtulip_hip_dev.so (include/tulip_hip.h, conventions)
 import argparse
 import os
 import sys

@@ -1,5 +1,7 @@
 """dev tool: per-phase shader-clock profile of the fused C = 96 block kernels (tulip_swin96_block_{fwd,bwd}_profiled) + launch time.
 usage: python tools/swin96_phases.py [batch=8] [recompute=1]"""
+import os as _os
+_os.environ.setdefault("TULIP_HIP_DEV", "1")     # the profiled twins live in libtulip_hip_dev.so (include/tulip_hip.h, conventions)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,7 @@
 """dev tool: per-phase shader-clock profile of swinw_fwd_kernel (tulip_swinw_block_fwd_profiled) + launch time.
 usage: python tools/swinw_phases.py [stage=1] [batch=8]"""
+import os as _os
+_os.environ.setdefault("TULIP_HIP_DEV", "1")     # the profiled twins live in libtulip_hip_dev.so (include/tulip_hip.h, conventions)
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -2,6 +2,8 @@
 end of prologue / end of k-loop / end of write-out, for the grouped launch of one block.  The counters of different
 XCDs have different bases: only differences inside a workgroup mean something; the tick is about the shader clock
 (prologue + k-loop + write-out of the slowest workgroup ~ the kernel's duration x 1.7 GHz)."""
+import os as _os
+_os.environ.setdefault("TULIP_HIP_DEV", "1")     # the profiled twins live in libtulip_hip_dev.so (include/tulip_hip.h, conventions)
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -141,6 +141,7 @@ SIGNATURES = {
     "tulip_stamp_realtime": [P, P],
     "tulip_abi_version": [],
     "tulip_build_arch": [],
+    "tulip_dev_variants": [],
 }
 
 (EPI_BF16, EPI_GELU_DUAL, EPI_GELU_BWD, EPI_F32, EPI_RESID_F32, EPI_PIXSHUF2_F32, _EPI_RETIRED_6,
@@ -153,32 +154,62 @@ class TulipHipError(RuntimeError):
     pass
 
 
-def load() -> ctypes.CDLL:
-    """dlopen the in-tree library (import torch first so it binds to torch's HIP runtime)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+DEV_LIB_PATH = os.path.join(_PKG, "libtulip_hip_dev.so")    # -DTULIP_DEV_VARIANTS=1: + the forms no step launches (tulip_hip.h)
+_libs = {}
+# (the engine's environment switches that select a development-only kernel form select the development build with it)
+_dev_depth = [1 if (os.environ.get("TULIP_HIP_DEV", "0") == "1" or os.environ.get("TULIP_SWIN96_RECOMPUTE", "0") != "0" or
+                    os.environ.get("TULIP_SWINW_SPLIT_BWD", "0") != "0" or os.environ.get("TULIP_FC1_GRAD_WIDE", "1") == "0" or
+                    os.environ.get("TULIP_FUSE_WIDE", "1") == "0") else 0]
+
+
+def _open(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
         raise TulipHipError(
-            f"{LIB_PATH} not found: build it with `python -m tulip_amd.csrc.build` "
+            f"{path} not found: build it with `python -m tulip_amd.csrc.build` "
             "(tulip_amd has no CPU or PyTorch fallback for the hot path)")
     import torch  # noqa: F401  (loads libamdhip64 first)
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise TulipHipError(f"symbol {name} missing from {LIB_PATH}") from e
+            raise TulipHipError(f"symbol {name} missing from {path}") from e
         fn.argtypes = argtypes
         fn.restype = c_char_p if name == "tulip_build_arch" else c_int
     if lib.tulip_abi_version() != ABI_VERSION:
-        raise TulipHipError("libtulip_hip.so ABI version mismatch; rebuild")
+        raise TulipHipError(f"{path}: ABI version mismatch; rebuild")
+    return lib
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library (import torch first so it binds to torch's HIP runtime): libtulip_hip.so, or -- inside
+    `dev_library()` / under TULIP_HIP_DEV=1 -- libtulip_hip_dev.so, the same symbols plus the kernel forms no step launches."""
+    global _lib
+    path = DEV_LIB_PATH if _dev_depth[0] and not os.environ.get("TULIP_HIP_LIB") else LIB_PATH
+    lib = _libs.get(path)
+    if lib is None:
+        lib = _libs[path] = _open(path)
     _lib = lib
     return lib
+
+
+class dev_library:
+    """with _lib.dev_library(): ...  -- the launches inside go to the development build (profiled twins, the recomputing C = 96
+    backward, the backward's split form, the h-saving wide forms).  Launches captured into a graph keep their library."""
+    def __enter__(self):
+        _dev_depth[0] += 1
+        return load()
+
+    def __exit__(self, *exc):
+        _dev_depth[0] -= 1
+        return False
 
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
         if rc == -1:
             raise TulipHipError(f"{what}: unsupported argument combination (TULIP_ERR_ARG)")
+        if rc == -3:
+            raise TulipHipError(f"{what}: this form exists only in the development build (TULIP_ERR_NOT_BUILT): "
+                                "`with tulip_amd._lib.dev_library():` or TULIP_HIP_DEV=1")
         raise TulipHipError(f"{what}: HIP launch failed (hipError_t {-rc - 1000})")

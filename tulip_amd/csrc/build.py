@@ -11,7 +11,7 @@ LIB = os.path.join(PKG, "libtulip_hip.so")
 ARCH = "gfx950"
 
 
-def _stale() -> bool:
+def _stale(LIB: str = LIB) -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
@@ -21,13 +21,18 @@ def _stale() -> bool:
 
 
 ASAN_LIB = os.path.join(PKG, "libtulip_hip_asan.so")
+DEV_LIB = os.path.join(PKG, "libtulip_hip_dev.so")      # -DTULIP_DEV_VARIANTS=1 (include/tulip_hip.h, conventions)
 
 
-def build(force: bool = False, verbose: bool = True, asan: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, asan: bool = False, dev: bool = True) -> str:
     """asan=True (`--asan`): the AddressSanitizer build, libtulip_hip_asan.so -- host code AND kernels instrumented
     (`-fsanitize=address -shared-libsan`, device side needs the xnack+ target; INTEGRATION.md, "Sanitizer build")."""
     if asan:
         return _build(ASAN_LIB, "_asan", ["-fsanitize=address", "-shared-libsan", "-g", "-O1"], f"{ARCH}:xnack+", verbose)
+    # both libraries of the one source set: the product library and the development build (same objects' worth of compiles
+    # again; `--no-dev` skips it)
+    if dev and (force or _stale(DEV_LIB)):
+        _build(DEV_LIB, "_dev", ["-O3", "-DTULIP_DEV_VARIANTS=1"], ARCH, verbose)
     if not force and not _stale():
         return LIB
     return _build(LIB, "", ["-O3"], ARCH, verbose)
@@ -66,4 +71,4 @@ def _build(LIB: str, suffix: str, flags, ARCH: str, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, asan="--asan" in sys.argv))
+    print(build(force="--force" in sys.argv, asan="--asan" in sys.argv, dev="--no-dev" not in sys.argv))

@@ -11,6 +11,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define TULIP_OK 0
 #define TULIP_ERR_ARG (-1)
 #define TULIP_ERR_LAUNCH (-2)
+// -DTULIP_DEV_VARIANTS=1 (libtulip_hip_dev.so): the forms a training / inference step never launches -- the profiled twins (in-kernel
+// clock stamps), the recomputing C = 96 backward, the backward's split form at C = 384, the wide blocks' training forms that save h
+// instead of gelu'(h).  The product library keeps their entry points (one symbol set, one header) and answers TULIP_ERR_NOT_BUILT.
+#ifndef TULIP_DEV_VARIANTS
+#define TULIP_DEV_VARIANTS 0
+#endif
+#define TULIP_ERR_NOT_BUILT (-3)
 
 #define TULIP_CHECK_LAUNCH()                                   \
     do {                                                       \

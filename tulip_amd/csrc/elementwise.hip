@@ -508,3 +508,4 @@ extern "C" int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream) {
 
 extern "C" int tulip_abi_version(void) { return TULIP_ABI_VERSION; }
 extern "C" const char* tulip_build_arch(void) { return "gfx950"; }
+extern "C" int tulip_dev_variants(void) { return TULIP_DEV_VARIANTS; }

@@ -583,7 +583,11 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& p, const int bx, cons
     const int nt = (kend - kbeg + 31) >> 5;
     // p.aux (unused by this form): optional profile buffer, 4 shader-clock stamps per workgroup (tools/wgrad_phases.py)
     unsigned long long* prof = (unsigned long long*)p.aux;
+#if TULIP_DEV_VARIANTS
 #define TULIP_WG_STAMP(k) do { if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TULIP_WG_STAMP(k) ((void)0)
+#endif
     TULIP_WG_STAMP(0);
     if (nt <= 0) return;                               // (uniform; the launcher never creates an empty chunk)
 
@@ -1246,6 +1250,9 @@ extern "C" int tulip_wgrad_group_adamw(const tulip_wgrad_item* items, int n, con
 // dev (tools/wgrad_phases.py): the grouped launch alone (no fold, no optimizer step) with 4 shader-clock stamps per workgroup
 extern "C" int tulip_wgrad_group_profiled(const tulip_wgrad_item* items, int n, void* workspace, int64_t workspace_bytes, int flags,
                                           void* stamps, hipStream_t stream) {
+#if !TULIP_DEV_VARIANTS
+    return TULIP_ERR_NOT_BUILT;
+#endif
     return wgrad_group_impl(items, n, nullptr, 0, workspace, workspace_bytes, flags & ~TULIP_WGRAD_FOLD, nullptr, stamps, stream);
 }
 

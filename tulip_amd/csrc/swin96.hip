@@ -937,12 +937,17 @@ static int swin96_fwd_impl(const tulip_swin96_desc* d, unsigned long long* prof,
     if (any && !(core && (!d->qkv == !d->fc1_pre))) return TULIP_ERR_ARG;
     const bool hgrad = (d->masked & TULIP_BLOCK_FC1_GRAD) != 0;
     const dim3 g(blocks), b(NT);
+#if TULIP_DEV_VARIANTS
     if (prof) {                                         // diagnostic twin: the full training forms only
         if (!any || !d->qkv) return TULIP_ERR_ARG;
         if (hgrad) hipLaunchKernelGGL((swin96_fwd_kernel<3, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((swin96_fwd_kernel<2, true>), g, b, 0, stream, a);
-    } else if (!any) hipLaunchKernelGGL((swin96_fwd_kernel<0, false>), g, b, 0, stream, a);
-    else if (!d->qkv) hipLaunchKernelGGL((swin96_fwd_kernel<1, false>), g, b, 0, stream, a);
+    } else if (any && !d->qkv) hipLaunchKernelGGL((swin96_fwd_kernel<1, false>), g, b, 0, stream, a);    // the lean form of the recomputing backward
+    else
+#else
+    if (prof || (any && !d->qkv)) return TULIP_ERR_NOT_BUILT;
+#endif
+    if (!any) hipLaunchKernelGGL((swin96_fwd_kernel<0, false>), g, b, 0, stream, a);
     else if (hgrad) hipLaunchKernelGGL((swin96_fwd_kernel<3, false>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((swin96_fwd_kernel<2, false>), g, b, 0, stream, a);
     TULIP_CHECK_LAUNCH();
@@ -985,12 +990,17 @@ static int swin96_bwd_impl(const tulip_swin96_bwd_desc* d, unsigned long long* p
     const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
     const bool hgrad = (d->masked & TULIP_BLOCK_FC1_GRAD) != 0;
     const dim3 g(blocks), b(NT);
+#if TULIP_DEV_VARIANTS
     if (prof) {
         if (recomp) hipLaunchKernelGGL((swin96_bwd_kernel<true, false, true>), g, b, 0, stream, a);
         else if (hgrad) hipLaunchKernelGGL((swin96_bwd_kernel<false, true, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((swin96_bwd_kernel<false, false, true>), g, b, 0, stream, a);
     } else if (recomp) hipLaunchKernelGGL((swin96_bwd_kernel<true, false, false>), g, b, 0, stream, a);
-    else if (hgrad) hipLaunchKernelGGL((swin96_bwd_kernel<false, true, false>), g, b, 0, stream, a);
+    else
+#else
+    if (prof || recomp) return TULIP_ERR_NOT_BUILT;
+#endif
+    if (hgrad) hipLaunchKernelGGL((swin96_bwd_kernel<false, true, false>), g, b, 0, stream, a);
     else hipLaunchKernelGGL((swin96_bwd_kernel<false, false, false>), g, b, 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;

@@ -173,7 +173,11 @@ struct DeepArgs {
     int B, H, W, wh, ww, sh, sw, masked, save, ngrp;
     float eps, scale;
 };
+#if TULIP_DEV_VARIANTS
 #define DEEP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEEP_STAMP(k) ((void)0)
+#endif
 
 // The group's T rows of an fp32 [M][C] tensor, LPT lanes per token (48 channels per lane): loaded FIRST in a launch (vmcnt retires
 // in order: behind the cold weight loads these rows -- the critical path of the prologue -- would wait for every one of them), then
@@ -801,6 +805,9 @@ extern "C" int tulip_swind_block_fwd(const tulip_swin96_desc* d, int C, int wh, 
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.out_bf16 = (bf16_t*)out_bf16;
     a.prof = (unsigned long long*)stamps;
+#if !TULIP_DEV_VARIANTS
+    if (stamps) return TULIP_ERR_NOT_BUILT;
+#endif
     a.B = d->B; a.H = d->H; a.W = d->W; a.wh = wh; a.ww = ww; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.save = all ? 1 : 0;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
@@ -842,6 +849,9 @@ extern "C" int tulip_swind_block_bwd(const tulip_swin96_bwd_desc* d, int C, int 
     a.dyb_m = (bf16_t*)d->d_out_mlp; a.dh = (bf16_t*)d->d_fc1_pre; a.dyb_a = (bf16_t*)d->d_out_attn; a.dqkv = (bf16_t*)d->d_qkv;
     a.dxn = d_norm_out; a.biaspart = d->bias_partials;
     a.prof = (unsigned long long*)stamps;
+#if !TULIP_DEV_VARIANTS
+    if (stamps) return TULIP_ERR_NOT_BUILT;
+#endif
     a.B = d->B; a.H = d->H; a.W = d->W; a.wh = wh; a.ww = ww; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.save = 1;
     a.scale = 0.17677669529663687f;

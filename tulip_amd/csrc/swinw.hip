@@ -107,7 +107,11 @@ struct SwinWArgs {
     // split form (two workgroups per window, MODE bit 4): fc2 partial sums [window][half][thread][2] f32x4, arrival tickets [window]
     float* xws; unsigned* tick; unsigned xws_bytes;
 };
+#if TULIP_DEV_VARIANTS
 #define TULIP_STAMP(k) do { if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * NWV + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TULIP_STAMP(k) ((void)0)        // (the product library's kernels carry no stamp branches: tulip_swinw_block_fwd_profiled answers TULIP_ERR_NOT_BUILT)
+#endif
 
 
 template <int C, int G>
@@ -549,10 +553,14 @@ int launch_fwd(const SwinWArgs& a, hipStream_t stream) {
         if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 9>), grid, block, 0, stream, a);
         else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 10>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 8>), grid, block, 0, stream, a);
-    } else if (a.qkv) {
+    } else if (a.qkv) {                                     // training form that saves h itself: development build only
+#if TULIP_DEV_VARIANTS
         if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 1>), grid, block, 0, stream, a);
         else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 2>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 0>), grid, block, 0, stream, a);
+#else
+        return TULIP_ERR_NOT_BUILT;
+#endif
     } else {                                                // inference form: no saved activations
         if (warm == 1) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 5>), grid, block, 0, stream, a);
         else if (warm == 2) hipLaunchKernelGGL((swinw_fwd_kernel<C, G, 6>), grid, block, 0, stream, a);
@@ -994,12 +1002,16 @@ __global__ __launch_bounds__((GeoB<C, G>::NT)) void swinw_bwd_kernel(const SwinW
 }
 
 int launch_bwd_split(const SwinWBwdArgs& a, hipStream_t stream) {
+#if TULIP_DEV_VARIANTS      // built, bit-tested, 5.6 us faster per launch in isolation and 34 us slower per step (profiles/README.md): not shipped
     const int windows = a.B * (a.H / 2) * (a.W / 8);
     const dim3 grid(2 * windows), block(GeoB<384, 1>::NT);
     if (!(a.masked & TULIP_BLOCK_NO_WARM)) hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 13>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((swinw_bwd_kernel<384, 1, 12>), grid, block, 0, stream, a);
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
+#else
+    return TULIP_ERR_NOT_BUILT;
+#endif
 }
 template <int C, int G>
 int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
@@ -1011,10 +1023,14 @@ int launch_bwd(const SwinWBwdArgs& a, hipStream_t stream) {
         if (warm == 1) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 5>), grid, block, 0, stream, a);
         else if (warm == 2) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 6>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 4>), grid, block, 0, stream, a);
-    } else {
+    } else {                                    // h itself in the fc1_pre buffer: development build only
+#if TULIP_DEV_VARIANTS
         if (warm == 1) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 1>), grid, block, 0, stream, a);
         else if (warm == 2) hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 2>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((swinw_bwd_kernel<C, G, 0>), grid, block, 0, stream, a);
+#else
+        return TULIP_ERR_NOT_BUILT;
+#endif
     }
     TULIP_CHECK_LAUNCH();
     return TULIP_OK;
@@ -1139,6 +1155,9 @@ static int swinw_fwd_impl(const tulip_swin96_desc* d, int C, void* out_bf16, uns
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.out_bf16 = (bf16_t*)out_bf16;
     a.prof = prof;
+#if !TULIP_DEV_VARIANTS
+    if (prof) return TULIP_ERR_NOT_BUILT;
+#endif
     {   // every saved-activation pointer NULL: the inference form
         const bool any = d->xn1 || d->qkv || d->attn_out || d->x1 || d->xn2 || d->fc1_pre || d->fc1_act || d->mean1 || d->rstd1 ||
                          d->mean2 || d->rstd2;
