@@ -68,8 +68,10 @@ typedef struct ihipStream_t* hipStream_t;
 #define TULIP_GEMM_ACCUMULATE 1
 #define TULIP_GEMM_NO_TOUCH 0x100
 #define TULIP_GEMM_CHECKED 0x200
-/* the 192 x 192 loader-wave kernel of the mid-size shapes (M >= 1024, >= 160 such tiles, K range a multiple of 64): never /
- * wherever it fits (A/B measurements and the bit-compare test; the two kernels sum k in the same order per output element) */
+/* TULIP_GEMM_MID: run the 192 x 192 loader-wave kernel (csrc/gemm.hip, gemm_mid_tile) wherever it fits (a_trans = 0, K range per
+ * split a multiple of 64, M, N >= 96, not the PixelShuffle epilogues) -- the caller's choice, for narrow outputs over a deep K at
+ * M >= 4096 with the K split that fills the chip; bit-identical results (both kernels sum k in the same order per output element).
+ * TULIP_GEMM_NO_MID is accepted and means the default (never, unless asked). */
 #define TULIP_GEMM_NO_MID 0x400
 #define TULIP_GEMM_MID 0x800
 int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,

@@ -32,6 +32,7 @@ def main():
                      ("segments_bf16", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16")),
                      ("segments_bf16_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16",
                                                          bucket_adamw=True)),
+                     ("segments_sharded", dict(force_segments=True, bucket_mb=0.05, exchange="sharded")),
                      ("eager_plain", dict(use_graph=False)),
                      ("eager_segments", dict(force_segments=True, bucket_mb=0.05, use_graph=False))]:
         torch.manual_seed(11)
@@ -42,6 +43,7 @@ def main():
         tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, **kw)
         tr.load_batch(lo.cuda(), hi.cuda())
         losses = [tr.step().clone() for _ in range(steps)]
+        tr.gather_state()              # (exchange="sharded": the master whole again; a no-op otherwise)
         torch.cuda.synchronize()
         res[name] = {"flat": tr.eng.params.flat.cpu(), "losses": torch.stack(losses).cpu(),
                      "segments": len(tr._segments[True]) if tr.use_graph else 0, "buckets": len(tr.bucketer.buckets),

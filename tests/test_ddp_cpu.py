@@ -64,6 +64,64 @@ def test_single_process_is_a_no_op():
     assert torch.equal(flat, torch.arange(20.0)) and b.world == 1
 
 
+# ---------------------------------------------------------------------------------------------- the sharded exchange (round 5)
+def _sharded_worker(rank, world, port, buckets, replicated, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tulip_amd.ddp import ShardedExchange, shard_bounds
+        gs = [torch.randn(total, generator=torch.Generator().manual_seed(300 + r)) for r in range(world)]
+        gsum = gs[0] + gs[1]
+        p0 = torch.randn(total, generator=torch.Generator().manual_seed(7))
+        ref = p0 - 0.1 * gsum                                        # what the all-reduce plan's (toy) optimizer step gives every rank
+        g, p = gs[rank].clone(), p0.clone()
+        shadow = p0.bfloat16()
+        ex = ShardedExchange(buckets, replicated, torch.device("cpu"))
+        stepped = torch.zeros(total, dtype=torch.bool)
+        for tag, a, b in buckets:                                    # (completion order)
+            blocks = ex.reduce(tag, g)
+            s_, lo, hi, me = shard_bounds(a, b, world, rank)
+            assert torch.equal(g[lo:hi], gsum[lo:hi]) and torch.equal(g[me:b], gsum[me:b])
+            for x, y in replicated:
+                x, y = max(x, a), min(y, b)
+                if x < y:
+                    assert torch.equal(g[x:y], gsum[x:y]), (tag, x, y)
+            idx = (blocks.long()[:, None] * 64 + torch.arange(64)[None, :]).reshape(-1)
+            idx = idx[idx < total]
+            assert int(blocks.min()) * 64 >= a and int(blocks.max()) * 64 < b and len(set(blocks.tolist())) == blocks.numel()
+            p[idx] = p[idx] - 0.1 * g[idx]                           # the step, on what this rank owns / keeps replicated
+            shadow[idx] = p[idx].bfloat16()
+            stepped[idx] = True
+            ex.gather_shadow(tag, shadow)
+        ok_shadow = torch.equal(shadow, ref.bfloat16())              # every rank reads the same, complete bf16 weights
+        rep_ok = all(torch.equal(p[x:y], ref[x:y]) for x, y in replicated)      # fp32-read parameters current everywhere
+        stale = not torch.equal(p, ref)                               # ... the rest of the master only on its owner
+        ex.gather_state(p)
+        wb = ex.wire_bytes_per_step()
+        out[rank] = (bool(ok_shadow), bool(rep_ok), bool(stale), bool(torch.equal(p, ref)), float(stepped.float().mean()),
+                     wb["sharded"] / wb["allreduce_fp32"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_exchange_two_ranks_gloo():
+    """tulip_amd.ddp.ShardedExchange (optional plan, off by default): reduce-scatter -> step on the owned
+    shard + the fp32-read (replicated) ranges -> all-gather of the bf16 shadow.  World size 2 over gloo, a toy optimizer step:
+    both replicas end with the bf16 shadow of the all-reduce plan bit for bit, the replicated ranges' fp32 values too, each
+    rank steps ~half of the buffer, gather_state() restores the whole master, and the ring-model wire bytes are ~3/4."""
+    total = 64 * 300
+    buckets = [("dec0", 0, 64 * 90), ("enc3", 64 * 90, 64 * 211), ("embed", 64 * 211, total)]       # 211 - 90 = 121 blocks: odd
+    replicated = [(64 * 3, 64 * 4), (64 * 50, 64 * 52), (64 * 89, 64 * 92), (64 * 150, 64 * 151), (64 * 299, total)]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, _free_port(), buckets, replicated, total, out), nprocs=2, join=True)
+    for r in (0, 1):
+        ok_shadow, rep_ok, stale, whole, frac, wire = out[r]
+        assert ok_shadow and rep_ok and stale and whole, out[r]
+        assert 0.45 <= frac <= 0.60, frac
+        assert 0.74 <= wire <= 0.80, wire
+
+
 # ---------------------------------------------------------------------------------------------- the exchange chooser
 _BASE_BUCKETS = [("dec0", 0, 5_200_000), ("enc3", 5_200_000, 21_700_000), ("enc1", 21_700_000, 26_900_000),
                  ("embed", 26_900_000, 27_150_000)]       # tulip_base, bucket_mb = 16 (elements)

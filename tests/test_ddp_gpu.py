@@ -69,3 +69,30 @@ def test_two_ranks_match_single_process_on_the_full_batch(tmp_path, use_graph, a
     assert ((u_ddp - u_ref).abs() <= 2e-5).float().mean().item() >= 0.995
     full = torch.stack(losses).cpu()[:, 0]
     assert abs(got["losses"][-1, 0].item() - full[-1].item()) < 0.2 * full[-1].item()
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_sharded_exchange_equals_the_per_bucket_allreduce_plan(tmp_path, use_graph):
+    """Trainer(exchange="sharded") (round 5, optional plan: reduce-scatter -> AdamW on the owned shard and on the fp32-read
+    parameters -> all-gather of the bf16 shadow) against the per-bucket all-reduce plan, two ranks sharing the GPU over gloo, three
+    steps: with two ranks both plans add the same two gradients, so the bf16 shadows the kernels read, and after gather_state()
+    the fp32 master and both moments, must be identical bit for bit; the replicas' shadows agree with each other before any
+    gather; a small fraction of the parameters stays replicated; each rank's master was indeed partial before the gather."""
+    res = {}
+    for exchange in ("allreduce", "sharded"):
+        out = tmp_path / f"{exchange}.pt"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), str(out),
+               "1" if use_graph else "0", "3", "1", "same", exchange]
+        env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", TULIP_BUCKET_ADAMW="1")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res[exchange] = torch.load(out)
+    a, s = res["allreduce"], res["sharded"]
+    assert s["same_on_all_ranks"] and s["shadow_same"] and s["master_was_partial"] and s["bucket_adamw"]
+    assert 0 < s["replicated_fraction"] < 0.10, s["replicated_fraction"]      # (the tiny test model; ~1 % for tulip_base)
+    w = s["wire"]
+    print(f"replicated fraction {s['replicated_fraction']:.4f}; wire bytes sharded / all-reduce {w['sharded'] / w['allreduce_fp32']:.3f}")
+    assert torch.equal(s["shadow"], a["shadow"])
+    assert torch.equal(s["flat"], a["flat"]) and torch.equal(s["m"], a["m"]) and torch.equal(s["v"], a["v"])
+    assert (a["losses"] - s["losses"]).abs().max().item() == 0.0

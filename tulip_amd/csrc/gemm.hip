@@ -56,7 +56,7 @@ struct GemmArgs {
     int psH, psW;
     int touch;   // first touch of the cold weight panel split between the M-tile workgroups (off: TULIP_GEMM_NO_TOUCH)
     int checked; // the bounds-checked kernels even for whole-tile shapes (TULIP_GEMM_CHECKED: bit-compare tests)
-    int mid;     // the 192 x 192 kernel for mid-size shapes: 1 = by the launcher's rule, 0 = never (TULIP_GEMM_NO_MID), 2 = wherever it fits (TULIP_GEMM_MID)
+    int mid;     // the 192 x 192 kernel for mid-size shapes: 2 = the caller asked for it (TULIP_GEMM_MID: wherever it fits), else never
     int vec_ok;  // the vectorised PixelShuffle / inverse-shuffle write-outs may be used: pitches and bases aligned for their 16-B / 4-B stores
 };
 
@@ -64,12 +64,6 @@ struct GemmArgs {
 // launch heuristics (compile-time; mirrored by bench.py's kernel-name bookkeeping)
 #define TULIP_GEMM_MID_TILES 512    // taller tiles only while the launch still has this many of them (two rounds of the chip)
 #define TULIP_GEMM_KSUB_GRID 400    // 128-deep k stages for grids up to this many workgroups
-#ifndef TULIP_GEMM_MID_MIN
-#define TULIP_GEMM_MID_MIN 160      // 192 x 192 tiles (x K splits) a launch needs for the mid-size kernel
-#endif
-#ifndef TULIP_GEMM_MID_MIN_M
-#define TULIP_GEMM_MID_MIN_M 1024
-#endif
 #ifndef TULIP_WGRAD_RING
 #define TULIP_WGRAD_RING 3
 #endif
@@ -1086,12 +1080,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p, 
 template <bool A_T, bool B_T>
 int launch(const GemmArgs& p, int splits, hipStream_t stream) {
     if constexpr (!A_T) {
-        // the 192 x 192 loader-wave kernel: whole 64-deep stages, at least TULIP_GEMM_MID_MIN tiles (a launch of fewer leaves most
-        // of the chip idle whatever the tile does) of a matrix tall enough to be worth it; p.mid: 1 = by this rule, 2 = forced, 0 = never
+        // the 192 x 192 loader-wave kernel (whole 64-deep stages only): where the CALLER asks for it (TULIP_GEMM_MID) -- it wins on
+        // narrow outputs over a deep K with the K split that fills the chip and loses elsewhere (profiles/r5_gemm_big.txt; a rule
+        // of the launcher's own by tile count put the 32 768 x 96 x 192 skip Linear of the batch-8 step on it: 11 -> 17.6 us), so
+        // the choice is the engine's (TulipEngine._gemm), not a heuristic down here
         const int gx = (p.N + 191) / 192, gy = (p.M + 191) / 192;
         const bool fits = p.kchunk % 64 == 0 && p.K % p.kchunk == 0 && p.N >= 96 && p.M >= 96 &&
                           p.epi != TULIP_EPI_PIXSHUF2_F32 && p.epi != TULIP_EPI_UNSHUF2_BF16;
-        if (fits && (p.mid == 2 || (p.mid == 1 && p.M >= TULIP_GEMM_MID_MIN_M && gx * gy * splits >= TULIP_GEMM_MID_MIN))) {
+        if (fits && p.mid == 2) {
             hipLaunchKernelGGL((gemm_mid_kernel<B_T>), dim3(gx * gy * splits), dim3(512), 0, stream, p, gx, gy);
             TULIP_CHECK_LAUNCH();
             return TULIP_OK;

@@ -75,6 +75,95 @@ class GradBucketer:
         self.pending.clear()
 
 
+# ---------------------------------------------------------------------------------------------- sharded optimizer exchange
+def shard_bounds(a: int, b: int, world: int, rank: int, align: int = 64) -> Tuple[int, int, int, int]:
+    """Bucket [a, b) (a, b multiples of `align`) -> (s, lo, hi, me): `world` shards of s elements (a multiple of `align`) cover
+    [a, me), rank r owns [a + r s, a + (r + 1) s) = [lo, hi) for this rank; [me, b) is the remainder (< world * align elements)
+    that every rank keeps whole."""
+    s = ((b - a) // (world * align)) * align
+    return s, a + rank * s, a + (rank + 1) * s, a + world * s
+
+
+class ShardedExchange:
+    """Optional exchange plan (Trainer(exchange="sharded"); off by default, never measured on more than one GPU): per bucket
+      reduce-scatter of the fp32 gradients  ->  AdamW on the OWNED 1/N shard (fp32 master + moments sharded: optimizer HBM traffic
+      / N)  ->  all-gather of the bf16 shadow the kernels read
+    instead of an all-reduce and a full optimizer step on every rank: 4 + 2 instead of 4 + 4 wire bytes per parameter.
+    The kernels read ~1 % of the parameters as FP32 straight from the master buffer (biases, LayerNorm vectors, bias tables, the
+    patch-embedding / decoder convolutions: `replicated`, a list of (start, end) element ranges inside the flat buffer, recorded
+    by FlatParams.p32): those stay replicated -- their gradients are all-reduced through one small staging buffer per bucket and
+    every rank steps them -- so that only bf16 has to travel back.  Works on CPU tensors with gloo (tests/test_ddp_cpu.py).
+    After a step the fp32 master and the moments of a rank are current on its shards and on the replicated ranges only:
+    gather_state() before anything reads them whole (checkpoints, state_dict, a replica check)."""
+
+    def __init__(self, buckets: Sequence[Tuple[str, int, int]], replicated: Sequence[Tuple[int, int]], device,
+                 process_group: Optional[dist.ProcessGroup] = None, align: int = 64):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.align = align
+        self.plan = {}
+        smax = 0
+        for tag, a, b in buckets:
+            s, lo, hi, me = shard_bounds(a, b, self.world, self.rank, align)
+            # replicated ranges of this bucket, clipped to its sharded part (the remainder is replicated anyway)
+            rep = [(max(x, a), min(y, me)) for x, y in replicated if x < me and y > a]
+            idx = (torch.cat([torch.arange(x, y, dtype=torch.int64) for x, y in rep]) if rep else
+                   torch.zeros(0, dtype=torch.int64)).to(device)
+            # 64-element blocks this rank steps: its shard, the replicated ranges, the remainder
+            blk = set(range(lo // align, hi // align)) | set(range(me // align, -(-b // align)))
+            for x, y in rep:
+                blk |= set(range(x // align, -(-y // align)))
+            blocks = torch.tensor(sorted(blk), dtype=torch.int32, device=device)
+            self.plan[tag] = dict(a=a, b=b, s=s, lo=lo, hi=hi, me=me, idx=idx, blocks=blocks,
+                                  stage=torch.zeros(max(int(idx.numel()), 1), dtype=torch.float32, device=device))
+            smax = max(smax, s)
+        self.rs_out = torch.zeros(max(smax, 1), dtype=torch.float32, device=device)
+        self.ag_in = torch.zeros(max(smax, 1), dtype=torch.bfloat16, device=device)
+
+    def reduce(self, tag: str, g: torch.Tensor):
+        """g[a:b) holds this rank's gradients -> afterwards the SUM over ranks on this rank's shard, on the replicated ranges
+        and on the remainder (the other shards keep local values nobody reads).  Blocking on gloo; stream-ordered on RCCL."""
+        q = self.plan[tag]
+        a, b, s, lo, hi, me = q["a"], q["b"], q["s"], q["lo"], q["hi"], q["me"]
+        n = int(q["idx"].numel())
+        if n:
+            torch.index_select(g, 0, q["idx"], out=q["stage"][:n])          # local values, before the shard is overwritten
+        if s:
+            dist.reduce_scatter_tensor(self.rs_out[:s], g[a:me], op=dist.ReduceOp.SUM, group=self.pg)
+            g[lo:hi].copy_(self.rs_out[:s])
+        if n:
+            dist.all_reduce(q["stage"][:n], op=dist.ReduceOp.SUM, group=self.pg)
+            g.index_copy_(0, q["idx"], q["stage"][:n])
+        if me < b:
+            dist.all_reduce(g[me:b], op=dist.ReduceOp.SUM, group=self.pg)
+        return q["blocks"]
+
+    def gather_shadow(self, tag: str, shadow: torch.Tensor):
+        """every rank's freshly stepped bf16 shard -> all ranks (the replicated ranges arrive as what every rank computed anyway)"""
+        q = self.plan[tag]
+        if q["s"]:
+            self.ag_in[:q["s"]].copy_(shadow[q["lo"]:q["hi"]])
+            dist.all_gather_into_tensor(shadow[q["a"]:q["me"]], self.ag_in[:q["s"]], group=self.pg)
+
+    def gather_state(self, *flats: torch.Tensor):
+        """fp32 master / moments: every shard from its owner (in place)"""
+        for q in self.plan.values():
+            if not q["s"]:
+                continue
+            for t in flats:
+                mine = t[q["lo"]:q["hi"]].clone()
+                dist.all_gather_into_tensor(t[q["a"]:q["me"]], mine, group=self.pg)
+
+    def wire_bytes_per_step(self) -> dict:
+        """what one rank sends per step under the ring model, against the all-reduce of the same buckets"""
+        f = (self.world - 1) / self.world
+        shard = sum(q["me"] - q["a"] for q in self.plan.values())
+        rep = sum(int(q["idx"].numel()) + q["b"] - q["me"] for q in self.plan.values())
+        total = sum(q["b"] - q["a"] for q in self.plan.values())
+        return {"sharded": f * (4 * shard + 2 * shard) + 2 * f * 4 * rep, "allreduce_fp32": 2 * f * 4 * total}
+
+
 # ---------------------------------------------------------------------------------------------- choosing the exchange
 # Where in the backward a completion group's last gradient has been launched, as a fraction of the backward's duration
 # (tools/step_stamps.py on tulip_base, KITTI, batch 8: profiles/r3_step_stamps.txt; other depths: evenly spaced).

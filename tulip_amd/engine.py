@@ -97,6 +97,7 @@ class FlatParams:
             named[n].data = v
         self.base32 = self.flat.data_ptr()
         self.base16 = self.shadow.data_ptr()
+        self.fp32_read = set()
         self.shadow_dirty = True
         # the bf16 shadow is current but the fragment-major copies of the fused wide blocks are not: a Trainer rewrites them
         # at the START of its next step, beside the head of the forward (Trainer.pack_at_step_start); every other consumer of
@@ -142,6 +143,9 @@ class FlatParams:
         return order, marks
 
     def p32(self, name: str) -> int:
+        # (every launch argument that reads a parameter as FP32 from the master buffer passes through here: the sharded exchange
+        # plan keeps exactly these tensors replicated, Trainer(exchange="sharded"))
+        self.fp32_read.add(name)
         return self.base32 + 4 * self.offset[name]
 
     def p16(self, name: str) -> int:
@@ -200,9 +204,10 @@ class FlatParams:
         self.packed_t = torch.zeros(max(off, ALIGN) if with_transposes else ALIGN, dtype=torch.bfloat16, device=self.device)
         self._pk_entries, self._pk_joined = {}, {}
         for width, names in names_by_width.items():
-            # part 0: the encoder's blocks (read first in a forward), part 1: the decoder's ("layers_up."), see refresh_transposes
-            for part in (0, 1):
-                sel = [n for n in names if n.startswith("layers_up.") == bool(part)]
+            # part 0: the encoder's blocks (read first in a forward), part 1: the decoder's ("layers_up."), part 2: the deep stages'
+            # (C >= 768: 14 / 57 MB of weights per block, first read three stages into the forward), see refresh_transposes
+            for part in (0, 1, 2):
+                sel = [n for n in names if (2 if width >= 768 else int(n.startswith("layers_up."))) == part]
                 ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
                        for n in sel]
                 if with_transposes:
@@ -217,15 +222,16 @@ class FlatParams:
     def p16t(self, name: str) -> int:
         return self.packed_t.data_ptr() + 2 * self.pk_offset[name]
 
-    def refresh_transposes(self, part: Optional[int] = None):
-        """One launch for the copies of every active width (up to TULIP_PACK_MAX matrices per launch).  part = 0 / 1: only the
-        encoder's / the decoder's blocks (the Trainer's forward rewrites the two halves at different points, _issue_pack)."""
+    def refresh_transposes(self, part: Optional[int] = None, also: Tuple[int, ...] = ()):
+        """One launch for the copies of every active width (up to TULIP_PACK_MAX matrices per launch).  part = 0 / 1 / 2: only the
+        encoder's / the decoder's wide blocks / the deep stages' blocks (the Trainer's forward rewrites the pieces at different
+        points, _issue_pack)."""
         widths = tuple(sorted(getattr(self, "pk_active", ())))
         if not widths:
             return
-        key = (widths, part)
+        key = (widths, part, also)
         if key not in self._pk_joined:
-            parts = (0, 1) if part is None else (part,)
+            parts = (0, 1, 2) if part is None else (part,) + tuple(also)
             self._pk_joined[key] = ops.pack_items([e for width in widths for q in parts for e in self._pk_entries[(width, q)]])
         items, n = self._pk_joined[key]
         if n:
@@ -722,12 +728,15 @@ class TulipEngine:
     # chip idle -- and joined in front of the first decoder block that streams a copy: beside the 96-wide blocks at the head
     # of the forward the whole refresh cost those blocks ~15 us each (tools/step_stamps.py).  TULIP_SPLIT_PACK=0: one piece.
     split_pack = os.environ.get("TULIP_SPLIT_PACK", "1") != "0"
+    # the deep stages' copies as a third piece forked in front of stage 2 (run_forward): measured flat (1.953 vs 1.955 ms, three
+    # pairs, profiles/r5_ab_deep_pack.txt) -- wherever the 114 MB of pack traffic run, they cost the chain the same; off
+    deep_pack = os.environ.get("TULIP_DEEP_PACK", "0") != "0"
     _packs = None
 
-    def _fork_pack(self, part):
+    def _fork_pack(self, part, also=()):
         ev = torch.cuda.Event()
         ev.record()
-        self._packs[part] = [ev, False, False]
+        self._packs[part] = [ev, False, False, tuple(also)]
 
     def _issue_pack(self):
         """Enqueue the forked halves on the side stream -- called after the chain's next kernel (the graph executor keeps a
@@ -737,7 +746,7 @@ class TulipEngine:
                 st = self._side_streams[0]
                 st.wait_event(pk[0])
                 with torch.cuda.stream(st):
-                    self.params.refresh_transposes(part)
+                    self.params.refresh_transposes(part, pk[3])
                 pk[1] = True
 
     def _join_pack(self, prefix: Optional[str] = None):
@@ -745,11 +754,18 @@ class TulipEngine:
         if not self._packs:
             return
         self._issue_pack()
-        need = [q for q in self._packs if prefix is None or q is None or q == int(prefix.startswith("layers_up."))]
+        mine = None if prefix is None else (2 if self._deep_prefix(prefix) else int(prefix.startswith("layers_up.")))
+        need = [q for q in self._packs if mine is None or q is None or q == mine or mine in self._packs[q][3]]
         if any(not self._packs[q][2] for q in need):
             torch.cuda.current_stream().wait_stream(self._side_streams[0])     # (one side stream: waits for all issued halves)
             for pk in self._packs.values():
                 pk[2] = pk[2] or pk[1]
+
+    def _deep_prefix(self, prefix: str) -> bool:
+        d = getattr(self, "_deep_prefixes", None)
+        if d is None:
+            d = self._deep_prefixes = frozenset(sp.prefix for sp in self.blocks if sp.C >= 768)
+        return prefix in d
 
     def _stage_fwd(self, P: Plan, specs: List[BlockSpec], xin, out_bf16=None):
         """out_bf16: bf16 copy of the stage output, written by the last block's fc2 epilogue."""
@@ -816,12 +832,19 @@ class TulipEngine:
                             out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E,
                             draw=pend[1] if pend is not None else None)
         two_packs = pack_on_side and W_.pk_active and self.split_pack and nl > 2
+        deep_pack = two_packs and self.deep_pack and nl >= 4 and any(w >= 768 for w in W_.pk_active)
         if pack_on_side and W_.pk_active:
-            self._fork_pack(0 if two_packs else None)
+            self._fork_pack(0 if two_packs else None, also=(2,) if (two_packs and not deep_pack) else ())
         # every encoder stage input is x_save[s]: its bf16 copy goes straight into the second half of the level's
         # concat buffer (tulip.py:715) from the kernel that produces it
         x = None
+        # round 5 (TULIP_DEEP_PACK=1, off): the deep stages' copies (57 MB read + 57 MB written per step for tulip_base's stage 3) as a
+        # piece of their own, forked in front of stage 2 -- beside the C = 384 blocks, which stream weights from L2 and leave HBM
+        # alone -- instead of riding in piece 0 beside the HBM-bound 96-wide blocks at the head of the forward (the second of them
+        # takes 66 instead of 32 us there in the traced step): the step does not notice (profiles/README.md round 5)
         for s in range(nl):
+            if deep_pack and s == 2:
+                self._fork_pack(2)
             if two_packs and s == nl - 1:
                 self._fork_pack(1)
             x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"],

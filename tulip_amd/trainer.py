@@ -41,13 +41,17 @@ class Trainer:
                  weight_decay: float = 0.01, device=None, use_graph: bool = True, process_group=None,
                  bucket_mb: float = 16.0, accum_iter: int = 1, track_grad_norm: bool = False,
                  force_segments: bool = False, bucket_adamw: Optional[bool] = None, grad_dtype: str = "fp32",
-                 attn_fp8: Optional[bool] = None):
+                 attn_fp8: Optional[bool] = None, exchange: str = "allreduce"):
         """force_segments: run the N>1 step structure (graph segments cut at the bucket points, one all-reduce per
         bucket between replays) in a one-rank process group too -- how the RCCL path is exercised on a single GPU.
         bucket_adamw: None = environment default (TULIP_BUCKET_ADAMW, off).
         grad_dtype: "fp32" (DistributedDataParallel's exchange, main_lidar_upsampling.py:277) or "bf16": every bucket is
         cast to bf16 before its all-reduce (half the bytes on the xGMI links) and back into the fp32 gradient buffer in
-        front of AdamW, whose moments and master weights stay fp32."""
+        front of AdamW, whose moments and master weights stay fp32.
+        exchange: "allreduce" (default) or "sharded" (tulip_amd.ddp.ShardedExchange, round 5; optional, never measured on more
+        than one GPU): per bucket reduce-scatter -> AdamW on the owned shard and on the parameters the kernels read in fp32 ->
+        all-gather of the bf16 shadow, on the optimizer stream beside the rest of the backward.  The fp32 master and the moments
+        are then current only where this rank steps them: gather_state() (called by state_dict()) makes them whole."""
         self.model = model
         device = device or torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -90,8 +94,16 @@ class Trainer:
         # after the last bucket, the order the reference's DDP + optimizer.step() has.
         if bucket_adamw is None:
             bucket_adamw = os.environ.get("TULIP_BUCKET_ADAMW", "0") == "1"
+        if exchange not in ("allreduce", "sharded"):
+            raise ValueError("exchange must be 'allreduce' or 'sharded'")
+        self.exchange = exchange if self.segmented else "allreduce"
+        if self.exchange == "sharded":
+            if track_grad_norm or grad_dtype != "fp32" or self.accum_iter != 1:
+                raise ValueError("exchange='sharded': fp32 gradients, no gradient-norm read-out, accum_iter == 1")
+            bucket_adamw = True                      # the plan IS a per-bucket optimizer
         self.bucket_adamw = self.segmented and not track_grad_norm and bool(bucket_adamw)
         self._opt_stream = torch.cuda.Stream(device=device) if self.bucket_adamw else None
+        self._sharded = None                         # built at the first bucket (FlatParams.fp32_read is complete by then)
         # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
         # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
@@ -188,6 +200,10 @@ class Trainer:
         the collective on the optimizer stream (work.wait() is a stream-level dependency for RCCL)."""
         if cast:
             self._cast_bucket_down(tag)
+        if self.exchange == "sharded":
+            if tag in self.bucketer.by_tag:
+                self._sharded_bucket(tag)
+            return
         r = self.bucketer.on_group_done(tag, self.g if self.gb is None else self.gb, keep=not self.bucket_adamw)
         if r is None or not self.bucket_adamw:
             return
@@ -197,6 +213,32 @@ class Trainer:
             if self.gb is not None:
                 ops.cast_bf16_f32(self.gb.data_ptr() + 2 * a, self.g.data_ptr() + 4 * a, b - a)
             self._adamw_range(a, b)
+
+    def _sharded_bucket(self, tag):
+        """exchange="sharded": reduce-scatter -> AdamW on what this rank steps -> all-gather of the bf16 shadow, all on the
+        optimizer stream behind the bucket's last producer (the caller's stream position)."""
+        W = self.eng.params
+        if self._sharded is None:
+            from .ddp import ShardedExchange
+            rep = sorted((W.offset[n], W.offset[n] + W.numel[n]) for n in W.fp32_read)
+            self._sharded = ShardedExchange(self.bucketer.buckets, rep, self.device, self.process_group)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._opt_stream):
+            self._opt_stream.wait_event(ev)
+            if self.bucketer.dry:
+                return
+            blocks = self._sharded.reduce(tag, self.g)
+            ops.adamw_blocks(W.flat, self.g, self.m, self.v, W.shadow, blocks, blocks.numel(), self.hyper, W.decay_mask,
+                             zero_grad=not self.grad_overwrite)
+            self._sharded.gather_shadow(tag, W.shadow)
+
+    def gather_state(self):
+        """exchange="sharded": fp32 master and both moments whole on every rank again (checkpoints, state_dict(), evaluation
+        through anything that re-derives the shadow from the master).  A no-op for the all-reduce plans."""
+        if self._sharded is not None:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._sharded.gather_state(self.eng.params.flat, self.m, self.v)
 
     def _finish_buckets(self):
         if self.bucket_adamw:
@@ -228,6 +270,7 @@ class Trainer:
     # {'model', 'optimizer', 'epoch', ...}: this is the 'optimizer' entry of the fused AdamW)
     def state_dict(self) -> dict:
         W = self.eng.params
+        self.gather_state()
         cut = lambda flat, n: flat[W.offset[n]:W.offset[n] + W.numel[n]].view(W.shape[n]).clone()
         return {"step": self.t, "micro": self.micro, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
                 "weight_decay": self.wd, "accum_iter": self.accum_iter,
