@@ -753,9 +753,14 @@ class TulipEngine:
         """The chain waits for the halves a block with this prefix reads (None: for everything forked so far)."""
         if not self._packs:
             return
-        self._issue_pack()
         mine = None if prefix is None else (2 if self._deep_prefix(prefix) else int(prefix.startswith("layers_up.")))
         need = [q for q in self._packs if mine is None or q is None or q == mine or mine in self._packs[q][3]]
+        # (a piece this block does not read is NOT enqueued from here: it waits for _stage_fwd's _issue_pack behind the block's
+        # first kernel -- enqueued in front of it, the piece becomes the first successor of the chain's last node and the graph
+        # executor moves the chain to another queue and back: two ~9-us hops around the deep stage in the traced step; same-box
+        # A/B 1.938 -> 1.926 ms, three pairs, profiles/r5_ab_join_issue.txt)
+        if any(not self._packs[q][1] for q in need) or os.environ.get("TULIP_JOIN_ISSUES_ALL") == "1":      # (the switch: A/B only)
+            self._issue_pack()
         if any(not self._packs[q][2] for q in need):
             torch.cuda.current_stream().wait_stream(self._side_streams[0])     # (one side stream: waits for all issued halves)
             for pk in self._packs.values():
