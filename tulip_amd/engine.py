@@ -728,9 +728,11 @@ class TulipEngine:
     # chip idle -- and joined in front of the first decoder block that streams a copy: beside the 96-wide blocks at the head
     # of the forward the whole refresh cost those blocks ~15 us each (tools/step_stamps.py).  TULIP_SPLIT_PACK=0: one piece.
     split_pack = os.environ.get("TULIP_SPLIT_PACK", "1") != "0"
-    # the deep stages' copies as a third piece forked in front of stage 2 (run_forward): measured flat (1.953 vs 1.955 ms, three
-    # pairs, profiles/r5_ab_deep_pack.txt) -- wherever the 114 MB of pack traffic run, they cost the chain the same; off
-    deep_pack = os.environ.get("TULIP_DEEP_PACK", "0") != "0"
+    # the deep stages' copies as a third piece forked in front of stage 2 (run_forward): batch 8 1.9426 -> 1.9315 ms, batch 64 9.022 ->
+    # 9.007 (four interleaved runs each, same box, profiles/r5_ab_pack_layout2.txt; ONE piece for everything, TULIP_SPLIT_PACK=0:
+    # 1.9311 / 9.022).  (A first A/B read "flat": every piece was then enqueued in front of the deep stage's first kernel, _join_pack.)
+    deep_pack = os.environ.get("TULIP_DEEP_PACK", "1") != "0"
+    pack_layout = os.environ.get("TULIP_PACK_LAYOUT", "a")
     _packs = None
 
     def _fork_pack(self, part, also=()):
@@ -838,19 +840,23 @@ class TulipEngine:
                             draw=pend[1] if pend is not None else None)
         two_packs = pack_on_side and W_.pk_active and self.split_pack and nl > 2
         deep_pack = two_packs and self.deep_pack and nl >= 4 and any(w >= 768 for w in W_.pk_active)
+        # pack_layout (with a deep piece): "a" = three pieces (encoder's wide | deep | decoder's wide); "c" = two (all wide blocks in
+        # piece 0 | deep): one fork + join (~10 us of chain gaps) fewer; "d" = deep piece forked in front of stage 1 instead of 2
+        lay = self.pack_layout if deep_pack else "a"
         if pack_on_side and W_.pk_active:
-            self._fork_pack(0 if two_packs else None, also=(2,) if (two_packs and not deep_pack) else ())
+            also = ((2,) if (two_packs and not deep_pack) else ()) + ((1,) if lay in ("c", "e") else ())
+            self._fork_pack(0 if two_packs else None, also=also)
         # every encoder stage input is x_save[s]: its bf16 copy goes straight into the second half of the level's
         # concat buffer (tulip.py:715) from the kernel that produces it
         x = None
-        # round 5 (TULIP_DEEP_PACK=1, off): the deep stages' copies (57 MB read + 57 MB written per step for tulip_base's stage 3) as a
-        # piece of their own, forked in front of stage 2 -- beside the C = 384 blocks, which stream weights from L2 and leave HBM
-        # alone -- instead of riding in piece 0 beside the HBM-bound 96-wide blocks at the head of the forward (the second of them
-        # takes 66 instead of 32 us there in the traced step): the step does not notice (profiles/README.md round 5)
+        # round 5: the deep stages' copies (57 MB read + 114 MB written per step for tulip_base's stage 3) as a piece of their own,
+        # forked in front of stage 2 -- beside the C = 384 blocks, which stream weights from L2 and leave HBM alone -- instead of
+        # riding in piece 0 beside the HBM-bound 96-wide blocks at the head of the forward (the second of them took 66 instead
+        # of 32 us there in the traced step)
         for s in range(nl):
-            if deep_pack and s == 2:
+            if deep_pack and s == (1 if lay in ("d", "e") else 2):
                 self._fork_pack(2)
-            if two_packs and s == nl - 1:
+            if two_packs and s == nl - 1 and lay not in ("c", "e"):
                 self._fork_pack(1)
             x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"],
                                 out_bf16=P[f"lvl{s}.xb"] if (s == nl - 1 and nl > 1) else None)
