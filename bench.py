@@ -512,7 +512,7 @@ def replicas_identical(trainer, device) -> bool:
     return bool(torch.equal(lo_, hi_)) and bool(torch.isfinite(s).all())
 
 
-def reference_loop(args, device, steps=20, warmup=5):
+def reference_loop(args, device, steps=40, warmup=5):
     """The reference's OWN calling convention on the drop-in module, unchanged (engine_upsampling.py:69-100,
     util/misc.py:292-305, main_lidar_upsampling.py:282-283): torch.autocast around model(lo, hi), GradScaler
     scale -> backward -> unscale_ -> step -> update, torch.optim.AdamW(betas=(0.9, 0.95)) over timm-style decay groups,
@@ -545,14 +545,21 @@ def reference_loop(args, device, steps=20, warmup=5):
         one()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per = []
     for _ in range(steps):
-        v = one()
+        t1 = time.perf_counter()
+        v = one()                                   # (ends with the loop's own synchronize: a step's wall time is its own)
+        per.append(time.perf_counter() - t1)
     dt = time.perf_counter() - t0
+    per.sort()
     del model, opt
     torch.cuda.empty_cache()
     return {"metric": "range-images/sec training, the reference's loop body unchanged (autocast + GradScaler + "
                       "torch.optim.AdamW + loss.item() + synchronize per step) on the drop-in module",
             "value": round(args.batch * steps / dt, 2), "unit": "range-images/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            # (a host-bound loop of a few milliseconds: one hiccup of the box moves the mean of 20 steps by 5 %; the median says
+            # what a step takes)
+            "ms_per_step_median": round(per[len(per) // 2] * 1e3, 4), "ms_per_step_min": round(per[0] * 1e3, 4),
             "steps": steps, "warmup": warmup, "final_loss": round(v, 6), "grad_scale": scaler.get_scale()}
 
 
