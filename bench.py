@@ -503,6 +503,7 @@ def replicas_identical(trainer, device) -> bool:
     """Data-parallel replicas apply the same averaged gradients to the same weights: after any number of steps the flat
     parameter buffers of all ranks are equal bit for bit (DistributedDataParallel's invariant).  Checked through two order-
     sensitive checksums (MIN == MAX over ranks)."""
+    trainer.gather_state()        # (exchange="sharded": master and moments whole again first; a no-op for the all-reduce plans)
     flat = trainer.eng.params.flat
     w = torch.arange(1, 1025, device=device, dtype=torch.float64).repeat((flat.numel() + 1023) // 1024)[:flat.numel()]
     s = torch.stack([flat.double().sum(), (flat.double() * w).sum(), trainer.m.double().sum(), trainer.v.double().sum()])
@@ -645,6 +646,10 @@ def main():
                          "the measured bus bandwidth leaves it exposed and bf16 does not (tulip_amd.ddp.choose_comm_plan)")
     ap.add_argument("--bucket-adamw", default="auto", choices=["auto", "on", "off"],
                     help="N>1: the optimizer step per bucket behind that bucket's all-reduce (on) or once behind the last (off)")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded"],
+                    help="N>1: allreduce (default: per-bucket all-reduce, the plans choose_comm_plan picks from) or sharded (optional, "
+                         "never the default: reduce-scatter -> AdamW on the owned shard -> all-gather of the bf16 shadow, "
+                         "tulip_amd.ddp.ShardedExchange)")
     ap.add_argument("--bucket-mb", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -717,12 +722,16 @@ def main():
         plan_info["busbw_source"] = ("TULIP_BENCH_FAKE_BUSBW_GBPS (rehearsal)" if os.environ.get("TULIP_BENCH_FAKE_BUSBW_GBPS")
                                      else "collective_smoke, largest bucket")
         grad_dtype, bucket_adamw = plan_info["chosen"]["grad_dtype"], plan_info["chosen"]["bucket_adamw"]
+        if args.exchange == "sharded":           # asked for explicitly: fp32 reduce-scatter, the optimizer per bucket by construction
+            grad_dtype, bucket_adamw = "fp32", True
+            plan_info["reason"] += "; --exchange sharded requested (not one of the chooser's candidates)"
 
     def run_plan(gd, ba):
         """One Trainer on the chosen exchange: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize."""
         phase(f"trainer {gd} bucket_adamw={ba}")
         tr = Trainer(model, args.batch, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, device=device,
-                     use_graph=not args.no_graph, grad_dtype=gd, bucket_mb=args.bucket_mb, bucket_adamw=ba)
+                     use_graph=not args.no_graph, grad_dtype=gd, bucket_mb=args.bucket_mb, bucket_adamw=ba,
+                     exchange=args.exchange if world > 1 else "allreduce")
         trainer_ref[0] = tr
         lo, hi = synthetic(args, rank, device)
         tr.load_batch(lo, hi)
@@ -774,6 +783,7 @@ def main():
             drop(trainer)
             os.environ["TULIP_DETACH_BUCKETS"] = "0"
             grad_dtype, bucket_adamw = "fp32", False
+            args.exchange = "allreduce"
             trainer, dt, per_step, losses = run_plan(grad_dtype, bucket_adamw)
             same = replicas_identical(trainer, device)
         phase("comm_report")
@@ -782,7 +792,7 @@ def main():
         plans_tried.append({"grad_dtype": grad_dtype, "bucket_adamw": bool(trainer.bucket_adamw), "ms_per_step": round(dt / args.steps * 1e3, 4),
                             "exposed_exchange_ms": comm["exposed_exchange_ms"]})
         step_ms = dt / args.steps * 1e3
-        adapt = (args.grad_dtype == "auto" and fallback is None and os.environ.get("TULIP_BENCH_ADAPT", "1") != "0"
+        adapt = (args.grad_dtype == "auto" and args.exchange == "allreduce" and fallback is None and os.environ.get("TULIP_BENCH_ADAPT", "1") != "0"
                  and grad_dtype == "fp32" and comm["exposed_exchange_ms"] > max(0.15, 0.07 * step_ms))
         if adapt:
             # the prediction said fp32 hides; the measurement says it does not: measure the bf16 exchange as well
@@ -858,7 +868,9 @@ def main():
                  "segments+detached_buckets" if dets else "segments"),
         "graph_segments": segs, "detached_bucket_graphs": dets,
         "optimizer": ("in_weight_gradient_write_out" if world == 1 and getattr(trainer, "fuse_adamw", False) else
+                      "sharded_per_bucket" if getattr(trainer, "exchange", "allreduce") == "sharded" else
                       "per_bucket" if getattr(trainer, "bucket_adamw", False) else "end_of_step"),
+        "exchange": getattr(trainer, "exchange", "allreduce"),
         "ladder_rung": len(attempts), "after_failed": [a.get("attempt", a) if isinstance(a, dict) else a for a in attempts]}
     if attempts or fallback:
         out["graph_path_failed"] = True

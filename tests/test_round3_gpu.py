@@ -127,13 +127,15 @@ def test_reference_loop_body_on_the_dropin(golden_dir, tmp_path):
     assert all(np.isfinite(v) and v > 0 for v in got["norms"])
 
 
-def test_bench_self_spawns_its_ranks():
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+def test_bench_self_spawns_its_ranks(exchange):
     """`python bench.py --gpus 2` with NO launcher in the environment (the driver's command line) must start its two ranks
     itself and print ONE JSON line from rank 0.  One GPU here, so the ranks share it over gloo (TULIP_BENCH_BACKEND);
     on a multi-GPU node the same entry point uses RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(TULIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+                       + (["--exchange", "sharded"] if exchange == "sharded" else []),
                        env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -144,6 +146,8 @@ def test_bench_self_spawns_its_ranks():
     ss = d["config"]["step_structure"]          # what the timed step was, without opening `comm`
     assert ss["form"] == "segments+detached_buckets" and ss["graph_segments"] >= 3 and ss["detached_bucket_graphs"] >= 3
     assert ss["ladder_rung"] == 0 and ss["after_failed"] == []
+    assert ss["exchange"] == exchange        # (all-reduce plans: the chooser decides where the optimizer step goes)
+    assert ss["optimizer"] in (("sharded_per_bucket",) if exchange == "sharded" else ("end_of_step", "per_bucket"))
     c = d["comm"]
     assert c["world_size_rccl"] == 2 and c["launcher"] == "bench.py spawn_ranks"
     assert c["collective_smoke"]["bucket"]["bytes"] == 66 << 20 and c["collective_smoke"]["bucket"]["busbw_GBps"] > 0

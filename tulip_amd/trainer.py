@@ -226,12 +226,12 @@ class Trainer:
         ev.record()
         with torch.cuda.stream(self._opt_stream):
             self._opt_stream.wait_event(ev)
-            if self.bucketer.dry:
-                return
-            blocks = self._sharded.reduce(tag, self.g)
+            dry = self.bucketer.dry              # (bench.py's re-timing with the collectives skipped: the local work stays)
+            blocks = self._sharded.plan[tag]["blocks"] if dry else self._sharded.reduce(tag, self.g)
             ops.adamw_blocks(W.flat, self.g, self.m, self.v, W.shadow, blocks, blocks.numel(), self.hyper, W.decay_mask,
                              zero_grad=not self.grad_overwrite)
-            self._sharded.gather_shadow(tag, W.shadow)
+            if not dry:
+                self._sharded.gather_shadow(tag, W.shadow)
 
     def gather_state(self):
         """exchange="sharded": fp32 master and both moments whole on every rank again (checkpoints, state_dict(), evaluation
