@@ -761,7 +761,7 @@ class TulipEngine:
         # first kernel -- enqueued in front of it, the piece becomes the first successor of the chain's last node and the graph
         # executor moves the chain to another queue and back: two ~9-us hops around the deep stage in the traced step; same-box
         # A/B 1.938 -> 1.926 ms, three pairs, profiles/r5_ab_join_issue.txt)
-        if any(not self._packs[q][1] for q in need) or os.environ.get("TULIP_JOIN_ISSUES_ALL") == "1":      # (the switch: A/B only)
+        if any(not self._packs[q][1] for q in need):
             self._issue_pack()
         if any(not self._packs[q][2] for q in need):
             torch.cuda.current_stream().wait_stream(self._side_streams[0])     # (one side stream: waits for all issued halves)
@@ -1753,7 +1753,7 @@ class TulipEngine:
         if not hasattr(P, "_mod_gbufs"):
             P._mod_gbufs = [torch.zeros(W_.total, dtype=torch.float32, device=self.device) for _ in range(2)]
             P._mod_gscale = torch.ones(1, dtype=torch.float32, device=self.device)
-            P._mod_gidle = _storage_users(P._mod_gbufs[0])
+            P._mod_gidle = min(_storage_users(P._mod_gbufs[0]), (1 << 30) - 1)
         if dloss is None:
             P._mod_gscale.fill_(1.0)
         else:
@@ -1794,7 +1794,10 @@ class TulipEngine:
 
 
 def _storage_users(t: torch.Tensor) -> int:
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+    """References to the tensor's storage (torch's own count, as its CUDA-graph trees use it).  Without that private entry point a
+    huge count is reported: every buffer then looks taken and _module_backward falls back to its private buffer + copy."""
+    f = getattr(torch._C, "_storage_Use_Count", None)
+    return f(t.untyped_storage()._cdata) if f is not None else 1 << 30
 
 
 class _TulipFn(torch.autograd.Function):
