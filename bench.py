@@ -863,6 +863,8 @@ def main():
     # (first rung of the retry ladder), or eager launches (last rung / --no-graph)
     segs = len(trainer._segments[True]) if getattr(trainer, "_segments", None) else 0
     dets = len(getattr(trainer, "_det_graphs", {}))
+    from tulip_amd import knobs
+    out["config"]["knobs_non_default"] = knobs.non_default()      # an A/B switch in the environment shows in the line itself
     out["config"]["step_structure"] = {
         "form": ("eager" if not trainer.use_graph else "one_graph" if segs <= 1 and not dets else
                  "segments+detached_buckets" if dets else "segments"),

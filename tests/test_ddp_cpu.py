@@ -122,6 +122,21 @@ def test_sharded_exchange_two_ranks_gloo():
         assert 0.74 <= wire <= 0.80, wire
 
 
+def test_shard_bounds_cover_a_bucket_exactly():
+    """tulip_amd.ddp.shard_bounds: `world` equal shards of whole 64-element blocks from the bucket's start, the rest (less than
+    world x 64 elements) is the replicated remainder; every element belongs to exactly one rank's shard or to the remainder."""
+    from tulip_amd.ddp import shard_bounds
+    for (a, b) in [(0, 64 * 90), (64 * 90, 64 * 211), (64 * 7, 64 * 8), (64 * 5, 64 * 5 + 64 * 1000)]:
+        for world in (1, 2, 3, 8):
+            owned = []
+            for r in range(world):
+                s_, lo, hi, me = shard_bounds(a, b, world, r)
+                assert s_ % 64 == 0 and hi - lo == s_ and lo == a + r * s_ and me == a + world * s_ and a <= me <= b
+                assert b - me < world * 64
+                owned.append((lo, hi))
+            assert owned[0][0] == a and all(owned[i][1] == owned[i + 1][0] for i in range(world - 1)) and owned[-1][1] == me
+
+
 # ---------------------------------------------------------------------------------------------- the exchange chooser
 _BASE_BUCKETS = [("dec0", 0, 5_200_000), ("enc3", 5_200_000, 21_700_000), ("enc1", 21_700_000, 26_900_000),
                  ("embed", 26_900_000, 27_150_000)]       # tulip_base, bucket_mb = 16 (elements)

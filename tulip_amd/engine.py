@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from . import knobs, ops
 from ._lib import (EPI_BF16, EPI_F32, EPI_GELU_BWD, EPI_GELU_DUAL, EPI_PIXSHUF2_F32, EPI_RESID_F32,
                    EPI_UNSHUF2_BF16,
                    EPI_SPLIT_F32)
@@ -362,8 +362,8 @@ class TulipEngine:
         self.model = model
         self.device = None
         # A/B switches, carried per launch (the library keeps no state): the 64 x 96 weight-gradient tile everywhere; no L2 warm-up
-        self.wgrad_small_tiles = os.environ.get("TULIP_WGRAD_TILES", "1") == "0"
-        self.no_warm = os.environ.get("TULIP_SWINW_WARM", "1") == "0"            # (tools/cold_probe.py)
+        self.wgrad_small_tiles = knobs.is_zero("TULIP_WGRAD_TILES")
+        self.no_warm = knobs.is_zero("TULIP_SWINW_WARM")            # (tools/cold_probe.py)
         self.params: Optional[FlatParams] = None
         self.plans: Dict[int, Plan] = {}
         m = model
@@ -455,8 +455,8 @@ class TulipEngine:
         self._keep = rates.to(device)
         # fused blocks behind which the queued side work is flushed at once instead of at the end of their stage (dev knob:
         # TULIP_FLUSH_AFTER = comma-separated block prefixes)
-        self.flush_after = frozenset(x for x in os.environ.get("TULIP_FLUSH_AFTER", "").split(",") if x)
-        nearly = int(os.environ.get("TULIP_EARLY_FLUSH_BLOCKS", "1"))
+        self.flush_after = frozenset(knobs.names("TULIP_FLUSH_AFTER"))
+        nearly = knobs.integer("TULIP_EARLY_FLUSH_BLOCKS", 1)
         # backward order ends with encoder stage 0, block 1 then block 0
         self.early_flush = frozenset(sp.prefix for sp in self.enc_blocks[0][:nearly])
         self._drop_seed = torch.initial_seed()      # torch.manual_seed() governs the DropPath stream
@@ -504,7 +504,7 @@ class TulipEngine:
         torch.floor(self._keep + P.drop_u, out=P.drop_scale)
         P.drop_scale.div_(self._keep)
 
-    draw_in_embed = os.environ.get("TULIP_DRAW_IN_EMBED", "1") != "0"
+    draw_in_embed = knobs.on("TULIP_DRAW_IN_EMBED", True)
     _pending_draw = None
 
     def _ds(self, P: Plan, sp: BlockSpec, branch: int):
@@ -512,10 +512,10 @@ class TulipEngine:
             return None
         return P.drop_scale.data_ptr() + 4 * (sp.slot + branch) * P.B
 
-    infer_no_save = os.environ.get("TULIP_INFER_NO_SAVE", "1") != "0"   # fused blocks' inference form in with_loss=False forwards
+    infer_no_save = knobs.on("TULIP_INFER_NO_SAVE", True)   # fused blocks' inference form in with_loss=False forwards
     _no_save = False
-    fuse_block96 = os.environ.get("TULIP_FUSE_BLOCK96", "1") != "0"
-    fuse_block96_bwd = os.environ.get("TULIP_FUSE_BLOCK96_BWD", "1") != "0"
+    fuse_block96 = knobs.on("TULIP_FUSE_BLOCK96", True)
+    fuse_block96_bwd = knobs.on("TULIP_FUSE_BLOCK96_BWD", True)
 
     # round 4: the C = 96 forward no longer writes qkv and the fc1 pre-activation (1344 of 3472 B per token); the fused backward
     # recomputes both from x / x1 with the weights it holds in LDS anyway (csrc/swin96.hip swin96_bwd_kernel<true>).
@@ -523,18 +523,18 @@ class TulipEngine:
     # Measured (profiles/README.md round 4): the forward gains 1 us at batch 8 / 25 us at batch 64 (it is not store-bound), the
     # backward loses 12 / 45 us (126 more MFMAs per window, bank conflicts of the plain reads at the transpose pitch): off by
     # default, kept as a tested form (bit-identical outputs, tests/test_round4_gpu.py).
-    recompute96 = os.environ.get("TULIP_SWIN96_RECOMPUTE", "0") != "0"
+    recompute96 = knobs.on("TULIP_SWIN96_RECOMPUTE", False)
     # round 4: the fused C = 96 forward writes bf16(gelu'(h)) where it used to write h (same bytes); the only thing the backward
     # does with h is that derivative (100 of 134 vector instructions per 32 hidden channels of its MLP loop).
     # TULIP_FC1_GRAD=0: h is saved and the backward evaluates gelu' itself
-    fc1_grad96 = os.environ.get("TULIP_FC1_GRAD", "1") != "0"
+    fc1_grad96 = knobs.on("TULIP_FC1_GRAD", True)
 
     def _hgrad96(self, sp: BlockSpec) -> bool:
         return (self.fc1_grad96 and self.fuse_block96 and self.fuse_block96_bwd and self._fusable96(sp)
                 and not self._recomp96(sp))
 
     # ... and the same hand-off in the fused wide blocks (csrc/swinw.hip): TULIP_FC1_GRAD_WIDE=0 switches it off there
-    fc1_grad_wide = os.environ.get("TULIP_FC1_GRAD_WIDE", "1") != "0"
+    fc1_grad_wide = knobs.on("TULIP_FC1_GRAD_WIDE", True)
 
     def _hgrad_wide(self, sp: BlockSpec, B: int) -> bool:
         return self.fc1_grad_wide and self.fuse_wide and self.fuse_wide_bwd and self._fusable_wide(sp, B)
@@ -551,7 +551,7 @@ class TulipEngine:
     # (v_mfma_f32_16x16x32_fp8_fp8; q, k rounded from their bf16 values, round to nearest even; softmax, P.V and
     # everything else unchanged); the backward differentiates exactly that function (it multiplies dS with the rounded
     # q, k).  Off by default: the reference computes the scores from bf16 / fp16 operands.
-    attn_fp8 = os.environ.get("TULIP_ATTN_FP8", "0") == "1"
+    attn_fp8 = knobs.is_one("TULIP_ATTN_FP8")
 
     def _mask_arg(self, sp: BlockSpec, B: Optional[int] = None) -> int:
         """`masked` argument of the attention / block kernels: bit 0 shifted-window mask, bit 1 fp8 scores, bit 2 (fused
@@ -561,19 +561,19 @@ class TulipEngine:
         return int(bool(sp.shift)) | (2 if self.attn_fp8 else 0) | (4 if hg else 0) | (8 if self.no_warm else 0)
 
     # two workgroups per window for the C = 384 blocks where one workgroup owns one window (csrc/swinw.hip, SPLIT)
-    split_wide = os.environ.get("TULIP_SWINW_SPLIT", "1") != "0"
+    split_wide = knobs.on("TULIP_SWINW_SPLIT", True)
     # the backward's split form is 5.6 us faster per launch in isolation (50.9 -> 45.3 us) and 34 us SLOWER per step: the half of the
     # chip its 128 workgroups leave free is where the side queue's weight gradients run (profiles/README.md); off
-    split_wide_bwd = os.environ.get("TULIP_SWINW_SPLIT_BWD", "0") != "0"
-    fuse_wide = os.environ.get("TULIP_FUSE_WIDE", "1") != "0"
-    fuse_wide_bwd = os.environ.get("TULIP_FUSE_WIDE_BWD", "1") != "0"
+    split_wide_bwd = knobs.on("TULIP_SWINW_SPLIT_BWD", False)
+    fuse_wide = knobs.on("TULIP_FUSE_WIDE", True)
+    fuse_wide_bwd = knobs.on("TULIP_FUSE_WIDE_BWD", True)
     # C = 192 always; C = 384 (stage 2: 3.5 MB of weights per block) from 128 windows per launch up (batch 8 at the KITTI
     # size).  Every workgroup streams the block's whole weight set through its own CU: with two windows per workgroup the
     # 128 windows of batch 8 were 64 workgroups and the fused form only tied the 7-kernel sequences (66 + 65 us against
     # 63 + 91 us isolated); with ONE window per workgroup below 256 windows (csrc/swinw.hip wide_g) it is 50 + 51 us and
     # 1.7 % of the step; at batch 16 / 32 / 64 it wins 3 / 5 / 4.5 %.  TULIP_FUSE_WIDE_MIN_WINDOWS overrides.
-    wide_widths = tuple(int(c) for c in os.environ.get("TULIP_FUSE_WIDE_C", "192,384").split(",") if c)
-    wide_min_windows = int(os.environ.get("TULIP_FUSE_WIDE_MIN_WINDOWS", "128"))
+    wide_widths = tuple(int(c) for c in knobs.names("TULIP_FUSE_WIDE_C", "192,384"))
+    wide_min_windows = knobs.integer("TULIP_FUSE_WIDE_MIN_WINDOWS", 128)
 
     def _fusable_wide(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
         """csrc/swinw.hip covers C = 192 / 384: heads of 32, window 2x8, MLP C -> 4C -> C.  B = None: could the block ever
@@ -590,9 +590,9 @@ class TulipEngine:
     # forward / backward against the sequence (profiles/r5_bench_deep_shapes.txt): C = 768 with 32 windows 0.66 / 0.81, 64: 0.72 / 0.82,
     # 128: 1.10 / 1.05, 256 (batch 64): 1.32 / 1.18; C = 1536 with 16 windows (half the chip) 1.0 / 1.14, 32: 0.77 / 0.77 -- outside
     # [TULIP_FUSE_DEEP_MIN_WINDOWS, TULIP_FUSE_DEEP_MAX_WINDOWS] the GEMM sequence runs (its tiles fill the chip there)
-    fuse_deep = os.environ.get("TULIP_FUSE_DEEP", "1") != "0"
-    deep_min_windows = int(os.environ.get("TULIP_FUSE_DEEP_MIN_WINDOWS", "32"))
-    deep_max_windows = int(os.environ.get("TULIP_FUSE_DEEP_MAX_WINDOWS", "64"))
+    fuse_deep = knobs.on("TULIP_FUSE_DEEP", True)
+    deep_min_windows = knobs.integer("TULIP_FUSE_DEEP_MIN_WINDOWS", 32)
+    deep_max_windows = knobs.integer("TULIP_FUSE_DEEP_MAX_WINDOWS", 64)
 
     def _fusable_deep(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
         ok = (self.fuse_deep and sp.C in (768, 1536) and sp.nh * 32 == sp.C and self.hidden(sp.C) == 4 * sp.C
@@ -605,9 +605,9 @@ class TulipEngine:
         return ((self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
                 or self._fusable_deep(sp, B))
 
-    fuse_splitk_ln = os.environ.get("TULIP_FUSE_SPLITK_LN", "1") != "0"
-    fuse_tail_bwd = os.environ.get("TULIP_FUSE_TAIL_BWD", "1") != "0"      # head backward without the d(expand) tensor
-    fuse_tail_ln_bwd = os.environ.get("TULIP_FUSE_TAIL_LN_BWD", "1") != "0"   # ... and norm_up's backward in its epilogue
+    fuse_splitk_ln = knobs.on("TULIP_FUSE_SPLITK_LN", True)
+    fuse_tail_bwd = knobs.on("TULIP_FUSE_TAIL_BWD", True)      # head backward without the d(expand) tensor
+    fuse_tail_ln_bwd = knobs.on("TULIP_FUSE_TAIL_LN_BWD", True)   # ... and norm_up's backward in its epilogue
     _tail_fused = False
 
     def _unfused(self, sp: BlockSpec, B: int) -> bool:
@@ -727,12 +727,12 @@ class TulipEngine:
     # (the decoder's) is forked in front of the LAST encoder stage -- the few-token stage whose small GEMMs leave most of the
     # chip idle -- and joined in front of the first decoder block that streams a copy: beside the 96-wide blocks at the head
     # of the forward the whole refresh cost those blocks ~15 us each (tools/step_stamps.py).  TULIP_SPLIT_PACK=0: one piece.
-    split_pack = os.environ.get("TULIP_SPLIT_PACK", "1") != "0"
+    split_pack = knobs.on("TULIP_SPLIT_PACK", True)
     # the deep stages' copies as a third piece forked in front of stage 2 (run_forward): batch 8 1.9426 -> 1.9315 ms, batch 64 9.022 ->
     # 9.007 (four interleaved runs each, same box, profiles/r5_ab_pack_layout2.txt; ONE piece for everything, TULIP_SPLIT_PACK=0:
     # 1.9311 / 9.022).  (A first A/B read "flat": every piece was then enqueued in front of the deep stage's first kernel, _join_pack.)
-    deep_pack = os.environ.get("TULIP_DEEP_PACK", "1") != "0"
-    pack_layout = os.environ.get("TULIP_PACK_LAYOUT", "a")
+    deep_pack = knobs.on("TULIP_DEEP_PACK", True)
+    pack_layout = knobs.text("TULIP_PACK_LAYOUT", "a")
     _packs = None
 
     def _fork_pack(self, part, also=()):
@@ -809,7 +809,7 @@ class TulipEngine:
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
-    fuse_tail_fwd = os.environ.get("TULIP_FUSE_TAIL_FWD", "1") != "0"      # norm_up + head + loss partials in one launch
+    fuse_tail_fwd = knobs.on("TULIP_FUSE_TAIL_FWD", True)      # norm_up + head + loss partials in one launch
     _loss_final = None
 
     def run_forward(self, P: Plan, with_loss: bool = True, pack_on_side: bool = False, defer_loss_final: bool = False):
@@ -929,10 +929,10 @@ class TulipEngine:
     # weight gradients run beside the latency-bound chain: what matters is how much they disturb it, not their
     # own latency.  >= 1024 tokens per split keeps the slab traffic (splits x output, written then folded) at a
     # quarter of what "fill the chip" splitting (256 tokens) produced: step 4.07 -> 3.96 ms.
-    WGRAD_CTAS = int(os.environ.get("TULIP_WGRAD_CTAS", "512"))
-    WGRAD_MINK = int(os.environ.get("TULIP_WGRAD_MINK", "1024"))
-    WGRAD_BIG_CTAS = int(os.environ.get("TULIP_WGRAD_BIG_CTAS", "256"))
-    WGRAD_BIG_MINK = int(os.environ.get("TULIP_WGRAD_BIG_MINK", "512"))
+    WGRAD_CTAS = knobs.integer("TULIP_WGRAD_CTAS", 512)
+    WGRAD_MINK = knobs.integer("TULIP_WGRAD_MINK", 1024)
+    WGRAD_BIG_CTAS = knobs.integer("TULIP_WGRAD_BIG_CTAS", 256)
+    WGRAD_BIG_MINK = knobs.integer("TULIP_WGRAD_BIG_MINK", 512)
     # A large-tile workgroup takes a whole CU (8 waves x 256 registers, 92 KB of LDS): a group is sized to one round of
     # the CUs that are FREE.  With a gradient all-reduce running beside the backward RCCL's channel workgroups hold wave
     # slots on up to ~32 CUs for the length of a collective, and a 256-workgroup launch would need a second round for
@@ -940,7 +940,7 @@ class TulipEngine:
     # for up to 64 channels and costs 0.2 % of the one-GPU step (2.749 vs 2.743 ms).  Not measured on a multi-GPU node;
     # TULIP_WGRAD_DDP_CTAS overrides.
     wgrad_ctas = 0                                   # 0: WGRAD_BIG_CTAS
-    WGRAD_DDP_CTAS = int(os.environ.get("TULIP_WGRAD_DDP_CTAS", "192"))
+    WGRAD_DDP_CTAS = knobs.integer("TULIP_WGRAD_DDP_CTAS", 192)
 
     # Workgroups of a grouped large-tile launch as a function of the tiles it holds ("min_tiles:workgroups;..."): a stage
     # with many tiles (C = 384: ~112) fills half the chip without any token split -- no slabs, nothing to fold -- and the
@@ -948,7 +948,7 @@ class TulipEngine:
     # (round 3 sweep, same box, batch 8 / 64 ms per step): all 256: 2.2755 / 9.691; this map: 2.2784 / 9.717 with the slabs
     # of a step at 70 MB instead of 220 MB; "100:112;20:28" (no split at C = 192 either): 2.360 / 10.16.
     wgrad_ctas_map = tuple(sorted((tuple(int(v) for v in e.split(":")) for e in
-                                   os.environ.get("TULIP_WGRAD_CTAS_MAP", "100:112;20:128;5:128").split(";") if e), reverse=True))
+                                   knobs.text("TULIP_WGRAD_CTAS_MAP", "100:112;20:128;5:128").split(";") if e), reverse=True))
 
     def _group_ctas(self, group_tiles: int) -> int:
         if not self.wgrad_ctas:                      # (a DDP run pins the count: RCCL's channels hold CUs)
@@ -998,19 +998,19 @@ class TulipEngine:
                 return
         ops.gemm(A, B, M, N, K, **kw)
 
-    mid_gemm = os.environ.get("TULIP_GEMM_MID", "1") != "0"
+    mid_gemm = knobs.on("TULIP_GEMM_MID", True)
 
     # Side launches per STAGE, not per block (default since the side queue, not the chain, ends the backward): a grouped
     # weight-gradient launch is one round of the chip whatever it holds, so its slabs are ~one 147-KB tile per workgroup --
     # 28-37 MB written, read back by the fold -- per LAUNCH.  A stage's two blocks and its boundary linears in one launch
     # (up to 12 linears) halve the launches, the slab traffic (1.36 -> 0.7 GB per step) and the fold launches: 2.46 -> 2.33 ms
     # at batch 8, 10.41 -> 10.24 ms at batch 64 (same box; per-block launches for the backward's last stage only: 2.36).
-    flush_per_block = os.environ.get("TULIP_FLUSH_PER_BLOCK", "0") != "0"
-    flush_unfused_blocks = os.environ.get("TULIP_FLUSH_UNFUSED_BLOCKS", "0") != "0"
-    merge_embed_fold = os.environ.get("TULIP_MERGE_EMBED_FOLD", "0") != "0"      # measured neutral (2.245 vs 2.243 ms): off
-    wgrad_group_max = int(os.environ.get("TULIP_WGRAD_GROUP_MAX", "12"))    # linears per grouped launch (<= 16)
+    flush_per_block = knobs.on("TULIP_FLUSH_PER_BLOCK", False)
+    flush_unfused_blocks = knobs.on("TULIP_FLUSH_UNFUSED_BLOCKS", False)
+    merge_embed_fold = knobs.on("TULIP_MERGE_EMBED_FOLD", False)      # measured neutral (2.245 vs 2.243 ms): off
+    wgrad_group_max = knobs.integer("TULIP_WGRAD_GROUP_MAX", 12)    # linears per grouped launch (<= 16)
     early_flush = frozenset()   # block prefixes with a mid-block side flush (set in bind())
-    lag_bucket_join = os.environ.get("TULIP_LAG_BUCKET_JOIN", "1") != "0"
+    lag_bucket_join = knobs.on("TULIP_LAG_BUCKET_JOIN", True)
     _lagged_hook = None
     # Side streams.  How the HIP graph executor (ROCm 7.2) turns captured branches into hardware-queue work decides what
     # a fork costs the chain: it walks the graph depth first along each node's FIRST-created successor and gives every
@@ -1019,7 +1019,7 @@ class TulipEngine:
     # side streams used round-robin are best: 1 stream 4.63 ms, 2: 4.46, 3: 4.82, 4: 4.05, 8: 4.05 at the time).  With
     # defer_side the chain's next kernel is created first, the chain stays on one queue for the whole step, and a
     # single side stream is best (1: 3.32 ms, 2: 3.59, 3: 3.63, 4: 3.67, 8: 3.63; 3.42 for the old layout).
-    n_side = int(os.environ.get("TULIP_SIDE_STREAMS", "1" if os.environ.get("TULIP_DEFER_SIDE", "1") != "0" else "4"))
+    n_side = knobs.integer("TULIP_SIDE_STREAMS", 1 if knobs.on("TULIP_DEFER_SIDE", True) else 4)
     overlap_wgrad = True   # run the weight-gradient branch on a second HIP stream (forked inside the graph)
 
     def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
@@ -1103,7 +1103,7 @@ class TulipEngine:
                 ops.reduce_rows_multi(carry, adam=self._adam_arg())
             self._side_dirty = True
 
-    group_wgrad = os.environ.get("TULIP_GROUP_WGRAD", "1") != "0"
+    group_wgrad = knobs.on("TULIP_GROUP_WGRAD", True)
 
     def _issue_pending(self, ws: int, pending=None):
         """Launch the queued side work on the current stream: weight gradients as grouped GEMMs (<= wgrad_group_max per launch), every
@@ -1195,7 +1195,7 @@ class TulipEngine:
         self._pending = []
         self._side_dirty = True
 
-    defer_side = os.environ.get("TULIP_DEFER_SIDE", "1") != "0"
+    defer_side = knobs.on("TULIP_DEFER_SIDE", True)
     _deferred = None
 
     def _release_deferred(self):
@@ -1483,7 +1483,7 @@ class TulipEngine:
     adam_apply = False
     adam_probe = None
     _gflat = None
-    fuse_adamw_folds = os.environ.get("TULIP_FUSE_ADAMW_FOLDS", "1") != "0"      # (0: only the un-split write-outs step)
+    fuse_adamw_folds = knobs.on("TULIP_FUSE_ADAMW_FOLDS", True)      # (0: only the un-split write-outs step)
 
     def overwrite_supported(self, B: int) -> bool:
         return bool(self.group_wgrad and self.overlap_wgrad)
@@ -1697,7 +1697,7 @@ class TulipEngine:
     # ~3 ms of host time per step against 2 ms of GPU work.  The two launch sequences are fixed per (batch size, train / eval),
     # so the module path replays them from HIP graphs as well: first call eager (loads kernels, sizes lazy buffers), second call
     # captures, later calls replay.  TULIP_GRAPH_MODULE=0: eager launches every time.
-    graph_module = os.environ.get("TULIP_GRAPH_MODULE", "1") != "0"
+    graph_module = knobs.on("TULIP_GRAPH_MODULE", True)
 
     def _module_sequence(self, P: Plan, key, fn):
         graphs = P.__dict__.setdefault("_module_graphs", {})

@@ -23,7 +23,7 @@ from typing import Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import knobs, ops
 from .ddp import GradBucketer
 from .engine import ALIGN
 
@@ -93,7 +93,7 @@ class Trainer:
         # Opt-in (TULIP_BUCKET_ADAMW=1): it relies on RCCL's stream-ordered work.wait(); the default is one update
         # after the last bucket, the order the reference's DDP + optimizer.step() has.
         if bucket_adamw is None:
-            bucket_adamw = os.environ.get("TULIP_BUCKET_ADAMW", "0") == "1"
+            bucket_adamw = knobs.is_one("TULIP_BUCKET_ADAMW")
         if exchange not in ("allreduce", "sharded"):
             raise ValueError("exchange must be 'allreduce' or 'sharded'")
         self.exchange = exchange if self.segmented else "allreduce"
@@ -109,22 +109,22 @@ class Trainer:
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
         # the fragment-major weight copies of the fused wide blocks (one ~25-us launch) are rewritten at the START of the
         # next step, beside the forward's first kernels, instead of on the chain behind AdamW (TULIP_PACK_AT_START=0: old)
-        self.pack_at_step_start = os.environ.get("TULIP_PACK_AT_START", "1") != "0"
+        self.pack_at_step_start = knobs.on("TULIP_PACK_AT_START", True)
         # without gradient accumulation the backward WRITES every gradient (one producer per parameter and step) instead of adding
         # to a buffer AdamW has to clear: TulipEngine.grad_overwrite (TULIP_GRAD_OVERWRITE=0: accumulate + clear, as with accum_iter > 1)
-        self.grad_overwrite = (self.accum_iter == 1 and os.environ.get("TULIP_GRAD_OVERWRITE", "1") != "0"
+        self.grad_overwrite = (self.accum_iter == 1 and knobs.on("TULIP_GRAD_OVERWRITE", True)
                                and self.eng.overwrite_supported(batch_size))
         # ... and where a weight-gradient workgroup holds a tensor's COMPLETE gradient tile (no token split: the deep stages, 90 %
         # of the parameters), the optimizer step is taken right there, in the write-out, beside the backward instead of behind it
         # (TULIP_FUSE_ADAMW=0: one AdamW launch over everything at the end of the step).  Captured steps on one GPU only: a
         # gradient all-reduce, the gradient-norm read-out and accumulation need the gradients themselves.
         self.fuse_adamw = (self.grad_overwrite and use_graph and not self.segmented and not track_grad_norm
-                           and os.environ.get("TULIP_FUSE_ADAMW", "1") != "0")
+                           and knobs.on("TULIP_FUSE_ADAMW", True))
         self._adam_mask = None
         self._adam_blocks = None
         self._adam_ctx, self._adam_fused = None, frozenset()
         self.fused_adamw_params = 0
-        self._fuse_adamw_skip = tuple(x for x in os.environ.get("TULIP_FUSE_ADAMW_SKIP", "").split(",") if x)   # dev: name prefixes
+        self._fuse_adamw_skip = knobs.names("TULIP_FUSE_ADAMW_SKIP")   # dev: name prefixes
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
         # set before the first step (the choice is baked into the captured graphs)
         self.inject_drop_u: Optional[torch.Tensor] = None
@@ -135,7 +135,7 @@ class Trainer:
         # N > 1, captured steps: the last side group of every bucket but the final one is a graph of its own on this stream (own
         # split-K workspace), so that a cut of the step graph does not make the chain wait for it (TULIP_DETACH_BUCKETS=0: the
         # group is forked inside the segment and joined at the cut, one block late)
-        self.detach_buckets = bool(use_graph and self.segmented and os.environ.get("TULIP_DETACH_BUCKETS", "1") != "0")
+        self.detach_buckets = bool(use_graph and self.segmented and knobs.on("TULIP_DETACH_BUCKETS", True))
         self._det_stream = torch.cuda.Stream(device=device) if self.detach_buckets else None
         self._ws_det = (torch.empty(self.eng.WS_ELEMS + (1 << 20), dtype=torch.float32, device=device)
                         if self.detach_buckets else None)
