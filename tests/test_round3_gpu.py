@@ -33,7 +33,8 @@ def test_kitti_b8_train_step_vs_oracle():
     lr, wd, betas = 5e-4, 0.01, (0.9, 0.95)
     tr = Trainer(m, B, lr=lr, betas=betas, weight_decay=wd)
     eng, W = tr.eng, tr.eng.params
-    assert all(eng._fused_bwd(sp, B) for sp in eng.blocks if sp.C in (96, 192, 384))      # the bench's kernel mix
+    assert all(eng._fused_bwd(sp, B) for sp in eng.blocks if sp.C in (96, 192, 384))      # the bench's kernel mix ...
+    assert all(eng._fusable_deep(sp, B) for sp in eng.blocks if sp.C == 768)               # ... round 5: the deep stage's sliced launches (32 windows)
     g = torch.Generator().manual_seed(7)
     table = torch.zeros(eng.n_drop_slots, B)
     du = {}
