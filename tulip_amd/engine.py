@@ -1170,8 +1170,9 @@ class TulipEngine:
         for fn in fns:
             fn()
 
-    def _flush_wgrads(self, advance: bool = True):
-        """Issue the queued side work on the current side stream; advance: move on to the next stream afterwards."""
+    def _flush_wgrads(self, advance: bool = True, mark: bool = False):
+        """Issue the queued side work on the current side stream; advance: move on to the next stream afterwards.
+        mark: an event behind this group on its stream (pack_at_end: every packable weight has been stepped once it has run)."""
         if not self._pending:
             return
         main = torch.cuda.current_stream()
@@ -1185,27 +1186,44 @@ class TulipEngine:
             self._release_deferred()
             ev = torch.cuda.Event()
             ev.record(main)
-            self._deferred = (ev, st, ws, self._pending)
+            self._deferred = (ev, st, ws, self._pending, mark)
             self._pending = []
             self._side_dirty = True
             return
         st.wait_stream(main)
         with torch.cuda.stream(st):
             self._issue_pending(ws)
+        if mark:
+            self._pack_ev = torch.cuda.Event()
+            self._pack_ev.record(st)
         self._pending = []
         self._side_dirty = True
 
     defer_side = knobs.on("TULIP_DEFER_SIDE", True)
     _deferred = None
+    pack_at_end = False           # per run_backward call (the Trainer's choice, Trainer._pack_at_end)
+    _pack_ev = None
+
+    @property
+    def _pack_mark_tag(self):
+        """backward hook of the LAST completion group that holds a packed weight: the lowest encoder stage with a packed width"""
+        t = getattr(self, "_pack_mark_tag_", None)
+        if t is None:
+            ss = [s for s, blks in enumerate(self.enc_blocks) if any(sp.C in self.params.pk_active for sp in blks)]
+            t = self._pack_mark_tag_ = f"enc{min(ss)}" if ss else ""
+        return t
 
     def _release_deferred(self):
         d, self._deferred = self._deferred, None
         if d is None:
             return
-        ev, st, ws, pending = d
+        ev, st, ws, pending, mark = d
         st.wait_event(ev)
         with torch.cuda.stream(st):
             self._issue_pending(ws, pending)
+        if mark:
+            self._pack_ev = torch.cuda.Event()
+            self._pack_ev.record(st)
 
     # run_backward(join_tags=...) under Trainer._capture: see hook() in run_backward
     detach_buckets = False
@@ -1489,7 +1507,7 @@ class TulipEngine:
         return bool(self.group_wgrad and self.overlap_wgrad)
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
-                     join_tags=None, overwrite: bool = False, apply_adamw: bool = False):
+                     join_tags=None, overwrite: bool = False, apply_adamw: bool = False, pack_at_end: bool = False):
         """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
         (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
         each parameter group has been *launched* (DDP overlap)."""
@@ -1498,7 +1516,9 @@ class TulipEngine:
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
         self._detached = None
+        self._pack_ev = None
         self.grad_overwrite = bool(overwrite)
+        self.pack_at_end = bool(pack_at_end)
         self._gflat = gflat
         self.adam_apply = bool(apply_adamw and overwrite and self.adam_ctx is not None)
         if self._loss_final is not None:             # the loss read-out of run_forward(defer_loss_final=True): off the chain
@@ -1530,7 +1550,7 @@ class TulipEngine:
                 self._wait_side()
                 user_hook(tag)
                 return
-            self._flush_wgrads()
+            self._flush_wgrads(mark=self.pack_at_end and self.adam_apply and tag == self._pack_mark_tag)
             if tag == "embed":
                 join_and_fire(tag)
             elif bucket and self.lag_bucket_join:
@@ -1680,6 +1700,13 @@ class TulipEngine:
                             ep + rel("patch_embed.norm.weight"), ep + rel("patch_embed.norm.bias"), B, m.in_chans,
                             m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
                             self.eps, partial_stride=P.embed_stride)
+        if self._pack_ev is not None:
+            # pack_at_end: the chain has nothing left to do but wait for the side queue's last groups -- the fragment-major copies of
+            # every wide / deep weight (all stepped by now: the marked group was the last that holds any) are rewritten HERE, on the
+            # chain's queue, instead of beside the next forward (three forks and three joins there)
+            torch.cuda.current_stream().wait_event(self._pack_ev)
+            W_.refresh_transposes()
+            self._pack_ev = None
         gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
         if self.merge_embed_fold and self._deferred is not None and self.overlap_wgrad:
             # the last stage's side work was forked in front of patch_embed_bwd and is not enqueued yet: its fold launch waits

@@ -110,6 +110,13 @@ class Trainer:
         # the fragment-major weight copies of the fused wide blocks (one ~25-us launch) are rewritten at the START of the
         # next step, beside the forward's first kernels, instead of on the chain behind AdamW (TULIP_PACK_AT_START=0: old)
         self.pack_at_step_start = knobs.on("TULIP_PACK_AT_START", True)
+        # round 5 (TULIP_PACK_AT_END=0: off): the copies rewritten at the END of the step, on the chain's own queue while it waits for the
+        # side queue's last groups (TulipEngine.run_backward) -- no forks or joins beside the forward, no pack traffic beside its
+        # kernels: 1.9107 -> 1.8941 ms at batch 8, 9.054 -> 9.017 at batch 64 (four interleaved same-box runs each,
+        # profiles/r5_ab_pack_at_end.txt; identical losses: the same arithmetic).  Needs every packed weight stepped beside the backward
+        # (decided in _plan_fused_adamw: one GPU, captured step); otherwise the pieces beside the forward stay
+        self._want_pack_at_end = knobs.on("TULIP_PACK_AT_END", True)
+        self._pack_at_end = False
         # without gradient accumulation the backward WRITES every gradient (one producer per parameter and step) instead of adding
         # to a buffer AdamW has to clear: TulipEngine.grad_overwrite (TULIP_GRAD_OVERWRITE=0: accumulate + clear, as with accum_iter > 1)
         self.grad_overwrite = (self.accum_iter == 1 and knobs.on("TULIP_GRAD_OVERWRITE", True)
@@ -180,7 +187,7 @@ class Trainer:
         eng.run_forward(P, pack_on_side=self.pack_at_step_start, defer_loss_final=True)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None,
-                         overwrite=self.grad_overwrite, apply_adamw=apply_adamw)
+                         overwrite=self.grad_overwrite, apply_adamw=apply_adamw, pack_at_end=self._pack_at_end and apply_adamw)
 
     def _adamw_range(self, lo: int, hi: int):
         W = self.eng.params
@@ -263,7 +270,7 @@ class Trainer:
                              mask, zero_grad=not self.grad_overwrite)
         else:
             ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, mask, zero_grad=not self.grad_overwrite)
-        if not self.pack_at_step_start:
+        if not self.pack_at_step_start and not self._pack_at_end:
             W.refresh_transposes()
 
     # ------------------------------------------------------------------ checkpoint (misc.save_model / load_model keep
@@ -353,6 +360,10 @@ class Trainer:
             self._adam_ctx = ops.adamw_ref(self.hyper, self.g, W.flat, self.m, self.v, W.shadow, decay_mask64=mask)
             self.eng.adam_fused, self.eng.adam_ctx = self._adam_fused, self._adam_ctx
             self.fused_adamw_params = count
+            if self._want_pack_at_end and getattr(W, "pk_offset", None):
+                packed = [n for n in W.pk_offset if W.shape[n][0] in W.pk_active or W.shape[n][1] in W.pk_active]
+                if packed and all(bool((mask[W.offset[n] // 64:(W.offset[n] + W.numel[n] + 63) // 64] & 2).all()) for n in packed):
+                    self._pack_at_end, self.pack_at_step_start = True, False
             left = torch.nonzero((mask[:(W.total + 63) // 64] & 2) == 0).flatten().to(torch.int32)
             if 0 < left.numel() * 64 <= W.total // 4:       # (a long list gains nothing over the scan)
                 self._adam_blocks = left.contiguous()
