@@ -25,7 +25,7 @@ def test_knob_registry_and_non_default_report():
             del env[k]
     import json
     base = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
-    assert base["n"] >= 35 and base["nd"] == {}
+    assert 10 <= base["n"] <= 25 and base["nd"] == {}      # (round 6: the switches whose losing side was measured are gone)
     env.update(TULIP_FUSE_DEEP="0", TULIP_WGRAD_GROUP_MAX="7", TULIP_ATTN_FP8="1")
     got = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
     assert got["nd"] == {"TULIP_ATTN_FP8": True, "TULIP_FUSE_DEEP": False, "TULIP_WGRAD_GROUP_MAX": 7}

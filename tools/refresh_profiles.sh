@@ -22,6 +22,8 @@ python tools/timeline.py $(find $O/kt -name "*.db" | head -1) > $O/timeline_summ
 python tools/timeline.py $(find $O/kt -name "*.db" | head -1) full > $O/timeline_full.txt
 python tools/instep_summary.py $(find $O/kt -name "*.db" | head -1) $O/instep_durations.json > /dev/null
 cp $O/instep_durations.json profiles/instep_durations.json
+python tools/step_stamps.py 8 $O/step_stamps.json 2>/dev/null | grep -v amdgpu.ids > $O/step_stamps.txt
+cp $O/step_stamps.json profiles/step_stamps.json
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 rocprofv3 --kernel-trace --stats -d $O/kt64 -- python bench.py --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary --no-reference-loop > $O/kt64.log 2>&1
 python tools/kstats.py $(find $O/kt64 -name "*.db" | head -1) 20 > $O/kernel_stats_b64.txt
@@ -31,7 +33,6 @@ python tools/wgrad_phases.py > $O/wgrad_phases.txt 2>/dev/null
 python tools/bench_wgrad.py > $O/wgrad_isolated.txt 2>/dev/null
 python tools/chain_gemms.py > $O/chain_gemms.txt 2>/dev/null
 bash tools/other_configs.sh > $O/other_configs.txt 2>/dev/null
-python tools/step_stamps.py 2>/dev/null | grep -v amdgpu.ids > $O/step_stamps.txt
 python tools/exp_wgrad_contig.py 2>/dev/null | grep -v amdgpu.ids > $O/exp_wgrad_contig.txt
 python tools/cold_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/cold_probe.txt
 rm -rf $O/kt $O/kt64 $O/pmc_f $O/pmc_w $O/pmc_m $O/cal_f $O/cal_w

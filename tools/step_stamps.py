@@ -59,3 +59,14 @@ print(f"{len(ev)} stamps; 10-ns ticks since the first one; every stamp is a 1-th
 for t, tag, k in ev:
     print(f"  +{(t - t0) / 100.0:9.1f} us  {tag}" + (f" #{k}" if tag.startswith("side") else "")
           + (f"   [{contents[len(contents) - seen['side  group begins'] + k]}]" if tag == "side  group begins" else ""))
+
+# machine-readable twin for bench.py (`tracer_distortion`): when the side queue's first group begins, measured from the head of the
+# backward chain, in the UN-traced captured step
+if B == 8 and len(sys.argv) > 2:
+    import json
+    at = {(tag, k): (t - t0) / 100.0 for t, tag, k in ev}
+    b0, s0 = at.get(("chain backward begins", 0)), at.get(("side  group begins", 0))
+    json.dump({"source": "tools/step_stamps.py: stamp kernels captured into the step's graph, no tracer attached",
+               "source_stamp": bench.kernel_source_stamp(), "step_us": (ev[-1][0] - t0) / 100.0,
+               "side_queue_start_after_backward_begins_us": (s0 - b0) if (b0 is not None and s0 is not None) else None},
+              open(sys.argv[2], "w"), indent=1)

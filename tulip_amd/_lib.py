@@ -205,6 +205,11 @@ class dev_library:
         return False
 
 
+def dev_active() -> bool:
+    """Would a launch issued now go to the development build?"""
+    return bool(_dev_depth[0]) and not os.environ.get("TULIP_HIP_LIB")
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         if rc == -1:

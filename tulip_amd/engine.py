@@ -103,6 +103,12 @@ class FlatParams:
         # at the START of its next step, beside the head of the forward (Trainer.pack_at_step_start); every other consumer of
         # the copies (run_forward outside a Trainer step, GraphedForward) refreshes them first when this is set
         self.pack_dirty = False
+        # Trainer(exchange="sharded") on more than one rank: the fp32 master is current only on the shards this rank steps until
+        # Trainer.gather_state() has run -- refresh_shadow() refuses to cast from it meanwhile
+        self.master_partial = False
+        # bumped whenever a plan activates the copies of another block width (TulipEngine.plan): a Trainer whose captured step
+        # rewrites the copies re-captures (its graph holds the pack launch of the widths active at capture time)
+        self.pack_epoch = 0
 
     @staticmethod
     def _completion_order(model, named) -> List[str]:
@@ -186,6 +192,10 @@ class FlatParams:
         return out
 
     def refresh_shadow(self):
+        if self.master_partial:
+            raise RuntimeError("tulip_amd: the fp32 master weights are partial (Trainer(exchange='sharded') stepped only this rank's "
+                               "shards); call Trainer.gather_state() on EVERY rank (it is a collective) before anything re-derives "
+                               "the bf16 weights from them -- model(x), load_state_dict, GraphedForward.weights_changed")
         ops.cast_flat(self.flat, self.shadow, self.total)
         self.refresh_transposes()
         self.shadow_dirty = False
@@ -442,10 +452,11 @@ class TulipEngine:
                     by_width.setdefault(sp.C, []).extend(sp.prefix + suffix for suffix in (
                         ".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"))
         self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd or self.fuse_deep)
-        # every width that CAN run fused keeps its fragment-major copies fresh from the start: a Trainer's captured AdamW
-        # bakes in the pack launch for the widths active at capture time, so a width first activated by a later plan
-        # (GraphedForward at another batch size) would otherwise stream stale weights after every replayed step
-        self.params.pk_active = set(by_width)
+        # the wide widths (a few MB of copies) keep their fragment-major copies fresh from the start; the DEEP widths (57 MB read +
+        # 114 MB written per refresh for tulip_base) only once a plan runs them fused (plan(): a launch with 32-64 windows) -- at
+        # batch 64 or under the N > 1 step nothing streams those copies.  A Trainer's captured step bakes in the
+        # pack launch of the widths active at capture time: a later activation bumps params.pack_epoch and the Trainer re-captures
+        self.params.pk_active = {w for w in by_width if w < 768}
         rel = self.model.layers[0].blocks[0].attn.relative_position_index
         self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
         rates = torch.ones(max(1, self.n_drop_slots), 1)
@@ -453,12 +464,9 @@ class TulipEngine:
             if sp.slot >= 0:
                 rates[sp.slot] = rates[sp.slot + 1] = 1.0 - sp.rate
         self._keep = rates.to(device)
-        # fused blocks behind which the queued side work is flushed at once instead of at the end of their stage (dev knob:
-        # TULIP_FLUSH_AFTER = comma-separated block prefixes)
-        self.flush_after = frozenset(knobs.names("TULIP_FLUSH_AFTER"))
-        nearly = knobs.integer("TULIP_EARLY_FLUSH_BLOCKS", 1)
-        # backward order ends with encoder stage 0, block 1 then block 0
-        self.early_flush = frozenset(sp.prefix for sp in self.enc_blocks[0][:nearly])
+        # backward order ends with encoder stage 0, block 1 then block 0: the very last block's MLP-half weight gradients start as
+        # soon as their operands exist (nothing is left to hide them behind)
+        self.early_flush = frozenset(sp.prefix for sp in self.enc_blocks[0][:1])
         self._drop_seed = torch.initial_seed()      # torch.manual_seed() governs the DropPath stream
         self._drop_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
@@ -470,6 +478,8 @@ class TulipEngine:
                       or self._fusable_deep(sp, B)}
             if not widths <= self.params.pk_active:
                 self.params.pk_active |= widths
+                self.params.pack_epoch += 1
+                self._pack_mark_tag_ = None
                 if not self.params.shadow_dirty:
                     self.params.refresh_transposes()
         if getattr(self, "_ws", None) is None or self._ws.device != self.device:
@@ -479,9 +489,6 @@ class TulipEngine:
             self._ws_side = torch.empty(self.WS_ELEMS + (1 << 20), dtype=torch.float32, device=self.device)
             self._ws_side_ptr = self._ws_side.data_ptr()
             self._side_stream = torch.cuda.Stream(device=self.device)
-            self._side_streams = [self._side_stream] + [torch.cuda.Stream(device=self.device) for _ in range(self.n_side - 1)]
-            self._side_rr = 0
-            self._ws_sides = [self._ws_side] + [torch.empty_like(self._ws_side) for _ in range(self.n_side - 1)]
         return self.plans[B]
 
     # ------------------------------------------------------------------ forward
@@ -494,17 +501,12 @@ class TulipEngine:
         if drop_u is None:
             # the step counter lives on the device, so a graph replay draws fresh numbers.  The draw rides in the forward's first
             # launch (tulip_patch_embed_fwd_draw: run_forward picks it up) instead of being a launch of its own at the head of the chain
-            draw = (self._keep, P.drop_scale, P.drop_u, self.n_drop_slots, P.B, self._drop_seed, self._drop_counter)
-            if self.draw_in_embed:
-                self._pending_draw = (P, draw)
-            else:
-                ops.drop_path_scales(*draw)
+            self._pending_draw = (P, (self._keep, P.drop_scale, P.drop_u, self.n_drop_slots, P.B, self._drop_seed, self._drop_counter))
             return
         P.drop_u.copy_(drop_u)                     # injected draws (parity tests against the oracle)
         torch.floor(self._keep + P.drop_u, out=P.drop_scale)
         P.drop_scale.div_(self._keep)
 
-    draw_in_embed = knobs.on("TULIP_DRAW_IN_EMBED", True)
     _pending_draw = None
 
     def _ds(self, P: Plan, sp: BlockSpec, branch: int):
@@ -512,7 +514,7 @@ class TulipEngine:
             return None
         return P.drop_scale.data_ptr() + 4 * (sp.slot + branch) * P.B
 
-    infer_no_save = knobs.on("TULIP_INFER_NO_SAVE", True)   # fused blocks' inference form in with_loss=False forwards
+    infer_no_save = True   # fused blocks' inference form in with_loss=False forwards
     _no_save = False
     fuse_block96 = knobs.on("TULIP_FUSE_BLOCK96", True)
     fuse_block96_bwd = knobs.on("TULIP_FUSE_BLOCK96_BWD", True)
@@ -572,7 +574,7 @@ class TulipEngine:
     # 128 windows of batch 8 were 64 workgroups and the fused form only tied the 7-kernel sequences (66 + 65 us against
     # 63 + 91 us isolated); with ONE window per workgroup below 256 windows (csrc/swinw.hip wide_g) it is 50 + 51 us and
     # 1.7 % of the step; at batch 16 / 32 / 64 it wins 3 / 5 / 4.5 %.  TULIP_FUSE_WIDE_MIN_WINDOWS overrides.
-    wide_widths = tuple(int(c) for c in knobs.names("TULIP_FUSE_WIDE_C", "192,384"))
+    wide_widths = (192, 384)
     wide_min_windows = knobs.integer("TULIP_FUSE_WIDE_MIN_WINDOWS", 128)
 
     def _fusable_wide(self, sp: BlockSpec, B: Optional[int] = None) -> bool:
@@ -605,9 +607,9 @@ class TulipEngine:
         return ((self.fuse_block96_bwd and self._fusable96(sp)) or (self.fuse_wide_bwd and self._fusable_wide(sp, B))
                 or self._fusable_deep(sp, B))
 
-    fuse_splitk_ln = knobs.on("TULIP_FUSE_SPLITK_LN", True)
-    fuse_tail_bwd = knobs.on("TULIP_FUSE_TAIL_BWD", True)      # head backward without the d(expand) tensor
-    fuse_tail_ln_bwd = knobs.on("TULIP_FUSE_TAIL_LN_BWD", True)   # ... and norm_up's backward in its epilogue
+    fuse_splitk_ln = True
+    fuse_tail_bwd = True      # head backward without the d(expand) tensor
+    fuse_tail_ln_bwd = True   # ... and norm_up's backward in its epilogue
     _tail_fused = False
 
     def _unfused(self, sp: BlockSpec, B: int) -> bool:
@@ -726,13 +728,10 @@ class TulipEngine:
     # encoder's wide blocks) is forked behind the forward's first kernel and joined in front of the first wide block; half 1
     # (the decoder's) is forked in front of the LAST encoder stage -- the few-token stage whose small GEMMs leave most of the
     # chip idle -- and joined in front of the first decoder block that streams a copy: beside the 96-wide blocks at the head
-    # of the forward the whole refresh cost those blocks ~15 us each (tools/step_stamps.py).  TULIP_SPLIT_PACK=0: one piece.
-    split_pack = knobs.on("TULIP_SPLIT_PACK", True)
-    # the deep stages' copies as a third piece forked in front of stage 2 (run_forward): batch 8 1.9426 -> 1.9315 ms, batch 64 9.022 ->
-    # 9.007 (four interleaved runs each, same box, profiles/r5_ab_pack_layout2.txt; ONE piece for everything, TULIP_SPLIT_PACK=0:
-    # 1.9311 / 9.022).  (A first A/B read "flat": every piece was then enqueued in front of the deep stage's first kernel, _join_pack.)
-    deep_pack = knobs.on("TULIP_DEEP_PACK", True)
-    pack_layout = knobs.text("TULIP_PACK_LAYOUT", "a")
+    # of the forward the whole refresh cost those blocks ~15 us each (tools/step_stamps.py).
+    # The deep stages' copies are a third piece forked in front of stage 2 (run_forward): batch 8 1.9426 -> 1.9315 ms, batch 64 9.022 ->
+    # 9.007 (profiles/r5_ab_pack_layout2.txt).  One piece / two pieces cut the other way / the deep piece a stage earlier were all
+    # measured within +-5 us or worse (profiles/r5_ab_pack_layout*.txt) and their switches are gone (round 6).
     _packs = None
 
     def _fork_pack(self, part, also=()):
@@ -745,7 +744,7 @@ class TulipEngine:
         node's first-created successor on the node's queue, see defer_side)."""
         for part, pk in (self._packs or {}).items():
             if not pk[1]:
-                st = self._side_streams[0]
+                st = self._side_stream
                 st.wait_event(pk[0])
                 with torch.cuda.stream(st):
                     self.params.refresh_transposes(part, pk[3])
@@ -764,7 +763,7 @@ class TulipEngine:
         if any(not self._packs[q][1] for q in need):
             self._issue_pack()
         if any(not self._packs[q][2] for q in need):
-            torch.cuda.current_stream().wait_stream(self._side_streams[0])     # (one side stream: waits for all issued halves)
+            torch.cuda.current_stream().wait_stream(self._side_stream)     # (one side stream: waits for all issued halves)
             for pk in self._packs.values():
                 pk[2] = pk[2] or pk[1]
 
@@ -809,7 +808,7 @@ class TulipEngine:
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
-    fuse_tail_fwd = knobs.on("TULIP_FUSE_TAIL_FWD", True)      # norm_up + head + loss partials in one launch
+    fuse_tail_fwd = True      # norm_up + head + loss partials in one launch
     _loss_final = None
 
     def run_forward(self, P: Plan, with_loss: bool = True, pack_on_side: bool = False, defer_loss_final: bool = False):
@@ -829,7 +828,7 @@ class TulipEngine:
         H0, W0 = self.grid
         kw = 8 if m.circular_padding else m.patch_size[1]
         pend, self._pending_draw = self._pending_draw, None
-        if pend is not None and pend[0] is not P:          # (drawn for another plan: issue it on its own)
+        if pend is not None and pend[0] is not P:          # (drawn for another plan: a launch of its own)
             ops.drop_path_scales(*pend[1])
             pend = None
         ops.patch_embed_fwd(P.x_in, W_.p32("patch_embed.proj.weight"), W_.p32("patch_embed.proj.bias"),
@@ -838,14 +837,11 @@ class TulipEngine:
                             m.circular_padding, self.eps,
                             out_bf16=(P["dec0.cat"].data_ptr() + 2 * E) if nl > 1 else None, ld_bf16=2 * E,
                             draw=pend[1] if pend is not None else None)
-        two_packs = pack_on_side and W_.pk_active and self.split_pack and nl > 2
-        deep_pack = two_packs and self.deep_pack and nl >= 4 and any(w >= 768 for w in W_.pk_active)
-        # pack_layout (with a deep piece): "a" = three pieces (encoder's wide | deep | decoder's wide); "c" = two (all wide blocks in
-        # piece 0 | deep): one fork + join (~10 us of chain gaps) fewer; "d" = deep piece forked in front of stage 1 instead of 2
-        lay = self.pack_layout if deep_pack else "a"
+        # three pieces: the encoder's wide blocks | the deep stages | the decoder's wide blocks
+        two_packs = pack_on_side and W_.pk_active and nl > 2
+        deep_pack = two_packs and nl >= 4 and any(w >= 768 for w in W_.pk_active)
         if pack_on_side and W_.pk_active:
-            also = ((2,) if (two_packs and not deep_pack) else ()) + ((1,) if lay in ("c", "e") else ())
-            self._fork_pack(0 if two_packs else None, also=also)
+            self._fork_pack(0 if two_packs else None, also=(2,) if (two_packs and not deep_pack) else ())
         # every encoder stage input is x_save[s]: its bf16 copy goes straight into the second half of the level's
         # concat buffer (tulip.py:715) from the kernel that produces it
         x = None
@@ -854,9 +850,9 @@ class TulipEngine:
         # riding in piece 0 beside the HBM-bound 96-wide blocks at the head of the forward (the second of them took 66 instead
         # of 32 us there in the traced step)
         for s in range(nl):
-            if deep_pack and s == (1 if lay in ("d", "e") else 2):
+            if deep_pack and s == 2:
                 self._fork_pack(2)
-            if two_packs and s == nl - 1 and lay not in ("c", "e"):
+            if two_packs and s == nl - 1:
                 self._fork_pack(1)
             x = self._stage_fwd(P, self.enc_blocks[s], P[f"enc{s}.in"],
                                 out_bf16=P[f"lvl{s}.xb"] if (s == nl - 1 and nl > 1) else None)
@@ -929,10 +925,10 @@ class TulipEngine:
     # weight gradients run beside the latency-bound chain: what matters is how much they disturb it, not their
     # own latency.  >= 1024 tokens per split keeps the slab traffic (splits x output, written then folded) at a
     # quarter of what "fill the chip" splitting (256 tokens) produced: step 4.07 -> 3.96 ms.
-    WGRAD_CTAS = knobs.integer("TULIP_WGRAD_CTAS", 512)
-    WGRAD_MINK = knobs.integer("TULIP_WGRAD_MINK", 1024)
-    WGRAD_BIG_CTAS = knobs.integer("TULIP_WGRAD_BIG_CTAS", 256)
-    WGRAD_BIG_MINK = knobs.integer("TULIP_WGRAD_BIG_MINK", 512)
+    WGRAD_CTAS = 512
+    WGRAD_MINK = 1024
+    WGRAD_BIG_CTAS = 256
+    WGRAD_BIG_MINK = 512
     # A large-tile workgroup takes a whole CU (8 waves x 256 registers, 92 KB of LDS): a group is sized to one round of
     # the CUs that are FREE.  With a gradient all-reduce running beside the backward RCCL's channel workgroups hold wave
     # slots on up to ~32 CUs for the length of a collective, and a 256-workgroup launch would need a second round for
@@ -947,8 +943,7 @@ class TulipEngine:
     # step time is flat in the workgroup count (profiles/README.md), so the split-K traffic is what decides.  Default
     # (round 3 sweep, same box, batch 8 / 64 ms per step): all 256: 2.2755 / 9.691; this map: 2.2784 / 9.717 with the slabs
     # of a step at 70 MB instead of 220 MB; "100:112;20:28" (no split at C = 192 either): 2.360 / 10.16.
-    wgrad_ctas_map = tuple(sorted((tuple(int(v) for v in e.split(":")) for e in
-                                   knobs.text("TULIP_WGRAD_CTAS_MAP", "100:112;20:128;5:128").split(";") if e), reverse=True))
+    wgrad_ctas_map = ((100, 112), (20, 128), (5, 128))
 
     def _group_ctas(self, group_tiles: int) -> int:
         if not self.wgrad_ctas:                      # (a DDP run pins the count: RCCL's channels hold CUs)
@@ -998,28 +993,26 @@ class TulipEngine:
                 return
         ops.gemm(A, B, M, N, K, **kw)
 
-    mid_gemm = knobs.on("TULIP_GEMM_MID", True)
+    mid_gemm = True
 
     # Side launches per STAGE, not per block (default since the side queue, not the chain, ends the backward): a grouped
     # weight-gradient launch is one round of the chip whatever it holds, so its slabs are ~one 147-KB tile per workgroup --
     # 28-37 MB written, read back by the fold -- per LAUNCH.  A stage's two blocks and its boundary linears in one launch
     # (up to 12 linears) halve the launches, the slab traffic (1.36 -> 0.7 GB per step) and the fold launches: 2.46 -> 2.33 ms
     # at batch 8, 10.41 -> 10.24 ms at batch 64 (same box; per-block launches for the backward's last stage only: 2.36).
-    flush_per_block = knobs.on("TULIP_FLUSH_PER_BLOCK", False)
-    flush_unfused_blocks = knobs.on("TULIP_FLUSH_UNFUSED_BLOCKS", False)
-    merge_embed_fold = knobs.on("TULIP_MERGE_EMBED_FOLD", False)      # measured neutral (2.245 vs 2.243 ms): off
+    # (per-block side launches, a flush behind every unfused block, the patch-embedding fold riding in the last group: measured worse or
+    # neutral in rounds 2-5, profiles/README.md; their switches are gone)
     wgrad_group_max = knobs.integer("TULIP_WGRAD_GROUP_MAX", 12)    # linears per grouped launch (<= 16)
     early_flush = frozenset()   # block prefixes with a mid-block side flush (set in bind())
-    lag_bucket_join = knobs.on("TULIP_LAG_BUCKET_JOIN", True)
     _lagged_hook = None
     # Side streams.  How the HIP graph executor (ROCm 7.2) turns captured branches into hardware-queue work decides what
     # a fork costs the chain: it walks the graph depth first along each node's FIRST-created successor and gives every
     # other successor a new run list on another queue.  With the side kernels enqueued right at the fork (defer_side
     # off) they are the first successor, so the chain itself changes queue at every fork (~12 us each; then 4, 8, 12...
     # side streams used round-robin are best: 1 stream 4.63 ms, 2: 4.46, 3: 4.82, 4: 4.05, 8: 4.05 at the time).  With
-    # defer_side the chain's next kernel is created first, the chain stays on one queue for the whole step, and a
-    # single side stream is best (1: 3.32 ms, 2: 3.59, 3: 3.63, 4: 3.67, 8: 3.63; 3.42 for the old layout).
-    n_side = knobs.integer("TULIP_SIDE_STREAMS", 1 if knobs.on("TULIP_DEFER_SIDE", True) else 4)
+    # the fork deferred (_release_deferred) the chain's next kernel is created first, the chain stays on one queue for the whole
+    # step, and a single side stream is best (1: 3.32 ms, 2: 3.59, 3: 3.63, 4: 3.67, 8: 3.63; 3.42 for the old layout; two side
+    # streams re-measured in rounds 3 and 5: +0.36 ms).  One side stream, always deferred: the switches are gone (round 6).
     overlap_wgrad = True   # run the weight-gradient branch on a second HIP stream (forked inside the graph)
 
     def _wgrad(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias=None):
@@ -1086,10 +1079,8 @@ class TulipEngine:
         self._fold(part, nh * 256, dense, nh * 256, rows, overwrite=True)
         r = ops.reduce_region(dense, nh * 256, gtable, nh * 256, 1, overwrite=self.grad_overwrite, scatter_index=self._rel32,
                               scatter_nh=nh, scatter_len=256)
-        if self.overlap_wgrad and self.n_side == 1:
+        if self.overlap_wgrad:
             self._pending.append(("s", r))
-        elif self.overlap_wgrad:
-            self._pending.append(("f", lambda: ops.reduce_rows_multi([r])))
         else:
             ops.reduce_rows_multi([r])
 
@@ -1099,11 +1090,11 @@ class TulipEngine:
         """Launch the scatters still waiting (end of the backward / a DDP bucket point) on the side stream."""
         if self._carry:
             carry, self._carry = list(self._carry), ()
-            with torch.cuda.stream(self._side_streams[0]):
+            with torch.cuda.stream(self._side_stream):
                 ops.reduce_rows_multi(carry, adam=self._adam_arg())
             self._side_dirty = True
 
-    group_wgrad = knobs.on("TULIP_GROUP_WGRAD", True)
+    group_wgrad = True
 
     def _issue_pending(self, ws: int, pending=None):
         """Launch the queued side work on the current stream: weight gradients as grouped GEMMs (<= wgrad_group_max per launch), every
@@ -1116,9 +1107,6 @@ class TulipEngine:
         regions = list(self._carry) + [a for k, a in pending if k == "r"]
         self._carry = tuple(a for k, a in pending if k == "s")     # their dense sums are produced by THIS launch
         fns = [a for k, a in pending if k == "f"]
-        # "e": an event the flush's FOLD launch has to wait for (not its weight-gradient launch) -- regions appended behind it
-        # became ready on the chain after the flush was forked (the patch-embedding partial rows: run_backward)
-        late = [a for k, a in pending if k == "e"]
         ws_bytes = (self.WS_ELEMS + (1 << 20)) * 4
         if not self.group_wgrad:
             for a in items:
@@ -1155,15 +1143,8 @@ class TulipEngine:
                                           adamw=step_here))
                 items.pop(0)
             room = _lib.REDUCE_REGIONS_MAX - 2 * len(grp)
-            if late and not items and len(regions) <= room:
-                # one group, folded in ONE launch behind the late event together with everything else of this flush
-                ops.wgrad_group(grp, [], ws, ws_bytes, fold=False, adam=self._adam_arg(), small_tiles=self.wgrad_small_tiles)
-                regions = ops.wgrad_group_regions(grp, ws) + regions
-                break
             extra, regions = regions[:room], regions[room:]
             ops.wgrad_group(grp, extra, ws, ws_bytes, adam=self._adam_arg(), small_tiles=self.wgrad_small_tiles)
-        for ev in late:
-            torch.cuda.current_stream().wait_event(ev)
         while regions:
             ops.reduce_rows_multi(regions[:_lib.REDUCE_REGIONS_MAX], adam=self._adam_arg())
             regions = regions[_lib.REDUCE_REGIONS_MAX:]
@@ -1171,16 +1152,17 @@ class TulipEngine:
             fn()
 
     def _flush_wgrads(self, advance: bool = True, mark: bool = False):
-        """Issue the queued side work on the current side stream; advance: move on to the next stream afterwards.
-        mark: an event behind this group on its stream (pack_at_end: every packable weight has been stepped once it has run)."""
+        """Fork the queued side work: the fork point is here, the launches are enqueued behind the chain's next kernel
+        (_release_deferred); advance=False: a mid-block flush, enqueued at once.
+        mark: an event behind this group on the side stream (pack_at_end: every packable weight has been stepped once it has run)."""
+        st, ws = self._side_stream, self._ws_side_ptr
         if not self._pending:
+            if mark:
+                # nothing queued at the marked hook: everything that steps a packed weight is already forked (or still deferred)
+                self._mark_side()
             return
         main = torch.cuda.current_stream()
-        k = self._side_rr % self.n_side
-        st, ws = self._side_streams[k], self._ws_sides[k].data_ptr()
-        if advance:                         # advance=False: a mid-block flush, the block's remainder follows on
-            self._side_rr += 1              # the same stream
-        if self.defer_side and advance:
+        if advance:                         # (advance=False: a mid-block flush, issued at once; the block's remainder follows)
             # the fork point is HERE, but the side kernels are enqueued only after the chain's next kernel (see
             # _release_deferred): the graph executor keeps a node's first-created successor on the node's queue
             self._release_deferred()
@@ -1199,7 +1181,6 @@ class TulipEngine:
         self._pending = []
         self._side_dirty = True
 
-    defer_side = knobs.on("TULIP_DEFER_SIDE", True)
     _deferred = None
     pack_at_end = False           # per run_backward call (the Trainer's choice, Trainer._pack_at_end)
     _pack_ev = None
@@ -1212,6 +1193,15 @@ class TulipEngine:
             ss = [s for s, blks in enumerate(self.enc_blocks) if any(sp.C in self.params.pk_active for sp in blks)]
             t = self._pack_mark_tag_ = f"enc{min(ss)}" if ss else ""
         return t
+
+    def _mark_side(self):
+        """_pack_ev = everything forked so far has run (the deferred group is enqueued first; the side stream joins the chain's
+        position, so the event is valid inside a capture even when nothing was forked yet)."""
+        self._release_deferred()
+        self._side_stream.wait_stream(torch.cuda.current_stream())
+        self._pack_ev = torch.cuda.Event()
+        self._pack_ev.record(self._side_stream)
+        self._side_dirty = True
 
     def _release_deferred(self):
         d, self._deferred = self._deferred, None
@@ -1246,8 +1236,7 @@ class TulipEngine:
         self._release_deferred()
         self._flush_carry()
         if getattr(self, "_side_dirty", False):
-            for st in self._side_streams:
-                torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.current_stream().wait_stream(self._side_stream)
             self._side_dirty = False
 
     def _join_side(self):
@@ -1255,8 +1244,7 @@ class TulipEngine:
         self._release_deferred()
         self._flush_carry()
         if getattr(self, "_side_dirty", False):
-            for st in self._side_streams:
-                torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.current_stream().wait_stream(self._side_stream)
             self._side_dirty = False
 
     def _wgrad_launch(self, dY, ldy, X, ldx, Nw, Kw, Mtok, gout, gbias, ws):
@@ -1362,8 +1350,6 @@ class TulipEngine:
             if self._lagged_hook is not None:
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
-            if self.flush_per_block or sp.prefix in self.flush_after:
-                self._flush_wgrads()
             return
         if self._fused_bwd(sp, B):
             # the whole data-gradient chain of the block in one launch (csrc/swin96.hip, csrc/swinw.hip); the weight
@@ -1412,8 +1398,6 @@ class TulipEngine:
             if self._lagged_hook is not None:
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
-            if self.flush_per_block or sp.prefix in self.flush_after:
-                self._flush_wgrads()
             return
         # ---- MLP branch (tulip.py:346-351)
         if not have_dyb:
@@ -1448,10 +1432,6 @@ class TulipEngine:
         if self._lagged_hook is not None:
             fn, self._lagged_hook = self._lagged_hook, None
             fn()                                    # bucket join + all-reduce of the previous group, one block late
-        if self.flush_per_block or self.flush_unfused_blocks:
-            # (flush_unfused_blocks: the unfused blocks are the deep, few-token stages -- their chain is dozens of small
-            # GEMMs that leave most of the chip idle, the best place for their own weight gradients to run)
-            self._flush_wgrads()
 
     def _stage_bwd(self, P: Plan, specs: List[BlockSpec], stage_in, dx, G, have_dyb=False, next_cast=None):
         """have_dyb: the last block's dyb_m was already produced by whoever produced dx;
@@ -1501,7 +1481,7 @@ class TulipEngine:
     adam_apply = False
     adam_probe = None
     _gflat = None
-    fuse_adamw_folds = knobs.on("TULIP_FUSE_ADAMW_FOLDS", True)      # (0: only the un-split write-outs step)
+    fuse_adamw_folds = True      # (False: only the un-split write-outs step)
 
     def overwrite_supported(self, B: int) -> bool:
         return bool(self.group_wgrad and self.overlap_wgrad)
@@ -1553,13 +1533,11 @@ class TulipEngine:
             self._flush_wgrads(mark=self.pack_at_end and self.adam_apply and tag == self._pack_mark_tag)
             if tag == "embed":
                 join_and_fire(tag)
-            elif bucket and self.lag_bucket_join:
+            elif bucket:
                 # joining here would stall the chain behind the side work that was forked a moment ago; the join
                 # (and with it the bucket's all-reduce) moves to the end of the NEXT block's chain work, before that
                 # block's own side work is issued (see _block_bwd)
                 self._lagged_hook = lambda: join_and_fire(tag)
-            elif bucket:
-                join_and_fire(tag)
             else:
                 user_hook(tag)
 
@@ -1700,6 +1678,11 @@ class TulipEngine:
                             ep + rel("patch_embed.norm.weight"), ep + rel("patch_embed.norm.bias"), B, m.in_chans,
                             m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
                             self.eps, partial_stride=P.embed_stride)
+        if self.pack_at_end and self.adam_apply and self._pack_ev is None:
+            # the marked group has not been enqueued (its fork is still deferred: the marked tag is this last stage, e.g. a model
+            # whose stage 0 already has a packed width) or no hook carried the mark: enqueue what is deferred -- the chain's next
+            # kernel, patch_embed_bwd, exists by now -- and order the refresh behind everything on the side queue
+            self._mark_side()
         if self._pack_ev is not None:
             # pack_at_end: the chain has nothing left to do but wait for the side queue's last groups -- the fragment-major copies of
             # every wide / deep weight (all stepped by now: the marked group was the last that holds any) are rewritten HERE, on the
@@ -1708,14 +1691,7 @@ class TulipEngine:
             W_.refresh_transposes()
             self._pack_ev = None
         gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
-        if self.merge_embed_fold and self._deferred is not None and self.overlap_wgrad:
-            # the last stage's side work was forked in front of patch_embed_bwd and is not enqueued yet: its fold launch waits
-            # for the kernel above and takes the patch-embedding partial rows along (one launch less behind the chain's end)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._deferred[3].extend([("e", ev), ("r", ops.reduce_region(ep, P.embed_stride, gpe, P.embed_stride, nbe))])
-        else:
-            self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
+        self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge
@@ -1780,12 +1756,16 @@ class TulipEngine:
         if not hasattr(P, "_mod_gbufs"):
             P._mod_gbufs = [torch.zeros(W_.total, dtype=torch.float32, device=self.device) for _ in range(2)]
             P._mod_gscale = torch.ones(1, dtype=torch.float32, device=self.device)
-            P._mod_gidle = min(_storage_users(P._mod_gbufs[0]), (1 << 30) - 1)
+            P._mod_gidle = _storage_users(P._mod_gbufs[0])
+            if P._mod_gidle >= (1 << 30) or _storage_users(P._mod_gbufs[1]) != P._mod_gidle:
+                P._mod_gidle = -1                      # no trustworthy count: every call takes the private buffer + copy
         if dloss is None:
             P._mod_gscale.fill_(1.0)
         else:
             P._mod_gscale.copy_(dloss.detach().reshape(1))
-        which = next((i for i, b in enumerate(P._mod_gbufs[:2]) if _storage_users(b) <= P._mod_gidle), None)
+        # (EXACTLY the idle count: any other value -- a live .grad view, or a torch build that counts the temporary storage wrapper
+        # differently from the baseline call -- reads as "taken" and falls to the private buffer + copy)
+        which = next((i for i, b in enumerate(P._mod_gbufs[:2]) if _storage_users(b) == P._mod_gidle), None)
         if which is None:
             if len(P._mod_gbufs) == 2:
                 P._mod_gbufs.append(torch.zeros(W_.total, dtype=torch.float32, device=self.device))

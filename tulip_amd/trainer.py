@@ -107,9 +107,10 @@ class Trainer:
         # (FlatParams groups every parameter where it is last READ in the backward -- the skip Linears sit in their
         # encoder stage's group -- so a bucket's weights are dead once the bucket's hook has fired)
         self._segments = None     # {is_update_step: [(CUDAGraph, tag or None)]}
+        self._pack_epoch = -1
         # the fragment-major weight copies of the fused wide blocks (one ~25-us launch) are rewritten at the START of the
-        # next step, beside the forward's first kernels, instead of on the chain behind AdamW (TULIP_PACK_AT_START=0: old)
-        self.pack_at_step_start = knobs.on("TULIP_PACK_AT_START", True)
+        # next step, beside the forward's first kernels, instead of on the chain behind AdamW
+        self.pack_at_step_start = True
         # round 5 (TULIP_PACK_AT_END=0: off): the copies rewritten at the END of the step, on the chain's own queue while it waits for the
         # side queue's last groups (TulipEngine.run_backward) -- no forks or joins beside the forward, no pack traffic beside its
         # kernels: 1.9107 -> 1.8941 ms at batch 8, 9.054 -> 9.017 at batch 64 (four interleaved same-box runs each,
@@ -121,6 +122,11 @@ class Trainer:
         # to a buffer AdamW has to clear: TulipEngine.grad_overwrite (TULIP_GRAD_OVERWRITE=0: accumulate + clear, as with accum_iter > 1)
         self.grad_overwrite = (self.accum_iter == 1 and knobs.on("TULIP_GRAD_OVERWRITE", True)
                                and self.eng.overwrite_supported(batch_size))
+        if self.exchange == "sharded" and not self.grad_overwrite:
+            # the sharded plan clears nothing outside the blocks this rank steps: an accumulating (+=) backward would feed the stale
+            # running sums of the other ranks' shards into the next reduce-scatter
+            raise ValueError("exchange='sharded' needs the overwriting backward (accum_iter == 1, TULIP_GRAD_OVERWRITE on, grouped "
+                             "weight gradients)")
         # ... and where a weight-gradient workgroup holds a tensor's COMPLETE gradient tile (no token split: the deep stages, 90 %
         # of the parameters), the optimizer step is taken right there, in the write-out, beside the backward instead of behind it
         # (TULIP_FUSE_ADAMW=0: one AdamW launch over everything at the end of the step).  Captured steps on one GPU only: a
@@ -131,7 +137,6 @@ class Trainer:
         self._adam_blocks = None
         self._adam_ctx, self._adam_fused = None, frozenset()
         self.fused_adamw_params = 0
-        self._fuse_adamw_skip = knobs.names("TULIP_FUSE_ADAMW_SKIP")   # dev: name prefixes
         # parity tests: explicit DropPath uniforms [n_drop_slots][B] (device tensor) instead of the counter-based draws;
         # set before the first step (the choice is baked into the captured graphs)
         self.inject_drop_u: Optional[torch.Tensor] = None
@@ -239,13 +244,21 @@ class Trainer:
                              zero_grad=not self.grad_overwrite)
             if not dry:
                 self._sharded.gather_shadow(tag, W.shadow)
+        if self.world > 1:
+            # the fp32 master (what model.parameters() / state_dict() view) is now current only on the shards this rank owns:
+            # nobody may re-derive the bf16 shadow from it until gather_state() has run on every rank
+            W.master_partial = True
 
     def gather_state(self):
         """exchange="sharded": fp32 master and both moments whole on every rank again (checkpoints, state_dict(), evaluation
-        through anything that re-derives the shadow from the master).  A no-op for the all-reduce plans."""
+        through anything that re-derives the shadow from the master).  A COLLECTIVE: every rank of the process group must call it
+        (and therefore Trainer.state_dict()) together -- a call guarded by `if rank == 0` deadlocks.  A no-op for the all-reduce plans.
+        Until it has run, FlatParams.master_partial makes every path that would rebuild the bf16 shadow from the stale master
+        (model(x) through the module, GraphedForward.weights_changed, load_state_dict -> refresh_shadow) raise instead."""
         if self._sharded is not None:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._sharded.gather_state(self.eng.params.flat, self.m, self.v)
+            self.eng.params.master_partial = False
 
     def _finish_buckets(self):
         if self.bucket_adamw:
@@ -318,6 +331,7 @@ class Trainer:
             self.eng._drop_seed = seed
             self._segments = None          # the seed is a launch argument baked into the captured graphs: re-capture
         self.eng._drop_counter.fill_(int(sd["drop_counter"]))
+        W.master_partial = False       # (the model's load_state_dict wrote the whole master and this call the whole moments)
         W.shadow_dirty = True          # the model's own load_state_dict normally precedes this; refresh either way
 
     def _plan_fused_adamw(self, eligible):
@@ -340,8 +354,7 @@ class Trainer:
                 names.append(by_off[o])
                 o = (o + W.numel[by_off[o]] + ALIGN - 1) // ALIGN * ALIGN
             whole = bool(names) and W.offset[names[-1]] + W.numel[names[-1]] <= a + cnt <= o
-            if (not whole or any(n.startswith("skip_connection_layers.") for n in names)
-                    or any(n.startswith(x) for n in names for x in self._fuse_adamw_skip)):
+            if not whole or any(n.startswith("skip_connection_layers.") for n in names):
                 rejected_modules.update(module_of(n) for n in names)
                 continue
             cand.append((ptr, a, cnt, names))
@@ -530,6 +543,8 @@ class Trainer:
                 self._fwd_bwd(lambda tag: None, update=False)
             self.eng.params.pack_dirty = self.eng.params.pack_dirty or mark_pack_dirty
             return self.P.losses
+        if self._segments is not None and self._pack_epoch != self.eng.params.pack_epoch:
+            self._segments = None       # another plan activated the weight copies of a width this capture does not rewrite
         if self._segments is None:
             # load every kernel once outside capture, without touching parameters, optimizer state, the gradients of an
             # open accumulation window or the DropPath stream (the pass below accumulates into g and draws once)
@@ -547,6 +562,7 @@ class Trainer:
             self.eng._drop_counter.copy_(keep_c)
             del keep_g
             torch.cuda.synchronize()
+            self._pack_epoch = self.eng.params.pack_epoch
             try:
                 self._segments = {True: self._capture(True)}
                 if self.accum_iter > 1:
