@@ -399,10 +399,11 @@ def comm_report(trainer, args, world, device, steps=10):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item() / steps * 1e3
     with_coll = timed()
-    trainer.bucketer.dry = True
-    trainer.step()
+    trainer.set_dry(True)           # (the one-graph form re-captures: its collectives are nodes of the graph)
+    trainer.step(); trainer.step()
     without = timed()
-    trainer.bucketer.dry = False
+    trainer.set_dry(False)
+    trainer.step()
     el = 2 if trainer.grad_dtype == "bf16" else 4
     try:
         ver = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -889,8 +890,12 @@ def main():
     from tulip_amd import knobs
     out["config"]["knobs_non_default"] = knobs.non_default()      # an A/B switch in the environment shows in the line itself
     out["config"]["step_structure"] = {
-        "form": ("eager" if not trainer.use_graph else "one_graph" if segs <= 1 and not dets else
-                 "segments+detached_buckets" if dets else "segments"),
+        "form": ("eager" if not trainer.use_graph else
+                 "one_graph_captured_collectives" if getattr(trainer, "step_form", "") == "one_graph_captured_collectives" else
+                 "one_graph" if segs <= 1 and not dets else "segments+detached_buckets" if dets else "segments"),
+        "graph_collectives_fell_back": bool(world > 1 and trainer.use_graph and getattr(trainer, "exchange", "") == "allreduce"
+                                            and dist.get_backend() == "nccl" and not getattr(trainer, "graph_collectives", False)
+                                            and not knobs.is_zero("TULIP_GRAPH_COLLECTIVES")),
         "graph_segments": segs, "detached_bucket_graphs": dets,
         "optimizer": ("in_weight_gradient_write_out" if world == 1 and getattr(trainer, "fuse_adamw", False) else
                       "sharded_per_bucket" if getattr(trainer, "exchange", "allreduce") == "sharded" else

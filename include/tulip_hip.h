@@ -567,13 +567,83 @@ int tulip_swind_block_fwd(const tulip_swin96_desc* d, int C, int wh, int ww, voi
 int tulip_swind_block_bwd(const tulip_swin96_bwd_desc* d, int C, int wh, int ww, float* d_norm_out, int phases, uint64_t* stamps,
                           hipStream_t stream);
 
+/* ---- the stage boundaries of the U-Net as ONE launch each (csrc/glue.hip, round 6) -------------------------------------
+ * A workgroup owns a block of 16 / 32 rows for the whole boundary: the row block's activations sit in LDS as the MFMA B operand,
+ * the weights stream from their FRAGMENT-MAJOR copies (tulip_pack_bf16_multi: `*_packed` = the matrix as it is, `*_t_packed` =
+ * its transpose), and what the launch sequences below pass through HBM passes through LDS.  bf16 rounding points are those of
+ * the sequences they replace (every GEMM operand bf16, every accumulator fp32, LayerNorm in fp32): results agree with them to
+ * fp32 summation order.  Every *_supported() is 0 where the form does not exist; the caller then issues the sequence. */
+
+/* PatchMerging.forward (tulip.py:101-106) = tulip_layernorm_fwd(merge = 1) + tulip_gemm_bf16(TULIP_EPI_F32): x (B,H,W,Cin) fp32
+ * -> 2x2 gather -> LayerNorm(4 Cin) -> xm bf16 [rows][4 Cin], mean, rstd [rows] (saved for the backward) -> y fp32 [rows][2 Cin]
+ * = xm . W^T (no bias); y_bf16 (optional, row pitch ld_bf16 elements): bf16 copy of y (x_save half of the next level's skip
+ * concat, tulip.py:715).  rows = B H/2 W/2.  Cin in {96, 192, 384}, rows % 32 == 0. */
+typedef struct tulip_merge_fwd_desc {
+    const float* x; const float* gamma; const float* beta;
+    const void* w_packed;          /* reduction.weight [2 Cin][4 Cin], fragment-major */
+    void* xm; float* mean; float* rstd; float* y;
+    void* y_bf16; int ld_bf16;
+    int B, H, W, Cin; float eps;
+} tulip_merge_fwd_desc;
+int tulip_merge_fwd_supported(int Cin, int B, int H, int W);
+int tulip_merge_fwd(const tulip_merge_fwd_desc* d, hipStream_t stream);
+
+/* Backward of the same boundary (autograd of tulip.py:101-106, and of the x_save half of tulip.py:715 in front of it) =
+ * [tulip_gemm_bf16(dy_skip . W_skip[:, Cs:], TULIP_EPI_F32 accumulate + bf16 copy)] + tulip_gemm_bf16(dyb . W_red, TULIP_EPI_BF16)
+ * + tulip_layernorm_bwd(merge = 1).  (B,H,W,Cp) is the FINER stage (the LayerNorm's input x_prev), Cs = 2 Cp, rows = B H/2 W/2.
+ * dy_skip != NULL: dyb = bf16(dx_in + dy_skip . W_skip[:, Cs:2Cs]) is formed and WRITTEN (operand of the reduction's weight
+ * gradient; w_skip_t_packed = packed W_skip^T, a [2 Cs][Cs] matrix); dy_skip == NULL: dyb is READ (the bottleneck stage: no skip).
+ * dx_prev (B,H,W,Cp) fp32 is overwritten with the LayerNorm backward's result scattered through the gather; dx_bf16 (optional) =
+ * bf16(dx_prev * cast_rowscale[token / cast_rows_per_sample]); param_partials: tulip_merge_bwd_partial_rows() rows of
+ * [dgamma[4 Cp] | dbeta[4 Cp]] (fold with tulip_reduce_rows_multi).  Cp in {96, 192}, rows % 32 == 0. */
+typedef struct tulip_merge_bwd_desc {
+    const float* dx_in; const void* dy_skip; const void* w_skip_t_packed;
+    void* dyb;
+    const void* w_red_t_packed;    /* packed reduction.weight^T: a [4 Cp][2 Cp] matrix */
+    const float* x_prev; const float* mean; const float* rstd; const float* gamma;
+    float* dx_prev; float* param_partials;
+    void* dx_bf16; const float* cast_rowscale; int cast_rows_per_sample;
+    int B, H, W, Cp;
+} tulip_merge_bwd_desc;
+int tulip_merge_bwd_supported(int Cp, int B, int H, int W);
+int tulip_merge_bwd_partial_rows(int Cp, int B, int H, int W);
+int tulip_merge_bwd(const tulip_merge_bwd_desc* d, hipStream_t stream);
+
+/* PatchUnmerging.forward -> skip Linear(cat[...]) (tulip.py:117-123, :713-716) = tulip_gemm_bf16(TULIP_EPI_PIXSHUF2_F32) +
+ * tulip_gemm_bf16(TULIP_EPI_F32).  x_bf16 [M][C], M = B H W coarse tokens; cat bf16 [4M][C] (fine-token order): its first half
+ * [:, :C/2] = bf16(PixelShuffle(2)(x . We^T + be)) is WRITTEN (operand of the skip weight gradient), its second half (x_save)
+ * is READ; out fp32 [4M][C/2] = cat . Ws^T + bs.  C in {192, 384}, M % 16 == 0. */
+typedef struct tulip_unmerge_skip_desc {
+    const void* x_bf16;
+    const void* w_expand_packed; const float* b_expand;     /* expand.weight [2C][C] fragment-major, bias [2C] */
+    void* cat;
+    const void* w_skip_packed; const float* b_skip;         /* skip weight [C/2][C] fragment-major, bias [C/2] */
+    float* out;
+    int B, H, W, C;
+} tulip_unmerge_skip_desc;
+int tulip_unmerge_skip_supported(int C, int B, int H, int W);
+int tulip_unmerge_skip_fwd(const tulip_unmerge_skip_desc* d, hipStream_t stream);
+
+/* Its backward along the unmerged stream = tulip_gemm_bf16(dy_skip . W_skip[:, :C/2], TULIP_EPI_UNSHUF2_BF16) +
+ * tulip_gemm_bf16(dz . We, TULIP_EPI_F32 + bf16 copy): dy_skip bf16 [4M][C/2]; dz bf16 [M][2C] is WRITTEN (operand of the expand
+ * weight / bias gradient); dx fp32 [M][C] overwritten; dx_bf16 (optional) = bf16(dx * cast_rowscale[m / cast_rows_per_sample]).
+ * w_skip_t_packed = packed W_skip^T ([C][C/2], rows 0 .. C/2-1 used), w_expand_t_packed = packed We^T ([C][2C]). */
+typedef struct tulip_skip_unmerge_bwd_desc {
+    const void* dy_skip; const void* w_skip_t_packed;
+    void* dz;
+    const void* w_expand_t_packed;
+    float* dx; void* dx_bf16; const float* cast_rowscale; int cast_rows_per_sample;
+    int B, H, W, C;
+} tulip_skip_unmerge_bwd_desc;
+int tulip_skip_unmerge_bwd(const tulip_skip_unmerge_bwd_desc* d, hipStream_t stream);
+
 /* library self-description */
 /* diagnostics: *dst = the 100 MHz constant device clock (s_memrealtime) when the stream reaches this point; capturable
  * (tools/step_stamps.py time-lines a captured training step with it, no tracer attached) */
 int tulip_stamp_realtime(uint64_t* dst, hipStream_t stream);
 /* Layout version of the structs and signatures in this header (round 3: tulip_wgrad_item, tulip_reduce_region and tulip_adamw_ref grew
  * fields, entry points were added): a caller built against another version must not bind. */
-#define TULIP_ABI_VERSION 5
+#define TULIP_ABI_VERSION 6
 int tulip_abi_version(void);
 const char* tulip_build_arch(void);
 int tulip_dev_variants(void);      /* 1: the development build (see the conventions at the top) */

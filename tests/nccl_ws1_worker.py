@@ -33,6 +33,10 @@ def main():
                      ("segments_bf16_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16",
                                                          bucket_adamw=True)),
                      ("segments_sharded", dict(force_segments=True, bucket_mb=0.05, exchange="sharded")),
+                     # round 6, the N > 1 default: ONE graph, every bucket's all-reduce captured as a branch off the side queue
+                     ("captured", dict(force_segments=True, bucket_mb=0.05)),
+                     ("captured_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, bucket_adamw=True)),
+                     ("captured_bf16", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16")),
                      ("eager_plain", dict(use_graph=False)),
                      ("eager_segments", dict(force_segments=True, bucket_mb=0.05, use_graph=False))]:
         torch.manual_seed(11)
@@ -40,6 +44,7 @@ def main():
         # "segments": the last side group of a bucket is a graph of its own behind the segment (Trainer.detach_buckets, the default);
         # "segments_joined": forked inside the segment and joined at the cut
         os.environ["TULIP_DETACH_BUCKETS"] = "0" if name == "segments_joined" else "1"
+        os.environ["TULIP_GRAPH_COLLECTIVES"] = "1" if name.startswith("captured") else "0"
         tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, **kw)
         tr.load_batch(lo.cuda(), hi.cuda())
         losses = [tr.step().clone() for _ in range(steps)]
@@ -47,7 +52,8 @@ def main():
         torch.cuda.synchronize()
         res[name] = {"flat": tr.eng.params.flat.cpu(), "losses": torch.stack(losses).cpu(),
                      "segments": len(tr._segments[True]) if tr.use_graph else 0, "buckets": len(tr.bucketer.buckets),
-                     "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw, "detached": len(tr._det_graphs)}
+                     "segmented": tr.segmented, "bucket_adamw": tr.bucket_adamw, "detached": len(tr._det_graphs),
+                     "form": tr.step_form}
     from tests.conftest import describe_flat_diff
     for name in [k for k in res if k != "init"]:
         ref = res["eager_plain"] if name.startswith("eager") else res["plain"]

@@ -24,7 +24,7 @@ def test_library_builds_and_loads():
     path = build(force=False, verbose=False)
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.tulip_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.tulip_abi_version() == _lib.ABI_VERSION == 6
     assert lib.tulip_build_arch() == b"gfx950"
 
 
@@ -92,7 +92,9 @@ def test_struct_layouts_match_the_header(tmp_path):
     import ctypes
     import subprocess
     structs = {"tulip_swin96_desc": _lib.Swin96Desc, "tulip_swin96_bwd_desc": _lib.Swin96BwdDesc,
-               "tulip_reduce_region": _lib.ReduceRegion, "tulip_wgrad_item": _lib.WgradItem}
+               "tulip_reduce_region": _lib.ReduceRegion, "tulip_wgrad_item": _lib.WgradItem,
+               "tulip_merge_fwd_desc": _lib.MergeFwdDesc, "tulip_merge_bwd_desc": _lib.MergeBwdDesc,
+               "tulip_unmerge_skip_desc": _lib.UnmergeSkipDesc, "tulip_skip_unmerge_bwd_desc": _lib.SkipUnmergeBwdDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tulip_hip.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

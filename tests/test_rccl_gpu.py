@@ -28,7 +28,7 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
     # gradients exchanged in bf16 (Trainer(grad_dtype="bf16")): same structure, the update differs by the rounding of
     # the exchanged gradients only
     u_ref = plain["flat"] - got["init"]
-    for name in ("segments_bf16", "segments_bf16_bucket_adamw"):
+    for name in ("segments_bf16", "segments_bf16_bucket_adamw", "captured_bf16"):
         g = got[name]
         u = g["flat"] - got["init"]
         rel = ((u - u_ref).norm() / u_ref.norm()).item()
@@ -39,7 +39,12 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
     assert got["segments"]["detached"] >= 2 and got["segments_joined"]["detached"] == 0
     # "segments_sharded": Trainer(exchange="sharded") -- RCCL's reduce_scatter_tensor / all_gather_into_tensor between the segment
     # replays; with one rank both are the identity and the rank owns every shard, so the plain step's bits again
-    for name in ("segments", "segments_joined", "segments_bucket_adamw", "segments_sharded", "eager_segments"):
+    # round 6: the collectives captured into ONE graph (Trainer.graph_collectives, the N > 1 default on RCCL)
+    for name in ("captured", "captured_bucket_adamw", "captured_bf16"):
+        assert got[name]["form"] == "one_graph_captured_collectives" and got[name]["segments"] == 1 and got[name]["detached"] == 0, got[name]["form"]
+    assert got["segments"]["form"] == "segments"
+    for name in ("segments", "segments_joined", "segments_bucket_adamw", "segments_sharded", "eager_segments", "captured",
+                 "captured_bucket_adamw"):
         g = got[name]
         assert g["segmented"] and g["buckets"] >= 2
         if name in ("segments", "segments_joined"):

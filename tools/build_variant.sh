@@ -6,7 +6,7 @@ NAME="$1"; shift
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OBJ="/tmp/tulip_objs_$NAME"; mkdir -p "$OBJ"
 pids=()
-for s in gemm norm attention elementwise tail prep evalpost swin96 expand swinw swind; do
+for s in gemm norm attention elementwise tail prep evalpost swin96 expand swinw swind glue; do
   F=("$@"); if [ -n "$ONLY" ] && ! [[ " $ONLY " == *" $s "* ]]; then F=(); fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I "$ROOT/include" -I "$ROOT/tulip_amd/csrc" "${F[@]}" \
     -c "$ROOT/tulip_amd/csrc/$s.hip" -o "$OBJ/$s.o" & pids+=($!)

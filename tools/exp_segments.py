@@ -25,7 +25,7 @@ def run(tag, **kw):
     tr.load_batch(lo, hi)
     out = []
     for dry in (False, True):
-        tr.bucketer.dry = dry
+        tr.set_dry(dry)
         for _ in range(10):
             tr.step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -34,12 +34,16 @@ def run(tag, **kw):
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) * 20)
     segs = len(tr._segments[True]) if tr._segments else 1
-    print(f"{tag:46s} segments {segs}  step {out[0]:.3f} ms   collectives skipped {out[1]:.3f} ms", flush=True)
+    print(f"{tag:58s} segments {segs} ({tr.step_form})  step {out[0]:.3f} ms   collectives skipped {out[1]:.3f} ms", flush=True)
 
 
 run("one graph (world 1)")
-for mb in (16.0, 24.0, 64.0, 1000.0):
-    run(f"segmented, fp32 buckets >= {mb:g} MB", force_segments=True, bucket_mb=mb)
-run("segmented, bf16 buckets", force_segments=True, grad_dtype="bf16")
-run("segmented, per-bucket AdamW", force_segments=True, bucket_adamw=True)
+run("N > 1 DEFAULT: one graph, captured collectives, 16 MB", force_segments=True)
+run("one graph, captured collectives, per-bucket AdamW", force_segments=True, bucket_adamw=True)
+run("one graph, captured collectives, bf16 buckets", force_segments=True, grad_dtype="bf16")
+run("one graph, captured collectives, sharded exchange?", force_segments=True, exchange="sharded")
+os.environ["TULIP_GRAPH_COLLECTIVES"] = "0"
+for mb in (16.0, 1000.0):
+    run(f"segmented (round 5), fp32 buckets >= {mb:g} MB", force_segments=True, bucket_mb=mb)
+run("segmented (round 5), per-bucket AdamW", force_segments=True, bucket_adamw=True)
 dist.destroy_process_group()

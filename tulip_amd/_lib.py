@@ -60,9 +60,30 @@ class PackItem(ctypes.Structure):
     _fields_ = [("src", P), ("dst", P), ("rows", I), ("cols", I), ("transpose", I)]
 
 
+class MergeFwdDesc(ctypes.Structure):      # tulip_merge_fwd_desc
+    _fields_ = [("x", P), ("gamma", P), ("beta", P), ("w_packed", P), ("xm", P), ("mean", P), ("rstd", P), ("y", P),
+                ("y_bf16", P), ("ld_bf16", I), ("B", I), ("H", I), ("W", I), ("Cin", I), ("eps", F)]
+
+
+class MergeBwdDesc(ctypes.Structure):      # tulip_merge_bwd_desc
+    _fields_ = [("dx_in", P), ("dy_skip", P), ("w_skip_t_packed", P), ("dyb", P), ("w_red_t_packed", P), ("x_prev", P),
+                ("mean", P), ("rstd", P), ("gamma", P), ("dx_prev", P), ("param_partials", P), ("dx_bf16", P),
+                ("cast_rowscale", P), ("cast_rows_per_sample", I), ("B", I), ("H", I), ("W", I), ("Cp", I)]
+
+
+class UnmergeSkipDesc(ctypes.Structure):   # tulip_unmerge_skip_desc
+    _fields_ = [("x_bf16", P), ("w_expand_packed", P), ("b_expand", P), ("cat", P), ("w_skip_packed", P), ("b_skip", P),
+                ("out", P), ("B", I), ("H", I), ("W", I), ("C", I)]
+
+
+class SkipUnmergeBwdDesc(ctypes.Structure):    # tulip_skip_unmerge_bwd_desc
+    _fields_ = [("dy_skip", P), ("w_skip_t_packed", P), ("dz", P), ("w_expand_t_packed", P), ("dx", P), ("dx_bf16", P),
+                ("cast_rowscale", P), ("cast_rows_per_sample", I), ("B", I), ("H", I), ("W", I), ("C", I)]
+
+
 REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 64
 GEMM_NO_TOUCH, GEMM_CHECKED, GEMM_NO_MID, GEMM_MID, WGRAD_SMALL_TILES, BLOCK_NO_WARM = 0x100, 0x200, 0x400, 0x800, 0x100, 8     # per-call flag bits (tulip_hip.h)
-ABI_VERSION = 5      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
+ABI_VERSION = 6      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
 SIGNATURES = {
@@ -138,6 +159,14 @@ SIGNATURES = {
     "tulip_range_to_xyz_durlar": [P, P, P, P, F, F, D, I, I, P, P],
     "tulip_voxel_metrics": [P, L, P, L, I, D, P, P, L, P, P, P],
     "tulip_chamfer_sq": [P, L, P, L, I, P, P, P, P, P],
+    "tulip_merge_fwd_supported": [I, I, I, I],
+    "tulip_merge_fwd": [P, P],
+    "tulip_merge_bwd_supported": [I, I, I, I],
+    "tulip_merge_bwd_partial_rows": [I, I, I, I],
+    "tulip_merge_bwd": [P, P],
+    "tulip_unmerge_skip_supported": [I, I, I, I],
+    "tulip_unmerge_skip_fwd": [P, P],
+    "tulip_skip_unmerge_bwd": [P, P],
     "tulip_stamp_realtime": [P, P],
     "tulip_abi_version": [],
     "tulip_build_arch": [],

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "tail.hip", "prep.hip", "evalpost.hip", "swin96.hip", "expand.hip", "swinw.hip", "swind.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "tail.hip", "prep.hip", "evalpost.hip", "swin96.hip", "expand.hip", "swinw.hip", "swind.hip", "glue.hip"]
 LIB = os.path.join(PKG, "libtulip_hip.so")
 ARCH = "gfx950"
 

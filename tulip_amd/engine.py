@@ -205,23 +205,33 @@ class FlatParams:
         stream, csrc/swinw.hip), grouped by block width; refresh_transposes() rewrites the copies of the widths some plan
         actually runs fused (`pk_active`) from the shadow."""
         self.pk_offset: Dict[str, int] = {}
+        self.pk_width: Dict[str, int] = {}
         off = 0
-        for names in names_by_width.values():
+        for width, names in names_by_width.items():
             for n in names:
                 self.pk_offset[n] = off
+                self.pk_width[n] = width
                 off = _ceil(off + self.numel[n], ALIGN)
         self.packed = torch.zeros(max(off, ALIGN), dtype=torch.bfloat16, device=self.device)
         self.packed_t = torch.zeros(max(off, ALIGN) if with_transposes else ALIGN, dtype=torch.bfloat16, device=self.device)
         self._pk_entries, self._pk_joined = {}, {}
+        # names whose copies are rewritten AFTER the end-of-step AdamW launch instead of with the others (Trainer pack_at_end: the
+        # weights that launch steps -- the skip Linears -- are not current any earlier); refresh_transposes(late=...)
+        self.pk_late = frozenset()
+
+        def part_of(width, n):
+            # part 0: the encoder's blocks and PatchMerging reductions (read first in a forward), part 1: the decoder's, part 2: the
+            # deep stages' (C >= 768: 14 / 57 MB of weights per block, first read three stages into the forward), see refresh_transposes
+            if width >= 768:
+                return 2
+            return int(n.startswith(("layers_up.", "skip_connection_layers.", "first_patch_expanding.")))
         for width, names in names_by_width.items():
-            # part 0: the encoder's blocks (read first in a forward), part 1: the decoder's ("layers_up."), part 2: the deep stages'
-            # (C >= 768: 14 / 57 MB of weights per block, first read three stages into the forward), see refresh_transposes
             for part in (0, 1, 2):
-                sel = [n for n in names if (2 if width >= 768 else int(n.startswith("layers_up."))) == part]
-                ent = [(self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0)
+                sel = [n for n in names if part_of(width, n) == part]
+                ent = [(n, (self.p16(n), self.packed.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 0))
                        for n in sel]
                 if with_transposes:
-                    ent += [(self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1)
+                    ent += [(n, (self.p16(n), self.packed_t.data_ptr() + 2 * self.pk_offset[n], self.shape[n][0], self.shape[n][1], 1))
                             for n in sel]
                 self._pk_entries[(width, part)] = ent
         self.pk_active = set()
@@ -232,22 +242,27 @@ class FlatParams:
     def p16t(self, name: str) -> int:
         return self.packed_t.data_ptr() + 2 * self.pk_offset[name]
 
-    def refresh_transposes(self, part: Optional[int] = None, also: Tuple[int, ...] = ()):
+    def refresh_transposes(self, part: Optional[int] = None, also: Tuple[int, ...] = (), late: Optional[bool] = None):
         """One launch for the copies of every active width (up to TULIP_PACK_MAX matrices per launch).  part = 0 / 1 / 2: only the
         encoder's / the decoder's wide blocks / the deep stages' blocks (the Trainer's forward rewrites the pieces at different
-        points, _issue_pack)."""
+        points, _issue_pack).  late: None = every name, False = all but `pk_late`, True = only `pk_late`."""
         widths = tuple(sorted(getattr(self, "pk_active", ())))
         if not widths:
             return
-        key = (widths, part, also)
+        key = (widths, part, also, late, self.pk_late if late is not None else None)
         if key not in self._pk_joined:
             parts = (0, 1, 2) if part is None else (part,) + tuple(also)
-            self._pk_joined[key] = ops.pack_items([e for width in widths for q in parts for e in self._pk_entries[(width, q)]])
+            self._pk_joined[key] = ops.pack_items([e for width in widths for q in parts for n, e in self._pk_entries[(width, q)]
+                                                   if late is None or (n in self.pk_late) == late])
         items, n = self._pk_joined[key]
         if n:
             ops.pack_bf16_multi(items, n)
-        if part is None or part == 1:
+        if (part is None or part == 1) and late is not False:
             self.pack_dirty = False
+
+    def packed_names(self) -> List[str]:
+        """names whose fragment-major copies are being maintained (an active width)"""
+        return [n for n, w in self.pk_width.items() if w in self.pk_active]
 
 
 class Plan:
@@ -451,12 +466,24 @@ class TulipEngine:
                 if self._fusable_wide(sp) or self._fusable_deep(sp):
                     by_width.setdefault(sp.C, []).extend(sp.prefix + suffix for suffix in (
                         ".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"))
-        self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd or self.fuse_deep)
+        if self.fuse_glue and self.model.patch_unmerging:
+            # the stage boundaries as one launch each (csrc/glue.hip) stream fragment-major copies too: the PatchMerging reductions,
+            # the PatchUnmerging expand convs and the skip Linears, under the pseudo-width 0
+            m, nl = self.model, self.model.num_layers
+            glue = [f"layers.{s}.downsample.reduction.weight" for s in range(nl - 1)]
+            glue += [f"skip_connection_layers.{i}.weight" for i in range(nl - 1)]
+            glue += [f"layers_up.{i}.upsample.expand.weight" for i in range(nl - 2)]
+            if nl > 1:
+                glue.append("first_patch_expanding.expand.weight")
+            ok = lambda n: (self.params.shape[n][0] % 16 == 0 and self.params.shape[n][1] % 32 == 0 and self.params.shape[n][1] % 16 == 0
+                            and self.params.shape[n][0] % 32 == 0)
+            by_width[0] = [n for n in glue if n in self.params.offset and ok(n)]
+        self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd or self.fuse_deep or bool(by_width.get(0)))
         # the wide widths (a few MB of copies) keep their fragment-major copies fresh from the start; the DEEP widths (57 MB read +
         # 114 MB written per refresh for tulip_base) only once a plan runs them fused (plan(): a launch with 32-64 windows) -- at
         # batch 64 or under the N > 1 step nothing streams those copies.  A Trainer's captured step bakes in the
         # pack launch of the widths active at capture time: a later activation bumps params.pack_epoch and the Trainer re-captures
-        self.params.pk_active = {w for w in by_width if w < 768}
+        self.params.pk_active = {w for w in by_width if w < 768 and by_width[w]}
         rel = self.model.layers[0].blocks[0].attn.relative_position_index
         self._rel32 = rel.to(device=device, dtype=torch.int32).contiguous()
         rates = torch.ones(max(1, self.n_drop_slots), 1)
@@ -750,11 +777,12 @@ class TulipEngine:
                     self.params.refresh_transposes(part, pk[3])
                 pk[1] = True
 
-    def _join_pack(self, prefix: Optional[str] = None):
-        """The chain waits for the halves a block with this prefix reads (None: for everything forked so far)."""
+    def _join_pack(self, prefix: Optional[str] = None, part: Optional[int] = None):
+        """The chain waits for the halves a block with this prefix reads (None: for everything forked so far; part: that piece)."""
         if not self._packs:
             return
-        mine = None if prefix is None else (2 if self._deep_prefix(prefix) else int(prefix.startswith("layers_up.")))
+        mine = part if part is not None else (
+            None if prefix is None else (2 if self._deep_prefix(prefix) else int(prefix.startswith("layers_up."))))
         need = [q for q in self._packs if mine is None or q is None or q == mine or mine in self._packs[q][3]]
         # (a piece this block does not read is NOT enqueued from here: it waits for _stage_fwd's _issue_pack behind the block's
         # first kernel -- enqueued in front of it, the piece becomes the first successor of the chain's last node and the graph
@@ -808,6 +836,31 @@ class TulipEngine:
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
                  bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
 
+    # round 6: the stage boundaries as one launch each (csrc/glue.hip).  TULIP_FUSE_GLUE=0: the LayerNorm / GEMM launches
+    fuse_glue = knobs.on("TULIP_FUSE_GLUE", True)
+
+    # Where the one-launch forms win (tools/bench_glue.py, profiles/r6_bench_glue_*.txt): every workgroup streams the boundary's whole
+    # weight set through its CU, so with many row blocks the GEMM launches' tiles (weights shared by a whole tile column) take over.
+    # Rows of the launch up to which the fused FORWARD forms run, by input width; the backward forms won at every size measured.
+    glue_forms = frozenset(("merge_fwd", "merge_bwd", "unmerge_fwd", "unmerge_bwd"))      # (tests / A-B: a subset)
+    glue_merge_fwd_max_rows = {96: 1 << 30, 192: 8192, 384: 2048}
+    glue_unmerge_fwd_max_rows = {192: 1 << 30, 384: 8192}
+    glue_unmerge_bwd_widths = (192, 384)
+
+    def _glue_merge_fwd(self, Cin: int, B: int, H: int, W: int) -> bool:
+        return (self.fuse_glue and "merge_fwd" in self.glue_forms and f"layers.0.downsample.reduction.weight" in getattr(self.params, "pk_offset", {})
+                and ops.merge_fwd_supported(Cin, B, H, W) and B * (H // 2) * (W // 2) <= self.glue_merge_fwd_max_rows.get(Cin, 0))
+
+    def _glue_merge_bwd(self, Cp: int, B: int, H: int, W: int) -> bool:
+        return (self.fuse_glue and "merge_bwd" in self.glue_forms and f"layers.0.downsample.reduction.weight" in getattr(self.params, "pk_offset", {})
+                and ops.merge_bwd_supported(Cp, B, H, W))
+
+    def _glue_unmerge(self, C: int, B: int, H: int, W: int, fwd: bool = False) -> bool:
+        """(B,H,W,C): the coarse stage whose PatchUnmerging + the finer level's skip Linear run as one launch each way"""
+        return (self.fuse_glue and ("unmerge_fwd" if fwd else "unmerge_bwd") in self.glue_forms and self.model.patch_unmerging
+                and "first_patch_expanding.expand.weight" in getattr(self.params, "pk_offset", {})
+                and ops.unmerge_skip_supported(C, B, H, W) and (fwd or C in self.glue_unmerge_bwd_widths) and (not fwd or B * H * W <= self.glue_unmerge_fwd_max_rows.get(C, 0)))
+
     fuse_tail_fwd = True      # norm_up + head + loss partials in one launch
     _loss_final = None
 
@@ -860,27 +913,44 @@ class TulipEngine:
                 Hs, Ws, Cs = H0 >> s, W0 >> s, E << s
                 rows = B * (Hs // 2) * (Ws // 2)
                 pre = f"layers.{s}.downsample"
+                save16 = (P[f"dec{s + 1}.cat"].data_ptr() + 2 * (2 * Cs)) if s + 1 < nl - 1 else None
+                if self._glue_merge_fwd(Cs, B, Hs, Ws):
+                    # gather + LayerNorm + reduction GEMM in ONE launch (csrc/glue.hip)
+                    self._join_pack(part=0)
+                    ops.merge_fwd(x=x, gamma=W_.p32(pre + ".norm.weight"), beta=W_.p32(pre + ".norm.bias"),
+                                  w_packed=W_.p16p(pre + ".reduction.weight"), xm=P[f"enc{s}.xm"], mean=P[f"enc{s}.mmean"],
+                                  rstd=P[f"enc{s}.mrstd"], y=P[f"enc{s + 1}.in"], y_bf16=save16,
+                                  ld_bf16=4 * Cs if save16 is not None else 0, B=B, H=Hs, W=Ws, Cin=Cs, eps=self.eps)
+                    self._issue_pack()
+                    continue
                 ops.layernorm_fwd(x, W_.p32(pre + ".norm.weight"), W_.p32(pre + ".norm.bias"), P[f"enc{s}.xm"],
                                   P[f"enc{s}.mmean"], P[f"enc{s}.mrstd"], rows, 4 * Cs, self.eps, merge=True, B=B,
                                   H=Hs, W=Ws)
-                save16 = (P[f"dec{s + 1}.cat"].data_ptr() + 2 * (2 * Cs)) if s + 1 < nl - 1 else None
                 self._gemm(P[f"enc{s}.xm"], W_.p16(pre + ".reduction.weight"), rows, 2 * Cs, 4 * Cs, lda=4 * Cs,
                          ldb=4 * Cs, epi=EPI_F32, out=P[f"enc{s + 1}.in"], out2=save16,
                          ldo2=4 * Cs if save16 is not None else 0)
-        if nl > 1:
-            self._unmerge_fwd(P, "first_patch_expanding", nl - 1)
         for i in range(nl - 1):
             s = nl - i - 2
             Cs = E << s
             Ms = B * (H0 >> s) * (W0 >> s)
             pre = f"skip_connection_layers.{i}"
-            # dec{s}.cat = cat[unmerged stream, x_save[s]] (tulip.py:715) was filled by its two producers
-            self._gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
-                     bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"])
+            up = "first_patch_expanding" if i == 0 else f"layers_up.{i - 1}.upsample"
+            if self._glue_unmerge(2 * Cs, B, H0 >> (s + 1), W0 >> (s + 1), fwd=True):
+                # PatchUnmerging of level s+1 -> skip Linear of level s in ONE launch (csrc/glue.hip): the x_save half of dec{s}.cat
+                # was written by its producer, the unmerged half is written here (operand of the skip weight gradient)
+                self._join_pack(part=1)
+                ops.unmerge_skip_fwd(x_bf16=P[f"lvl{s + 1}.xb"], w_expand_packed=W_.p16p(up + ".expand.weight"),
+                                     b_expand=W_.p32(up + ".expand.bias"), cat=P[f"dec{s}.cat"],
+                                     w_skip_packed=W_.p16p(pre + ".weight"), b_skip=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"],
+                                     B=B, H=H0 >> (s + 1), W=W0 >> (s + 1), C=2 * Cs)
+                self._issue_pack()
+            else:
+                self._unmerge_fwd(P, up, s + 1)
+                # dec{s}.cat = cat[unmerged stream, x_save[s]] (tulip.py:715) was filled by its two producers
+                self._gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
+                           bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"])
             x = self._stage_fwd(P, self.dec_blocks[i], P[f"dec{s}.in"],
                                 out_bf16=P[f"lvl{s}.xb"] if i < nl - 2 else None)
-            if i < nl - 2:
-                self._unmerge_fwd(P, f"layers_up.{i}.upsample", s)
         M0 = B * H0 * W0
         loss_done = False
         if m.pixel_shuffle and self.fuse_tail_fwd:
@@ -1085,6 +1155,7 @@ class TulipEngine:
             ops.reduce_rows_multi([r])
 
     _carry = ()          # scatter regions waiting for the next side launch
+    _glue_done = {}      # level -> arguments of the fused skip' + PatchUnmerging' launch that _unmerge_bwd issues (run_backward)
 
     def _flush_carry(self):
         """Launch the scatters still waiting (end of the backward / a DDP bucket point) on the side stream."""
@@ -1190,8 +1261,12 @@ class TulipEngine:
         """backward hook of the LAST completion group that holds a packed weight: the lowest encoder stage with a packed width"""
         t = getattr(self, "_pack_mark_tag_", None)
         if t is None:
-            ss = [s for s, blks in enumerate(self.enc_blocks) if any(sp.C in self.params.pk_active for sp in blks)]
-            t = self._pack_mark_tag_ = f"enc{min(ss)}" if ss else ""
+            W_ = self.params
+            last = -1
+            for n in W_.packed_names():
+                if n not in W_.pk_late:
+                    last = max(last, next(k for k, (_, end) in enumerate(W_.groups) if W_.offset[n] < end))
+            t = self._pack_mark_tag_ = W_.groups[last][0] if last >= 0 else ""
         return t
 
     def _mark_side(self):
@@ -1464,6 +1539,12 @@ class TulipEngine:
             self._fold(part, 3 * Cn, G(prefix + ".norm.weight"), Cn, R)
             self._fold(part + 4 * Cn, 3 * Cn, G(prefix + ".norm.bias"), Cn, R)
         self._wgrad(dz, 2 * C, P[f"lvl{s}.xb"], C, 2 * C, C, M, G(prefix + ".expand.weight"), gbias)
+        if s in self._glue_done:
+            # the skip Linear's data gradient (unmerged half) and this data gradient in ONE launch (csrc/glue.hip), issued HERE --
+            # behind the decoder stage's hook, where the expand data-gradient GEMM used to be
+            ops.skip_unmerge_bwd(**self._glue_done.pop(s))
+            self._release_deferred()
+            return
         self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
                  out=dx_out, ldo=C, out2=cb, ldo2=C if cb is not None else 0, rowscale=cs, rows_per_sample=ct)
         self._release_deferred()
@@ -1487,7 +1568,8 @@ class TulipEngine:
         return bool(self.group_wgrad and self.overlap_wgrad)
 
     def run_backward(self, P: Plan, gflat: torch.Tensor, gscale_dev=None, gscale: float = 1.0, bucket_hook=None,
-                     join_tags=None, overwrite: bool = False, apply_adamw: bool = False, pack_at_end: bool = False):
+                     join_tags=None, overwrite: bool = False, apply_adamw: bool = False, pack_at_end: bool = False,
+                     bucket_on_side: bool = False):
         """Parameter gradients of P.losses[0] accumulated (+=) into the flat fp32 buffer `gflat`
         (same layout as the parameters).  bucket_hook(name) is called after the last gradient of
         each parameter group has been *launched* (DDP overlap)."""
@@ -1496,6 +1578,7 @@ class TulipEngine:
         H0, W0 = self.grid
         self._pending, self._lagged_hook, self._deferred, self._carry = [], None, None, ()   # nothing survives an aborted call
         self._detached = None
+        self._glue_done = {}
         self._pack_ev = None
         self.grad_overwrite = bool(overwrite)
         self.pack_at_end = bool(pack_at_end)
@@ -1519,6 +1602,18 @@ class TulipEngine:
                 fn, self._lagged_hook = self._lagged_hook, None
                 fn()
             bucket = join_tags is not None and tag in join_tags
+            if bucket and bucket_on_side and tag != "embed" and self.overlap_wgrad:
+                # round 6 (Trainer.graph_collectives: the whole N > 1 step is ONE captured graph): the bucket's hook -- its all-reduce --
+                # is issued ON THE SIDE STREAM behind the bucket's last side group (the closure runs last in the group's flush), so
+                # the collective becomes a branch of the graph off the side queue and the chain never waits for it: no cut, no join
+                def fire(tag=tag):
+                    if self._carry:          # the scatter regions this group left "for the next side launch" belong to this bucket
+                        carry, self._carry = list(self._carry), ()
+                        ops.reduce_rows_multi(carry, adam=self._adam_arg())
+                    user_hook(tag)
+                self._pending.append(("f", fire))
+                self._flush_wgrads(mark=self.pack_at_end and self.adam_apply and tag == self._pack_mark_tag)
+                return
             if bucket and self.detach_buckets and tag != "embed" and self.overlap_wgrad and self._pending:
                 # The bucket's LAST side group is not forked inside this capture at all: the caller (Trainer._capture) ends the
                 # chain's graph segment here, captures the group as a graph of its own (issue_detached) that is replayed on
@@ -1620,7 +1715,17 @@ class TulipEngine:
             self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
             # grad w.r.t. the first concat half (the unmerged stream), un-shuffled to the coarser level's layout in bf16 by
             # the epilogue: it is the operand of that level's PatchUnmerging backward; the x_save half is deferred
-            if m.patch_unmerging:
+            if self._glue_unmerge(2 * Cs, B, H0 >> (s + 1), W0 >> (s + 1)):
+                # ... and on through the PatchUnmerging's data gradient in the same launch (csrc/glue.hip): lvl{s+1}.dz2 is still
+                # written (operand of the expand weight / bias gradient, queued by _unmerge_bwd below / at the next level)
+                up_blocks = self.dec_blocks[i - 1] if i > 0 else self.enc_blocks[nl - 1]
+                cb, cs, ct = self._mlp_cast(P, up_blocks[-1]) or (None, None, 1)
+                self._glue_done[s + 1] = dict(
+                    dy_skip=dys, w_skip_t_packed=W_.p16t(pre + ".weight"), dz=P[f"lvl{s + 1}.dz2"],
+                    w_expand_t_packed=W_.p16t(("first_patch_expanding" if i == 0 else f"layers_up.{i - 1}.upsample") + ".expand.weight"),
+                    dx=P[f"dec{s + 1}.dx"] if i > 0 else P[f"enc{nl - 1}.dx"], dx_bf16=cb, cast_rowscale=cs,
+                    cast_rows_per_sample=ct, B=B, H=H0 >> (s + 1), W=W0 >> (s + 1), C=2 * Cs)
+            elif m.patch_unmerging:
                 self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True,
                            epi=EPI_UNSHUF2_BF16, out=P[f"lvl{s + 1}.dz2"], ldo=4 * Cs, psH=H0 >> (s + 1), psW=W0 >> (s + 1))
             else:       # PatchExpanding: fine-token order; its LayerNorm backward does the un-rearrange (_unmerge_bwd)
@@ -1638,6 +1743,28 @@ class TulipEngine:
             bottom_to_merge = (s == nl - 1 and s > 0)
             self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G, have_dyb=(nl > 1),
                             next_cast=(P[f"enc{s}.dyb"], None, 1) if bottom_to_merge else None)
+            if s > 0 and self._glue_merge_bwd(E << (s - 1), B, H0 >> (s - 1), W0 >> (s - 1)):
+                # [x_save half of the skip Linear's input gradient ->] PatchMerging reduction data gradient -> LayerNorm backward with
+                # the 2x2 scatter, ONE launch (csrc/glue.hip) instead of three (two at the bottleneck)
+                Cp, Cs = E << (s - 1), E << s
+                Hp, Wp = H0 >> (s - 1), W0 >> (s - 1)
+                rows = B * (Hp // 2) * (Wp // 2)
+                pre = f"layers.{s - 1}.downsample"
+                has_skip = s < nl - 1
+                R = ops.merge_bwd_partial_rows(Cp, B, Hp, Wp)
+                part = P.scratch("lnp." + pre + ".glue", R * 8 * Cp)
+                cb, cs, ct = self._mlp_cast(P, self.enc_blocks[s - 1][-1]) or (None, None, 1)
+                ops.merge_bwd(dx_in=dx if has_skip else None, dy_skip=P[f"dec{s}.dyskip"] if has_skip else None,
+                              w_skip_t_packed=W_.p16t(f"skip_connection_layers.{nl - s - 2}.weight") if has_skip else None,
+                              dyb=P[f"enc{s}.dyb"], w_red_t_packed=W_.p16t(pre + ".reduction.weight"),
+                              x_prev=P[self.enc_blocks[s - 1][-1].prefix + ".out"], mean=P[f"enc{s - 1}.mmean"],
+                              rstd=P[f"enc{s - 1}.mrstd"], gamma=W_.p32(pre + ".norm.weight"), dx_prev=P[f"enc{s - 1}.dx"],
+                              param_partials=part, dx_bf16=cb, cast_rowscale=cs, cast_rows_per_sample=ct, B=B, H=Hp, W=Wp, Cp=Cp)
+                self._wgrad(P[f"enc{s}.dyb"], 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows, G(pre + ".reduction.weight"))
+                self._fold(part, 8 * Cp, G(pre + ".norm.weight"), 4 * Cp, R)
+                self._fold(part + 16 * Cp, 8 * Cp, G(pre + ".norm.bias"), 4 * Cp, R)
+                hook(f"enc{s}")
+                continue
             if s < nl - 1:
                 # deferred skip-connection gradient w.r.t. x_save[s] (second concat half, tulip.py:715)
                 Cs = E << s
@@ -1688,7 +1815,7 @@ class TulipEngine:
             # every wide / deep weight (all stepped by now: the marked group was the last that holds any) are rewritten HERE, on the
             # chain's queue, instead of beside the next forward (three forks and three joins there)
             torch.cuda.current_stream().wait_event(self._pack_ev)
-            W_.refresh_transposes()
+            W_.refresh_transposes(late=False if W_.pk_late else None)     # (the late names: behind the end-of-step AdamW, Trainer._adamw)
             self._pack_ev = None
         gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
         self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
@@ -1707,7 +1834,7 @@ class TulipEngine:
         # what the captured launch sequence depends on besides the caller's key: the fuse switches, the DropPath seed (a launch
         # argument) and the number of draw slots
         key = key + (self.fuse_wide, self.fuse_wide_bwd, self.fuse_block96, self.fuse_block96_bwd, self.split_wide, self.split_wide_bwd,
-                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd,
+                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd, self.fuse_glue,
                      int(self._drop_seed), int(self.n_drop_slots))
         ent = graphs.get(key)
         if not self.graph_module or ent is None:

@@ -514,3 +514,57 @@ def swin96_block_bwd(stamps=None, **kw):
         check(_lib.load().tulip_swin96_block_bwd_profiled(ctypes.byref(d), _p(stamps), _stream()), "tulip_swin96_block_bwd_profiled")
         return
     check(_lib.load().tulip_swin96_block_bwd(ctypes.byref(d), _stream()), "tulip_swin96_block_bwd")
+
+
+# ---- the stage boundaries as one launch each (csrc/glue.hip): keyword arguments are the descriptor's fields
+def _fill(cls, kw, ints):
+    d = cls()
+    for name, _t in cls._fields_:
+        v = kw.pop(name, None)
+        if name in ints:
+            setattr(d, name, 0 if v is None else v)
+        else:
+            setattr(d, name, _p(v))
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    return d
+
+
+def merge_fwd_supported(Cin, B, H, W) -> bool:
+    return bool(_lib.load().tulip_merge_fwd_supported(Cin, B, H, W))
+
+
+def merge_fwd(**kw):
+    """tulip_merge_fwd: PatchMerging.forward (2x2 gather + LayerNorm + reduction GEMM) in one launch."""
+    d = _fill(_lib.MergeFwdDesc, kw, ("ld_bf16", "B", "H", "W", "Cin", "eps"))
+    check(_lib.load().tulip_merge_fwd(ctypes.byref(d), _stream()), "tulip_merge_fwd")
+
+
+def merge_bwd_supported(Cp, B, H, W) -> bool:
+    return bool(_lib.load().tulip_merge_bwd_supported(Cp, B, H, W))
+
+
+def merge_bwd_partial_rows(Cp, B, H, W) -> int:
+    return _lib.load().tulip_merge_bwd_partial_rows(Cp, B, H, W)
+
+
+def merge_bwd(**kw):
+    """tulip_merge_bwd: [x_save half of the skip Linear's data gradient +] reduction data gradient + LayerNorm backward."""
+    d = _fill(_lib.MergeBwdDesc, kw, ("cast_rows_per_sample", "B", "H", "W", "Cp"))
+    check(_lib.load().tulip_merge_bwd(ctypes.byref(d), _stream()), "tulip_merge_bwd")
+
+
+def unmerge_skip_supported(C, B, H, W) -> bool:
+    return bool(_lib.load().tulip_unmerge_skip_supported(C, B, H, W))
+
+
+def unmerge_skip_fwd(**kw):
+    """tulip_unmerge_skip_fwd: PatchUnmerging.forward -> skip Linear(cat[...]) in one launch."""
+    d = _fill(_lib.UnmergeSkipDesc, kw, ("B", "H", "W", "C"))
+    check(_lib.load().tulip_unmerge_skip_fwd(ctypes.byref(d), _stream()), "tulip_unmerge_skip_fwd")
+
+
+def skip_unmerge_bwd(**kw):
+    """tulip_skip_unmerge_bwd: the skip Linear's data gradient (unmerged half) -> PatchUnmerging's data gradient."""
+    d = _fill(_lib.SkipUnmergeBwdDesc, kw, ("cast_rows_per_sample", "B", "H", "W", "C"))
+    check(_lib.load().tulip_skip_unmerge_bwd(ctypes.byref(d), _stream()), "tulip_skip_unmerge_bwd")

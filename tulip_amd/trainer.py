@@ -152,6 +152,15 @@ class Trainer:
         self._ws_det = (torch.empty(self.eng.WS_ELEMS + (1 << 20), dtype=torch.float32, device=device)
                         if self.detach_buckets else None)
         self._det_graphs, self._det_events = {}, {}
+        # round 6 (TULIP_GRAPH_COLLECTIVES=0: off): the N > 1 step as ONE captured graph -- every bucket's all-reduce is captured as a
+        # branch off the side queue behind the bucket's last weight-gradient group (TulipEngine.run_backward(bucket_on_side=True)),
+        # AdamW behind the last of them -- instead of graph segments cut at the bucket points with eager collectives in between (each
+        # cut costs the chain ~20 us on one GPU: tools/exp_segments.py).  RCCL only (gloo cannot be captured); a capture that raises
+        # falls back to the segmented form (self.step_form says which one runs).  Never run on more than one GPU.
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self.graph_collectives = bool(use_graph and self.segmented and self.exchange == "allreduce" and backend == "nccl"
+                                      and knobs.on("TULIP_GRAPH_COLLECTIVES", True))
+        self.step_form = "unset"
         self.process_group = process_group
         if self.world > 1:
             # DistributedDataParallel's constructor broadcasts rank 0's parameters and buffers (main_lidar_upsampling.py:277
@@ -179,7 +188,7 @@ class Trainer:
             self._hyper_events[k] = torch.cuda.Event()
         self._hyper_events[k].record()
 
-    def _fwd_bwd(self, hook, update: bool = True, apply_adamw: bool = False):
+    def _fwd_bwd(self, hook, update: bool = True, apply_adamw: bool = False, bucket_on_side: bool = False):
         eng, P = self.eng, self.P
         # the fused-AdamW plan points at THIS trainer's gradient / moment / mask buffers: a second Trainer on the same model
         # (another batch size, a rebuild) must not leave its own on the engine for this one's launches or captures
@@ -192,7 +201,8 @@ class Trainer:
         eng.run_forward(P, pack_on_side=self.pack_at_step_start, defer_loss_final=True)
         eng.run_backward(P, self.g, gscale=1.0 / self.accum_iter, bucket_hook=hook,
                          join_tags=set(self.bucketer.by_tag) if (self.segmented and update) else None,
-                         overwrite=self.grad_overwrite, apply_adamw=apply_adamw, pack_at_end=self._pack_at_end and apply_adamw)
+                         overwrite=self.grad_overwrite, apply_adamw=apply_adamw, pack_at_end=self._pack_at_end and apply_adamw,
+                         bucket_on_side=bucket_on_side)
 
     def _adamw_range(self, lo: int, hi: int):
         W = self.eng.params
@@ -220,7 +230,10 @@ class Trainer:
         if r is None or not self.bucket_adamw:
             return
         work, a, b = r
+        ev = torch.cuda.Event()
+        ev.record()                      # (the collective implies this order; a dry run and a capture need it said)
         with torch.cuda.stream(self._opt_stream):
+            self._opt_stream.wait_event(ev)
             work.wait()
             if self.gb is not None:
                 ops.cast_bf16_f32(self.gb.data_ptr() + 2 * a, self.g.data_ptr() + 4 * a, b - a)
@@ -283,7 +296,10 @@ class Trainer:
                              mask, zero_grad=not self.grad_overwrite)
         else:
             ops.adamw(W.flat, self.g, self.m, self.v, W.shadow, W.total, self.hyper, mask, zero_grad=not self.grad_overwrite)
-        if not self.pack_at_step_start and not self._pack_at_end:
+        if self._pack_at_end:
+            if W.pk_late:
+                W.refresh_transposes(late=True)
+        elif not self.pack_at_step_start:
             W.refresh_transposes()
 
     # ------------------------------------------------------------------ checkpoint (misc.save_model / load_model keep
@@ -374,9 +390,15 @@ class Trainer:
             self.eng.adam_fused, self.eng.adam_ctx = self._adam_fused, self._adam_ctx
             self.fused_adamw_params = count
             if self._want_pack_at_end and getattr(W, "pk_offset", None):
-                packed = [n for n in W.pk_offset if W.shape[n][0] in W.pk_active or W.shape[n][1] in W.pk_active]
-                if packed and all(bool((mask[W.offset[n] // 64:(W.offset[n] + W.numel[n] + 63) // 64] & 2).all()) for n in packed):
+                packed = W.packed_names()
+                stepped = lambda n: bool((mask[W.offset[n] // 64:(W.offset[n] + W.numel[n] + 63) // 64] & 2).all())
+                late = [n for n in packed if not stepped(n)]
+                # the copies of weights the END-of-step AdamW launch steps (the skip Linears: read again after their gradient is
+                # complete, so never stepped beside the backward) are rewritten by a small launch of their own behind that launch
+                if packed and all(n.startswith("skip_connection_layers.") for n in late):
                     self._pack_at_end, self.pack_at_step_start = True, False
+                    W.pk_late = frozenset(late)
+                    self.eng._pack_mark_tag_ = None
             left = torch.nonzero((mask[:(W.total + 63) // 64] & 2) == 0).flatten().to(torch.int32)
             if 0 < left.numel() * 64 <= W.total // 4:       # (a long list gains nothing over the scan)
                 self._adam_blocks = left.contiguous()
@@ -434,11 +456,39 @@ class Trainer:
                                       "exp_avg_sq": self.v[sl].view(W.shape[n]).clone()}
 
     # ------------------------------------------------------------------ graph capture
+    def _capture_one_graph(self):
+        """The N > 1 optimizer step as ONE graph: collectives captured as branches off the side queue (graph_collectives)."""
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(capture_error_mode="thread_local")
+            self.eng.detach_buckets = False
+            self._fwd_bwd(lambda tag: self._bucket_done(tag, cast=True), True, bucket_on_side=True)
+            self._finish_buckets()           # joins the collectives (and the per-bucket optimizer) / the end-of-step AdamW
+            g.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        return [(g, None)]
+
     def _capture(self, update: bool):
         """Capture one step as graph segments cut at the all-reduce points.  update=False is a
         gradient-accumulation micro-step: forward + backward only, no all-reduce, no AdamW.
         Capture mode is thread-local: HIP calls of other threads (the RCCL watchdog polling its events) must not
         invalidate the capture."""
+        if update and self.graph_collectives:
+            try:
+                segs = self._capture_one_graph()
+                self.step_form = "one_graph_captured_collectives"
+                return segs
+            except Exception as e:      # noqa: BLE001  (a backend / runtime that cannot capture the collective: today's segmented form)
+                sys.stderr.write(f"tulip_amd.Trainer: capturing the collectives failed ({type(e).__name__}: {e}); "
+                                 "falling back to graph segments with eager collectives\n")
+                self.graph_collectives = False
+                self.bucketer.pending.clear()
+                self.P.reset_exchange()
+                torch.cuda.synchronize()
+        if update:
+            self.step_form = "segments" if self.segmented else "one_graph"
         segs = []
         if update:
             self._det_graphs = {}
@@ -502,6 +552,14 @@ class Trainer:
     def load_batch(self, x: torch.Tensor, target: torch.Tensor):
         self.P.x_in.copy_(x.reshape(self.P.x_in.shape), non_blocking=True)
         self.P.target.copy_(target.reshape(self.P.target.shape), non_blocking=True)
+
+    def set_dry(self, dry: bool):
+        """Measurement switch (tools/exp_segments.py, bench.py's comm report): keep the step structure, skip the collectives.  The
+        one-graph form bakes the collectives into its capture, so the step is re-captured."""
+        if self.bucketer.dry != bool(dry):
+            self.bucketer.dry = bool(dry)
+            if self.graph_collectives:
+                self._segments = None
 
     def zero_grad(self):
         """optimizer.zero_grad() at the top of an epoch (engine_upsampling.py:61): drops the gradients of
@@ -592,7 +650,7 @@ class Trainer:
                             self._det_stream.wait_event(ev)
                             sg.replay()
                             self._bucket_done(tag)
-        if update and self.bucket_adamw:
+        if update and self.bucket_adamw and not self.graph_collectives:
             self._finish_buckets()
         self.eng.params.pack_dirty = self.eng.params.pack_dirty or mark_pack_dirty
         return self.P.losses
