@@ -96,7 +96,11 @@ FAMILIES = {   # kernel-name prefixes per family: shared with tools/instep_summa
     "gemm": ("gemm_kernel",),
     "swin96_fwd": ("swin96_fwd_kernel",), "swin96_bwd": ("swin96_bwd_kernel",),
     "swinw_fwd": ("swinw_fwd_kernel",), "swinw_bwd": ("swinw_bwd_kernel",),
-    "fold": ("reduce_rows_multi_kernel",), "adamw": ("adamw_kernel",)}
+    "fold": ("reduce_rows_multi_kernel",), "adamw": ("adamw_kernel",),
+    # round 6: what is left of the glue between the Swin blocks -- the fused stage boundaries (csrc/glue.hip), the LayerNorm
+    # launches and split-K epilogues of the boundaries / deep blocks that keep their launch sequences ("gemm" above holds their GEMMs)
+    "glue": ("merge_fwd_kernel", "merge_bwd_kernel", "unmerge_skip_fwd_kernel", "skip_unmerge_bwd_kernel"),
+    "ln": ("ln_fwd_kernel", "ln_bwd_kernel"), "splitk": ("splitk_epilogue_kernel",)}
 
 
 def _stamped(fname, family):

@@ -32,6 +32,10 @@ python tools/exp_chain.py > $O/exp_chain.txt 2>/dev/null
 python tools/wgrad_phases.py > $O/wgrad_phases.txt 2>/dev/null
 python tools/bench_wgrad.py > $O/wgrad_isolated.txt 2>/dev/null
 python tools/chain_gemms.py > $O/chain_gemms.txt 2>/dev/null
+python tools/bench_glue.py 8 2>/dev/null | grep -v amdgpu.ids > $O/bench_glue_b8.txt
+python tools/bench_glue.py 64 2>/dev/null | grep -v amdgpu.ids > $O/bench_glue_b64.txt
+python tools/exp_segments.py 2>&1 | grep -v "amdgpu.ids\|RCCL\|HIP ver\|ROCm\|Hostname\|Librccl\|socket.cpp\|UserWarning\|capture_end" > $O/exp_segments.txt
+python tools/det_glue.py 2>&1 | grep -v amdgpu.ids | cut -c1-200 > $O/det_glue.txt
 bash tools/other_configs.sh > $O/other_configs.txt 2>/dev/null
 python tools/exp_wgrad_contig.py 2>/dev/null | grep -v amdgpu.ids > $O/exp_wgrad_contig.txt
 python tools/cold_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/cold_probe.txt
