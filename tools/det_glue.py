@@ -23,8 +23,7 @@ def run(nsteps=4, use_graph=True, **attrs):
     torch.cuda.synchronize()
     return tr, tr.eng.params.flat.clone(), torch.stack(ls)
 ALL = ("merge_fwd", "merge_bwd", "unmerge_fwd", "unmerge_bwd")
-variants = [("all forms", dict()), ("unmerge_bwd only", dict(glue_forms=frozenset(("unmerge_bwd",)))), ("merge_bwd only", dict(glue_forms=frozenset(("merge_bwd",)))),
-            ("all forms (again)", dict()), ("no fused boundary", dict(glue_forms=frozenset()))]
+variants = [("all forms", dict()), ("no fused boundary", dict(glue_forms=frozenset()))]
 for name, kw in variants:
     env = kw.pop("_env", None)
     if env: os.environ[env[0]] = env[1]

@@ -842,6 +842,7 @@ class TulipEngine:
     # Where the one-launch forms win (tools/bench_glue.py, profiles/r6_bench_glue_*.txt): every workgroup streams the boundary's whole
     # weight set through its CU, so with many row blocks the GEMM launches' tiles (weights shared by a whole tile column) take over.
     # Rows of the launch up to which the fused FORWARD forms run, by input width; the backward forms won at every size measured.
+    embed_fold_on_chain = True
     glue_forms = frozenset(("merge_fwd", "merge_bwd", "unmerge_fwd", "unmerge_bwd"))      # (tests / A-B: a subset)
     glue_merge_fwd_max_rows = {96: 1 << 30, 192: 8192, 384: 2048}
     glue_unmerge_fwd_max_rows = {192: 1 << 30, 384: 8192}
@@ -1805,6 +1806,18 @@ class TulipEngine:
                             ep + rel("patch_embed.norm.weight"), ep + rel("patch_embed.norm.bias"), B, m.in_chans,
                             m.img_size[0], m.img_size[1], E, m.patch_size[0], m.patch_size[1], kw, m.circular_padding,
                             self.eps, partial_stride=P.embed_stride)
+        gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
+        embed_on_chain = self.embed_fold_on_chain and self.pack_at_end and self.adam_apply and self.overlap_wgrad
+        if embed_on_chain:
+            # round 6: the patch-embedding fold (+ its optimizer step) on the CHAIN's queue, in front of the weight-copy refresh: queued
+            # for the side stream it was a launch group of its own behind the backward's last weight-gradient group AND behind the
+            # refresh (its fork event sits behind the refresh's launches) -- ~20 us at the very end of the step with nothing beside it
+            kw = dict(overwrite=self.grad_overwrite)
+            if kw["overwrite"] and self.fuse_adamw_folds and self._in_gflat(gpe):
+                if self.adam_probe is not None:
+                    self.adam_probe[gpe] = max(P.embed_stride, self.adam_probe.get(gpe, 0))
+                kw["adamw"] = self.adam_apply and gpe in self.adam_fused
+            ops.reduce_rows_multi([ops.reduce_region(ep, P.embed_stride, gpe, P.embed_stride, nbe, **kw)], adam=self._adam_arg())
         if self.pack_at_end and self.adam_apply and self._pack_ev is None:
             # the marked group has not been enqueued (its fork is still deferred: the marked tag is this last stage, e.g. a model
             # whose stage 0 already has a packed width) or no hook carried the mark: enqueue what is deferred -- the chain's next
@@ -1817,8 +1830,8 @@ class TulipEngine:
             torch.cuda.current_stream().wait_event(self._pack_ev)
             W_.refresh_transposes(late=False if W_.pk_late else None)     # (the late names: behind the end-of-step AdamW, Trainer._adamw)
             self._pack_ev = None
-        gpe, nbe = G("patch_embed.proj.weight"), ops.patch_embed_bwd_blocks(B * H0 * W0)
-        self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
+        if not embed_on_chain:
+            self._fold(ep, P.embed_stride, gpe, P.embed_stride, nbe)
         hook("embed")
 
     # ------------------------------------------------------------------ autograd bridge
