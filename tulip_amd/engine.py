@@ -475,8 +475,15 @@ class TulipEngine:
             glue += [f"layers_up.{i}.upsample.expand.weight" for i in range(nl - 2)]
             if nl > 1:
                 glue.append("first_patch_expanding.expand.weight")
-            ok = lambda n: (self.params.shape[n][0] % 16 == 0 and self.params.shape[n][1] % 32 == 0 and self.params.shape[n][1] % 16 == 0
-                            and self.params.shape[n][0] % 32 == 0)
+            # ... of the boundaries some fused form exists for (csrc/glue.hip: widths 96 / 192 / 384; tulip_large's two deepest
+            # boundaries keep their GEMM launches and get no copies)
+            def ok(n):
+                r, c = self.params.shape[n][0], self.params.shape[n][1]
+                if n.endswith("reduction.weight"):      # [2 Cin][4 Cin]: merge_fwd Cin <= 384
+                    return c // 4 in (96, 192, 384)
+                if n.startswith("skip_connection_layers."):     # [Cs][2 Cs]: merge_bwd (Cs = 192, 384), unmerge (Cs = 96, 192)
+                    return r in (96, 192, 384)
+                return c in (192, 384)                  # expand [2C][C]
             by_width[0] = [n for n in glue if n in self.params.offset and ok(n)]
         self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd or self.fuse_deep or bool(by_width.get(0)))
         # the wide widths (a few MB of copies) keep their fragment-major copies fresh from the start; the DEEP widths (57 MB read +
@@ -848,18 +855,22 @@ class TulipEngine:
     glue_unmerge_fwd_max_rows = {192: 1 << 30, 384: 8192}
     glue_unmerge_bwd_widths = (192, 384)
 
+    def _has_copies(self, *names) -> bool:
+        pk = getattr(self.params, "pk_offset", {})
+        return all(n in pk for n in names)
+
     def _glue_merge_fwd(self, Cin: int, B: int, H: int, W: int) -> bool:
-        return (self.fuse_glue and "merge_fwd" in self.glue_forms and f"layers.0.downsample.reduction.weight" in getattr(self.params, "pk_offset", {})
+        return (self.fuse_glue and "merge_fwd" in self.glue_forms and 0 in self.params.pk_active
                 and ops.merge_fwd_supported(Cin, B, H, W) and B * (H // 2) * (W // 2) <= self.glue_merge_fwd_max_rows.get(Cin, 0))
 
     def _glue_merge_bwd(self, Cp: int, B: int, H: int, W: int) -> bool:
-        return (self.fuse_glue and "merge_bwd" in self.glue_forms and f"layers.0.downsample.reduction.weight" in getattr(self.params, "pk_offset", {})
+        return (self.fuse_glue and "merge_bwd" in self.glue_forms and 0 in self.params.pk_active
                 and ops.merge_bwd_supported(Cp, B, H, W))
 
     def _glue_unmerge(self, C: int, B: int, H: int, W: int, fwd: bool = False) -> bool:
         """(B,H,W,C): the coarse stage whose PatchUnmerging + the finer level's skip Linear run as one launch each way"""
         return (self.fuse_glue and ("unmerge_fwd" if fwd else "unmerge_bwd") in self.glue_forms and self.model.patch_unmerging
-                and "first_patch_expanding.expand.weight" in getattr(self.params, "pk_offset", {})
+                and 0 in self.params.pk_active
                 and ops.unmerge_skip_supported(C, B, H, W) and (fwd or C in self.glue_unmerge_bwd_widths) and (not fwd or B * H * W <= self.glue_unmerge_fwd_max_rows.get(C, 0)))
 
     fuse_tail_fwd = True      # norm_up + head + loss partials in one launch
@@ -915,7 +926,7 @@ class TulipEngine:
                 rows = B * (Hs // 2) * (Ws // 2)
                 pre = f"layers.{s}.downsample"
                 save16 = (P[f"dec{s + 1}.cat"].data_ptr() + 2 * (2 * Cs)) if s + 1 < nl - 1 else None
-                if self._glue_merge_fwd(Cs, B, Hs, Ws):
+                if self._glue_merge_fwd(Cs, B, Hs, Ws) and self._has_copies(pre + ".reduction.weight"):
                     # gather + LayerNorm + reduction GEMM in ONE launch (csrc/glue.hip)
                     self._join_pack(part=0)
                     ops.merge_fwd(x=x, gamma=W_.p32(pre + ".norm.weight"), beta=W_.p32(pre + ".norm.bias"),
@@ -936,7 +947,7 @@ class TulipEngine:
             Ms = B * (H0 >> s) * (W0 >> s)
             pre = f"skip_connection_layers.{i}"
             up = "first_patch_expanding" if i == 0 else f"layers_up.{i - 1}.upsample"
-            if self._glue_unmerge(2 * Cs, B, H0 >> (s + 1), W0 >> (s + 1), fwd=True):
+            if self._glue_unmerge(2 * Cs, B, H0 >> (s + 1), W0 >> (s + 1), fwd=True) and self._has_copies(up + ".expand.weight", pre + ".weight"):
                 # PatchUnmerging of level s+1 -> skip Linear of level s in ONE launch (csrc/glue.hip): the x_save half of dec{s}.cat
                 # was written by its producer, the unmerged half is written here (operand of the skip weight gradient)
                 self._join_pack(part=1)
@@ -1716,7 +1727,8 @@ class TulipEngine:
             self._wgrad(dys, Cs, P[f"dec{s}.cat"], 2 * Cs, Cs, 2 * Cs, Ms, G(pre + ".weight"), G(pre + ".bias"))
             # grad w.r.t. the first concat half (the unmerged stream), un-shuffled to the coarser level's layout in bf16 by
             # the epilogue: it is the operand of that level's PatchUnmerging backward; the x_save half is deferred
-            if self._glue_unmerge(2 * Cs, B, H0 >> (s + 1), W0 >> (s + 1)):
+            if self._glue_unmerge(2 * Cs, B, H0 >> (s + 1), W0 >> (s + 1)) and self._has_copies(
+                    pre + ".weight", ("first_patch_expanding" if i == 0 else f"layers_up.{i - 1}.upsample") + ".expand.weight"):
                 # ... and on through the PatchUnmerging's data gradient in the same launch (csrc/glue.hip): lvl{s+1}.dz2 is still
                 # written (operand of the expand weight / bias gradient, queued by _unmerge_bwd below / at the next level)
                 up_blocks = self.dec_blocks[i - 1] if i > 0 else self.enc_blocks[nl - 1]
@@ -1744,7 +1756,8 @@ class TulipEngine:
             bottom_to_merge = (s == nl - 1 and s > 0)
             self._stage_bwd(P, self.enc_blocks[s], P[f"enc{s}.in"], dx, G, have_dyb=(nl > 1),
                             next_cast=(P[f"enc{s}.dyb"], None, 1) if bottom_to_merge else None)
-            if s > 0 and self._glue_merge_bwd(E << (s - 1), B, H0 >> (s - 1), W0 >> (s - 1)):
+            if s > 0 and self._glue_merge_bwd(E << (s - 1), B, H0 >> (s - 1), W0 >> (s - 1)) and self._has_copies(
+                    f"layers.{s - 1}.downsample.reduction.weight", *([f"skip_connection_layers.{nl - s - 2}.weight"] if s < nl - 1 else [])):
                 # [x_save half of the skip Linear's input gradient ->] PatchMerging reduction data gradient -> LayerNorm backward with
                 # the 2x2 scatter, ONE launch (csrc/glue.hip) instead of three (two at the bottleneck)
                 Cp, Cs = E << (s - 1), E << s
