@@ -22,6 +22,32 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    base = len(sys.argv) > 3 and sys.argv[3] == "base"
+    if base:
+        # the bench configuration (KITTI tulip_base, batch 8): the fused wide / deep blocks, the fused stage boundaries (csrc/glue.hip)
+        # and the optimizer step in the write-outs on the plain side; the one-graph N > 1 step with its collectives as branches on the other
+        cfg = O.tulip_base_config()
+        sd = O.key_seeded_state_dict(cfg, seed=3)
+        lo, hi = O.synthetic_batch(cfg, 8, seed=77)
+        res = {}
+        for name, kw in [("plain", dict()), ("captured", dict(force_segments=True)),
+                         ("captured_bucket_adamw", dict(force_segments=True, bucket_adamw=True))]:
+            torch.manual_seed(11)
+            m = build(cfg, sd, train=True)
+            os.environ["TULIP_GRAPH_COLLECTIVES"] = "1"
+            tr = Trainer(m, 8, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, **kw)
+            tr.load_batch(lo.cuda(), hi.cuda())
+            losses = [tr.step().clone() for _ in range(steps)]
+            torch.cuda.synchronize()
+            res[name] = {"flat": tr.eng.params.flat.cpu(), "m": tr.m.cpu(), "v": tr.v.cpu(), "losses": torch.stack(losses).cpu(),
+                         "form": tr.step_form, "buckets": len(tr.bucketer.buckets), "glue": bool(tr.eng.fuse_glue and 0 in tr.eng.params.pk_active)}
+        from tests.conftest import describe_flat_diff
+        for name in ("captured", "captured_bucket_adamw"):
+            res[name]["diff"] = describe_flat_diff(tr.eng, res[name]["flat"], res["plain"]["flat"])
+        res["backend"] = dist.get_backend()
+        torch.save(res, out_path)
+        dist.destroy_process_group()
+        return
     cfg = O.tiny_config()                                   # DropPath on: the counter-based draws replay identically
     sd = O.key_seeded_state_dict(cfg, seed=3)
     lo, hi = O.synthetic_batch(cfg, 4, seed=77)

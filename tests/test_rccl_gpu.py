@@ -56,3 +56,24 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
         ref = got["eager_plain"] if name.startswith("eager") else plain
         assert torch.equal(g["losses"], ref["losses"]), name
         assert torch.equal(g["flat"], ref["flat"]), (name, g["diff"])
+
+
+def test_one_graph_step_with_captured_collectives_at_the_bench_configuration(tmp_path):
+    """Round 6: KITTI tulip_base, batch 8 -- fused wide / deep blocks and fused stage boundaries on the chain, every bucket's RCCL
+    all-reduce a branch of the ONE captured graph behind the bucket's last side group (Trainer.graph_collectives), AdamW behind
+    the last of them (or per bucket on the optimizer stream).  One rank: the all-reduces are the identity, so parameters, both
+    moments and the losses equal the plain one-GPU step's -- whose optimizer step is taken in the weight-gradient write-outs --
+    bit for bit (both paths run adamw_step4 on the same sums)."""
+    out = tmp_path / "ws1_base.pt"
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_ws1_worker.py"), str(out), "3", "base"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    assert got["backend"] == "nccl" and got["plain"]["form"] == "one_graph" and got["plain"]["glue"]
+    for name in ("captured", "captured_bucket_adamw"):
+        g = got[name]
+        assert g["form"] == "one_graph_captured_collectives" and g["buckets"] >= 3 and g["glue"], (name, g["form"], g["buckets"])
+        assert torch.equal(g["losses"], got["plain"]["losses"]), name
+        assert torch.equal(g["flat"], got["plain"]["flat"]), (name, g["diff"])
+        assert torch.equal(g["m"], got["plain"]["m"]) and torch.equal(g["v"], got["plain"]["v"]), name
