@@ -444,7 +444,10 @@ def spawn_ranks(n: int, argv) -> int:
     # A failed attempt is repeated with the next more conservative step structure; every repeat carries the history of the
     # failures in TULIP_BENCH_ATTEMPTS, and the JSON line says so ("graph_path_failed", "attempts") -- a number measured on
     # a fallback is never mistaken for the captured, detached-bucket path.
-    ladder = [("detach_buckets_off", {"TULIP_DETACH_BUCKETS": "0"}, []), ("no_graph", {}, ["--no-graph"])]
+    # rung 0 (default): ONE captured graph with the collectives as its nodes (round 6); rung 1: graph segments with eager collectives
+    # between the replays and the detached bucket graphs (the round-5 default); rung 2: the same without the detached graphs; rung 3: eager
+    ladder = [("graph_collectives_off", {"TULIP_GRAPH_COLLECTIVES": "0"}, []),
+              ("detach_buckets_off", {"TULIP_GRAPH_COLLECTIVES": "0", "TULIP_DETACH_BUCKETS": "0"}, []), ("no_graph", {}, ["--no-graph"])]
     history, current = [], "default"
     for tag, extra_env, extra_argv in ladder:
         if rc == 0 or "--no-graph" in argv or os.environ.get("TULIP_BENCH_NO_RETRY", "0") == "1":
