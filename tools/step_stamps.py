@@ -53,7 +53,8 @@ lo, hi = bench.synthetic(a, 0, dev); tr.load_batch(lo, hi)
 for _ in range(20): tr.step()
 torch.cuda.synchronize()
 v = buf.cpu().tolist()
-ev = sorted(((v[i], tag, k) for (tag, k), i in slots.items() if v[i]), key=lambda e: e[0])
+# (slots the LAST launch sequence -- the captured one -- no longer stamps keep what an earlier eager pass wrote: dropped)
+ev = sorted(((v[i], tag, k) for (tag, k), i in slots.items() if v[i] and k < seen.get(tag, 0)), key=lambda e: e[0])
 t0 = ev[0][0]
 print(f"{len(ev)} stamps; 10-ns ticks since the first one; every stamp is a 1-thread launch of its own (~3-5 us each)")
 for t, tag, k in ev:
