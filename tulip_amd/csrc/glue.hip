@@ -115,6 +115,7 @@ struct MergeFwdArgs {
     const float* x; const float* gamma; const float* beta; const bf16_t* wp;
     bf16_t* xm; float* mean; float* rstd; float* y; bf16_t* y16; int ld16;
     int B, H, W, rows; float eps;
+    int xcd_rows;
 };
 
 // CIN input channels; K = 4 CIN, N = 2 CIN.  Workgroup: BM merged rows x NWG = (4 / KSPLIT) NT 16 output columns (column slice
@@ -131,14 +132,32 @@ __global__ __launch_bounds__(256) void merge_fwd_kernel(const MergeFwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char stg[BM * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char sink[1024];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
-    const int slice = blockIdx.x % NSL, row0 = (blockIdx.x / NSL) * BM;
+    // workgroup -> (row block, column slice).  Row blocks are XCD-affine (XCD = blockIdx % 8 holds row blocks x, x + 8, ...; all their
+    // slices follow one another on it): the rows are fetched into ONE L2 and every XCD streams the whole weight matrix -- with the slices
+    // of a row block spread over the XCDs instead, each slice's XCD fetched the rows again (16 x 3 MB at the deepest level against
+    // 8 x 2.4 MB of weights this way).  Needs the row-block count to be a multiple of 8 (the launcher falls back to slice-minor otherwise).
+    int slice, rb;
+    if (a.xcd_rows) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, rpx = (a.rows / BM) >> 3;     // row blocks per XCD
+        slice = j / rpx;
+        rb = (j - slice * rpx) * 8 + x;
+    } else {
+        slice = blockIdx.x % NSL;
+        rb = blockIdx.x / NSL;
+    }
+    const int row0 = rb * BM;
     const int wn = wid % NW, wk = wid / NW;
     WaveGemm<NT, G, KSW, BM> gm;
     gm.start(a.wp, (slice * NWG) / 16 + wn * NT, K, wk * KSW, lane);
     {
         int j, sh;
-        warm_geom(NSL, j, sh);
-        warm_region(a.wp + (size_t)slice * NWG * K, NWG * K * 2 / 1024, j, sh, wid, lane, sink);
+        if (a.xcd_rows) {
+            warm_geom(1, j, sh);
+            warm_region(a.wp, N * K * 2 / 1024, j, sh, wid, lane, sink);
+        } else {
+            warm_geom(NSL, j, sh);
+            warm_region(a.wp + (size_t)slice * NWG * K, NWG * K * 2 / 1024, j, sh, wid, lane, sink);
+        }
     }
     // ---- gather + LayerNorm: 16 lanes per row, 4 rows per wave and pass
     const float invK = 1.0f / (float)K;
@@ -537,12 +556,13 @@ extern "C" int tulip_merge_fwd(const tulip_merge_fwd_desc* d, hipStream_t stream
     if (!d->x || !d->gamma || !d->beta || !d->w_packed || !d->xm || !d->mean || !d->rstd || !d->y) return TULIP_ERR_ARG;
     if (d->y_bf16 && (d->ld_bf16 & 3)) return TULIP_ERR_ARG;
     MergeFwdArgs a{d->x, d->gamma, d->beta, (const bf16_t*)d->w_packed, (bf16_t*)d->xm, d->mean, d->rstd, d->y,
-                   (bf16_t*)d->y_bf16, d->ld_bf16, d->B, d->H, d->W, d->B * (d->H / 2) * (d->W / 2), d->eps};
+                   (bf16_t*)d->y_bf16, d->ld_bf16, d->B, d->H, d->W, d->B * (d->H / 2) * (d->W / 2), d->eps, 0};
     const int rows = a.rows;
     // (row block, column slices) per width: few rows -> small row blocks and narrow slices, so that the launch has >= 256 workgroups
     // and a workgroup streams ~150 KB of weights; many rows -> the widest slice (fewest redundant LayerNorms, least L2 -> CU traffic)
 #define MF(CIN, BM, NT, KSPLIT) do { \
         constexpr int NSL = (2 * CIN) / ((4 / KSPLIT) * NT * 16); \
+        a.xcd_rows = NSL > 1 && (rows / BM) % 8 == 0; \
         hipLaunchKernelGGL((merge_fwd_kernel<CIN, BM, NT, KSPLIT>), dim3((rows / BM) * NSL), dim3(256), 0, stream, a); } while (0)
     if (d->Cin == 96) MF(96, 32, 3, 1);
     else if (d->Cin == 192) { if (rows >= 8192) MF(192, 32, 3, 1); else MF(192, 16, 3, 2); }
