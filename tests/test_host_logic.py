@@ -185,3 +185,33 @@ def test_oracle_e4m3_rounding_known_answers():
     grid = torch.arange(-448, 449, dtype=torch.float32) / 7.0
     r = O._FP8Round.apply(grid)
     assert torch.equal(r.to(torch.bfloat16).float(), r)
+
+
+def test_weight_copies_of_the_fused_stage_boundaries_and_the_pack_mark():
+    """Round 6 (csrc/glue.hip): which boundary weights get fragment-major copies -- only those a fused form can stream (widths 96 /
+    192 / 384) --, in which refresh piece each sits, that the deep widths are NOT maintained until a plan streams them, and which
+    completion group carries the end-of-step refresh's mark once the skip Linears are rewritten late (TulipEngine.bind, CPU: no launch)."""
+    m = T.tulip_base(img_size=(16, 1024), target_img_size=(64, 1024), **KW)
+    eng = m.engine()
+    eng.bind(torch.device("cpu"))
+    W = eng.params
+    glue = sorted(n for n, w in W.pk_width.items() if w == 0)
+    assert glue == sorted([f"layers.{s}.downsample.reduction.weight" for s in range(3)] + [f"skip_connection_layers.{i}.weight" for i in range(3)]
+                          + ["layers_up.0.upsample.expand.weight", "layers_up.1.upsample.expand.weight"])
+    assert "first_patch_expanding.expand.weight" not in W.pk_width          # C = 768: the GEMM launches stay, no copy
+    assert W.pk_active == {0, 192, 384} and 768 in {w for w in W.pk_width.values()}
+    names = lambda part: {n for (w, q), ent in W._pk_entries.items() if q == part for n, _ in ent}
+    assert "layers.0.downsample.reduction.weight" in names(0) and "skip_connection_layers.0.weight" in names(1)
+    assert "layers_up.1.upsample.expand.weight" in names(1) and all(W.pk_width[n] == 768 for n in names(2))
+    assert eng._pack_mark_tag == "enc0"                  # the level-0 skip Linear sits in the last encoder group ...
+    W.pk_late = frozenset(n for n in W.packed_names() if n.startswith("skip_connection_layers."))
+    eng._pack_mark_tag_ = None
+    assert eng._pack_mark_tag == "enc1"                  # ... until the Trainer rewrites the skip Linears' copies behind its AdamW launch
+    # tulip_large: the two deepest boundaries (768 -> 1536, 1536 -> 3072 wide) get no copies
+    ml = T.tulip_large(img_size=(16, 2048), target_img_size=(64, 2048), **KW)
+    el = ml.engine()
+    el.bind(torch.device("cpu"))
+    gl = {n for n, w in el.params.pk_width.items() if w == 0}
+    assert "layers.3.downsample.reduction.weight" not in gl and "layers.2.downsample.reduction.weight" in gl
+    assert "skip_connection_layers.0.weight" not in gl and "skip_connection_layers.1.weight" in gl        # [768][1536] / [384][768]
+    assert {"layers_up.1.upsample.expand.weight", "layers_up.2.upsample.expand.weight"} <= gl and "layers_up.0.upsample.expand.weight" not in gl
