@@ -56,8 +56,10 @@ def merged(x):
     return torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)      # tulip.py:94-98
 
 
+# (B, H, W, Cin): KITTI grids at batch 2 / 8, the 16x2048 / 32x2048 grids of CARLA / DurLAR (W = 512 tokens at level 0), an odd batch
+# (sample / row arithmetic off the power-of-two path), and the row counts at which the launcher changes its (row block, slices) choice
 MERGE_CASES = [(2, 16, 256, 96), (8, 16, 256, 96), (2, 8, 128, 192), (8, 32, 512, 192), (2, 4, 64, 384), (8, 4, 64, 384),
-               (16, 8, 256, 384)]
+               (16, 8, 256, 384), (3, 16, 256, 96), (2, 32, 512, 96), (3, 8, 128, 192), (6, 4, 64, 384), (2, 8, 256, 384)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin", MERGE_CASES)
@@ -81,7 +83,7 @@ def test_merge_fwd(ops, B, H, W, Cin):
     ops.layernorm_fwd(x, gamma, beta, xm2, m2, r2, rows, K, 1e-6, merge=True, B=B, H=H, W=W)
     ops.gemm(xm2, w, rows, N, K, lda=K, ldb=K, epi=ops.EPI_F32, out=y2, out2=cat2.data_ptr() + 2 * N, ldo2=2 * N)
     torch.cuda.synchronize()
-    close(mean, m2, 1e-6, 1e-7, "mean"); close(rstd, r2, 1e-6, 1e-7, "rstd")
+    close(mean, m2, 1e-5, 2e-6, "mean"); close(rstd, r2, 1e-5, 1e-6, "rstd")        # (fp32 summation order: 16 lanes x K/64 chunks here)
     close(xm, xm2, 2 ** -7, 1e-6, "xm vs sequence", frac=1e-4)
     # the GEMM itself, from THIS launch's normalised rows (isolated 1-ulp flips of xm between the two forms move whole rows of y)
     close(y, xm.float() @ w.float().t(), 1e-4, 2e-5, "y vs fp32 matmul of its own xm")
@@ -96,7 +98,8 @@ def test_merge_fwd(ops, B, H, W, Cin):
 
 
 @pytest.mark.parametrize("B,H,W,Cp,skip", [(2, 16, 256, 96, True), (8, 16, 256, 96, True), (2, 8, 128, 192, True),
-                                            (8, 8, 128, 192, True), (2, 16, 256, 96, False), (4, 8, 128, 192, False)])
+                                            (8, 8, 128, 192, True), (2, 16, 256, 96, False), (4, 8, 128, 192, False),
+                                            (3, 16, 256, 96, True), (2, 32, 512, 96, True), (3, 16, 256, 192, True)])
 def test_merge_bwd(ops, B, H, W, Cp, skip):
     """(B,H,W,Cp): the finer stage.  skip: the x_save half of the skip Linear's input gradient is added in front."""
     assert ops.merge_bwd_supported(Cp, B, H, W)
@@ -161,7 +164,10 @@ def test_merge_bwd(ops, B, H, W, Cp, skip):
         assert r <= 4e-3, (nm, r)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 128, 192), (8, 8, 128, 192), (2, 4, 64, 384), (8, 4, 64, 384)])
+UNMERGE_CASES = [(2, 8, 128, 192), (8, 8, 128, 192), (2, 4, 64, 384), (8, 4, 64, 384), (3, 8, 128, 192), (2, 16, 256, 192), (3, 8, 128, 384)]
+
+
+@pytest.mark.parametrize("B,H,W,C", UNMERGE_CASES)
 def test_unmerge_skip_fwd(ops, B, H, W, C):
     """(B,H,W,C): the COARSE stage.  expand C -> 2C, PixelShuffle(2), cat with x_save, skip Linear C -> C/2."""
     assert ops.unmerge_skip_supported(C, B, H, W)
@@ -189,7 +195,7 @@ def test_unmerge_skip_fwd(ops, B, H, W, C):
     close(out, ref.reshape(4 * M, Cf), 2e-3, 2e-3, "out vs oracle")
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 128, 192), (8, 8, 128, 192), (2, 4, 64, 384), (8, 4, 64, 384)])
+@pytest.mark.parametrize("B,H,W,C", UNMERGE_CASES)
 def test_skip_unmerge_bwd(ops, B, H, W, C):
     Cf, M = C // 2, B * H * W
     dys = bf(rnd(4 * M, Cf, seed=1))
