@@ -468,6 +468,16 @@ int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream);
 /* diagnostic twins (tools/swin96_phases.py): stamps[(workgroup * 8 + wave) * 16 + k] = s_memtime (shader clock) at phase
  * boundary k of every wave; workgroups = tulip_swin96_bwd_partial_rows(B, H, W) */
 int tulip_swin96_block_fwd_profiled(const tulip_swin96_desc* d, uint64_t* stamps, hipStream_t stream);
+/* Two consecutive blocks of the stage (tulip.py:399-436: the un-shifted block d0, then the shifted block d1 on its output) in ONE
+ * launch: a workgroup runs its tile of d0, publishes the 49-KB output tile (write-through stores + one flag per tile), waits for
+ * the <= 4 tiles of d0 that its tile of d1 reads, and runs d1 -- no grid barrier; first-block tiles never wait.  d0->x_out must be
+ * d1->x_in; B (H/2) (W/64) <= the number of CUs (one workgroup per tile, all resident; TULIP_ERR_ARG beyond); both descriptors in the same form (inference, or training with TULIP_BLOCK_FC1_GRAD); same tensors and bits as the
+ * two launches.  sync: tulip_swin96_pair_sync_bytes(B, H, W) bytes, 16-byte aligned, ZERO before the first launch and owned by
+ * these launches from then on (epoch-stamped flags: nothing to clear between launches or graph replays; words 2 / 3 are a test
+ * hook that holds the tiles of one parity back, see csrc/swin96.hip). */
+int tulip_swin96_pair_sync_bytes(int B, int H, int W);
+int tulip_swin96_pair_fwd(const tulip_swin96_desc* d0, const tulip_swin96_desc* d1, void* sync, size_t sync_bytes,
+                          hipStream_t stream);
 
 /* Backward of the same block in ONE launch (replaces, for C = 96, the chain tulip_gemm_bf16(EPI_GELU_BWD) ->
  * tulip_gemm_bf16 -> tulip_layernorm_bwd -> tulip_gemm_bf16 -> tulip_window_attn_bwd -> tulip_gemm_bf16 ->

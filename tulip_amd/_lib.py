@@ -89,6 +89,8 @@ ABI_VERSION = 6      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes stru
 SIGNATURES = {
     "tulip_gemm_bf16": [P, I, I, P, I, I, I, I, I, I, P, P, I, P, I, P, I, P, I, I, I, I, I, P, L, P],
     "tulip_swin96_block_fwd": [P, P],
+    "tulip_swin96_pair_sync_bytes": [I, I, I],
+    "tulip_swin96_pair_fwd": [P, P, P, ctypes.c_size_t, P],
     "tulip_swin96_block_bwd": [P, P],
     "tulip_swin96_block_fwd_profiled": [P, P, P],
     "tulip_swin96_block_bwd_profiled": [P, P, P],

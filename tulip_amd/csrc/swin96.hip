@@ -147,16 +147,17 @@ struct StagedWeights {
 // SAVE = 3: as 2, but the fc1_pre buffer receives bf16(gelu'(h)) instead of h (TULIP_BLOCK_FC1_GRAD): the only thing the
 // backward does with h is that derivative (~12 vector instructions per element there, two more here where erf and the
 // Gaussian are at hand anyway).  PROF: the diagnostic twin with shader-clock stamps (tools/swin96_phases.py).
-template <int SAVE, bool PROF>
-__global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+// HAND (the two-block launch below), bits: 1 = the block output leaves with write-through (sc1) stores, 2 = the block input is read
+// with sc1 loads -- the lines another XCD's workgroup wrote in this same launch; 0 = plain (a launch of its own)
+template <int SAVE, bool PROF, int HAND, class ARGS>
+__device__ __forceinline__ void swin96_fwd_tile(ARGS& a, int blk, unsigned char* smem) {
+    typedef unsigned u32x4_h __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = lane & 15, gq = lane >> 4;
     unsigned char* ldsV = smem + OFF_V + wid * 1024;
     float* prm = (float*)(smem + OFF_P);
 
     // ---- which window, which token (cyclic shift + window partition are address arithmetic, tulip.py:289-297)
     const int nWx = a.W >> 3, nWy = a.H >> 1, gpr = nWx / NW;
-    int blk = blockIdx.x;
     const int b = blk / (nWy * gpr);
     blk -= b * nWy * gpr;
     const int wy = blk / gpr, wx = (blk - wy * gpr) * NW + wid;
@@ -171,8 +172,13 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     f32x4 xv[6];
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
-        const float4 u = *(const float4*)(a.xin + row * C + 16 * n + 4 * gq);
-        xv[n] = (f32x4){u.x, u.y, u.z, u.w};
+        if constexpr (HAND & 2) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xin), 0, 0x7FFFFFFF, 0x00020000);
+            xv[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(row * C + 16 * n + 4 * gq) * 4u, 0, 16));
+        } else {
+            const float4 u = *(const float4*)(a.xin + row * C + 16 * n + 4 * gq);
+            xv[n] = (f32x4){u.x, u.y, u.z, u.w};
+        }
     }
     // relative-position bias of this lane's (query t, keys 4gq..4gq+3), all heads (tulip.py:304-308)
     float rpb[3][4];
@@ -389,11 +395,87 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
     for (int n2 = 0; n2 < 6; ++n2) {
         const int c0 = 16 * n2 + 4 * gq;
         const float4 bb = *(const float4*)(prm + P_B2 + c0);
-        *(float4*)(a.xout + row * C + c0) =
-            make_float4(xv[n2][0] + s1v * (acc3[n2][0] + bb.x), xv[n2][1] + s1v * (acc3[n2][1] + bb.y),
-                        xv[n2][2] + s1v * (acc3[n2][2] + bb.z), xv[n2][3] + s1v * (acc3[n2][3] + bb.w));
+        const f32x4 y = {xv[n2][0] + s1v * (acc3[n2][0] + bb.x), xv[n2][1] + s1v * (acc3[n2][1] + bb.y),
+                         xv[n2][2] + s1v * (acc3[n2][2] + bb.z), xv[n2][3] + s1v * (acc3[n2][3] + bb.w)};
+        if constexpr (HAND & 1) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xout, 0, 0x7FFFFFFF, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_h, y), rsrc, (unsigned)(row * C + c0) * 4u, 0, 16);
+        } else {
+            *(float4*)(a.xout + row * C + c0) = make_float4(y[0], y[1], y[2], y[3]);
+        }
     }
     TULIP_STAMP(9);
+}
+
+template <int SAVE, bool PROF>
+__global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    swin96_fwd_tile<SAVE, PROF, 0>(a, blockIdx.x, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two blocks of a stage in ONE launch (tulip.py:399-436 runs them back to back: the un-shifted block, then the shifted one).
+// A tile of the second block reads its own rows plus those of at most three neighbouring tiles of the first: no grid barrier --
+// every workgroup publishes its first-block tile (sc1 stores, drained, then one flag per tile), polls the <= 4 flags of the tiles
+// its second-block tile reads, and goes on.  First-block tiles never wait, so the launch cannot deadlock whatever is resident.
+// sync: [0] epoch (a flag is "set" when it holds epoch + 1; the last workgroup to leave advances it: no clearing between graph
+// replays), [1] workgroups that left, [2] / [3] dev: tiles of parity [2] - 1 idle [3] sleep quanta before their first block
+// (forces the arrival order in the tests), [16 + 4 tile] flags.
+#ifndef TULIP_PAIR_HAND
+#define TULIP_PAIR_HAND 3              // dev (tools/bench_pair96.py): 0 = plain loads / stores, with TULIP_PAIR_NOSYNC=1 the bare cost of the form
+#endif
+#ifndef TULIP_PAIR_NOSYNC
+#define TULIP_PAIR_NOSYNC 0
+#endif
+struct Swin96Pair { Swin96Args a0, a1; unsigned* sync; int ntiles; };
+__device__ __forceinline__ int pair_source_tile(int H, int W, int dsh, int dsw, int tile, int corner) {
+    const int nWy = H >> 1, gpr = (W >> 3) / NW;
+    const int b = tile / (nWy * gpr);
+    const int r = tile - b * nWy * gpr, wy = r / gpr, g = r - wy * gpr;
+    int hh = 2 * wy + (corner & 1) + dsh, ww = 64 * g + 63 * (corner >> 1) + dsw;
+    hh = (hh % H + H) % H;
+    ww = (ww % W + W) % W;
+    return (b * nWy + (hh >> 1)) * gpr + (ww >> 6);
+}
+// One tile per workgroup (the launch is one round of the chip), straight-line: first block, publish, poll, second block.  The second
+// block's arguments are read through a pointer the compiler cannot see through until the first block is over -- hoisted to the top,
+// the two argument sets (2 x 70 scalar registers) spilled into vector lanes and came back through ~950 v_readlane (+5 us per block).
+typedef const __attribute__((address_space(4))) Swin96Args KSwin96Args;
+template <int SAVE>
+__global__ __launch_bounds__(NT) void swin96_pair_fwd_kernel(const Swin96Pair P) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const unsigned want = __hip_atomic_load(P.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned hold = __hip_atomic_load(P.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hold && (unsigned)(tile & 1) == hold - 1u) {
+        const unsigned n = __hip_atomic_load(P.sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    swin96_fwd_tile<SAVE, false, TULIP_PAIR_HAND & 1>(P.a0, tile, smem);
+    if (!TULIP_PAIR_NOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+    __syncthreads();
+    // (the kernel's arguments start at offset 0 of the kernarg segment; &P.a1 would make the compiler copy P to scratch)
+    KSwin96Args* a1 = (KSwin96Args*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Swin96Pair, a1));
+    unsigned* sync = P.sync;
+    asm volatile("" : "+s"(a1), "+s"(sync) :: "memory");
+    if (!TULIP_PAIR_NOSYNC) {
+        if (tid == 0) __hip_atomic_store(sync + 16 + 4 * tile, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 4) {
+            const unsigned* f = sync + 16 + 4 * pair_source_tile(a1->H, a1->W, a1->sh - P.a0.sh, a1->sw - P.a0.sw, tile, tid);
+            // (bounded: ~0.5 s of polling, then on with whatever is there -- a wrong result a test can see instead of a hung queue)
+            for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want; ++spin)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
+    swin96_fwd_tile<SAVE, false, TULIP_PAIR_HAND & 2>(*a1, tile, smem);
+    if (tid == 0) {
+        const unsigned left = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == gridDim.x - 1) {
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 
@@ -912,11 +994,12 @@ __global__ __launch_bounds__(NT) void swin96_bwd_kernel(const Swin96BwdArgs a) {
 
 }  // namespace
 
-static int swin96_fwd_impl(const tulip_swin96_desc* d, unsigned long long* prof, hipStream_t stream) {
+// descriptor -> kernel arguments; the form of the launch: -1 argument error, 0 inference, 1 lean (recomputing backward), 2 everything
+// saved, 3 everything with gelu'(h) in fc1_pre
+static int swin96_fwd_args(const tulip_swin96_desc* d, Swin96Args& a) {
     if (!d || d->B <= 0 || d->H <= 0 || (d->H & 1) || d->W <= 0 || (d->W & 63) || d->shift_h < 0 ||
         d->shift_h >= d->H || d->shift_w < 0 || d->shift_w >= d->W)
-        return TULIP_ERR_ARG;
-    Swin96Args a;
+        return -1;
     a.xin = d->x_in; a.x1 = d->x1; a.xout = d->x_out;
     a.xn1 = (bf16_t*)d->xn1; a.qkv = (bf16_t*)d->qkv; a.o = (bf16_t*)d->attn_out; a.xn2 = (bf16_t*)d->xn2;
     a.h = (bf16_t*)d->fc1_pre; a.g = (bf16_t*)d->fc1_act;
@@ -928,14 +1011,24 @@ static int swin96_fwd_impl(const tulip_swin96_desc* d, unsigned long long* prof,
     a.bias_table = d->bias_table; a.rel_index = d->rel_index; a.ds0 = d->drop_scale_attn; a.ds1 = d->drop_scale_mlp;
     a.B = d->B; a.H = d->H; a.W = d->W; a.sh = d->shift_h; a.sw = d->shift_w; a.masked = d->masked;
     a.eps = d->eps; a.scale = 0.17677669529663687f;        // head_dim^-0.5 = 32^-0.5 (tulip.py:220)
-    a.prof = prof;
-    const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
+    a.prof = nullptr;
     // every saved-activation pointer NULL: the inference form; qkv and fc1_pre alone NULL: the backward recomputes them
     const bool core = d->xn1 && d->attn_out && d->x1 && d->xn2 && d->fc1_act && d->mean1 && d->rstd1 && d->mean2 && d->rstd2;
     const bool any = d->xn1 || d->qkv || d->attn_out || d->x1 || d->xn2 || d->fc1_pre || d->fc1_act || d->mean1 || d->rstd1 ||
                      d->mean2 || d->rstd2;
-    if (any && !(core && (!d->qkv == !d->fc1_pre))) return TULIP_ERR_ARG;
-    const bool hgrad = (d->masked & TULIP_BLOCK_FC1_GRAD) != 0;
+    if (any && !(core && (!d->qkv == !d->fc1_pre))) return -1;
+    if (!any) return 0;
+    if (!d->qkv) return 1;
+    return (d->masked & TULIP_BLOCK_FC1_GRAD) ? 3 : 2;
+}
+
+static int swin96_fwd_impl(const tulip_swin96_desc* d, unsigned long long* prof, hipStream_t stream) {
+    Swin96Args a;
+    const int form = swin96_fwd_args(d, a);
+    if (form < 0) return TULIP_ERR_ARG;
+    a.prof = prof;
+    const int blocks = d->B * (d->H / 2) * (d->W / (8 * NW));
+    const bool any = form != 0, hgrad = form == 3;
     const dim3 g(blocks), b(NT);
 #if TULIP_DEV_VARIANTS
     if (prof) {                                         // diagnostic twin: the full training forms only
@@ -955,6 +1048,35 @@ static int swin96_fwd_impl(const tulip_swin96_desc* d, unsigned long long* prof,
 }
 
 extern "C" int tulip_swin96_block_fwd(const tulip_swin96_desc* d, hipStream_t stream) { return swin96_fwd_impl(d, nullptr, stream); }
+
+// two blocks, one launch (swin96_pair_fwd_kernel)
+extern "C" int tulip_swin96_pair_sync_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || (H & 1) || W <= 0 || (W & 63)) return 0;
+    return (16 + 4 * B * (H / 2) * (W / (8 * NW))) * (int)sizeof(unsigned);
+}
+extern "C" int tulip_swin96_pair_fwd(const tulip_swin96_desc* d0, const tulip_swin96_desc* d1, void* sync, size_t sync_bytes,
+                                     hipStream_t stream) {
+    Swin96Pair P;
+    const int f0 = swin96_fwd_args(d0, P.a0), f1 = swin96_fwd_args(d1, P.a1);
+    if (f0 < 0 || f1 < 0 || f0 != f1 || !sync) return TULIP_ERR_ARG;
+    if (d0->B != d1->B || d0->H != d1->H || d0->W != d1->W || d0->x_out != d1->x_in) return TULIP_ERR_ARG;
+    if (sync_bytes < (size_t)tulip_swin96_pair_sync_bytes(d0->B, d0->H, d0->W) || ((uintptr_t)sync & 15)) return TULIP_ERR_ARG;
+    if (f0 != 0 && f0 != 3) return TULIP_ERR_NOT_BUILT;      // the two forms the engine launches: inference, training with gelu'(h)
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return TULIP_ERR_LAUNCH;
+    }
+    P.sync = (unsigned*)sync;
+    P.ntiles = d0->B * (d0->H / 2) * (d0->W / (8 * NW));
+    if (P.ntiles > cus) return TULIP_ERR_ARG;                  // one workgroup per CU (LDS) and every one of them resident: a polling
+    const dim3 g(P.ntiles), b(NT);                             // workgroup must never hold the CU its producer is waiting for
+    if (f0 == 0) hipLaunchKernelGGL((swin96_pair_fwd_kernel<0>), g, b, 0, stream, P);
+    else hipLaunchKernelGGL((swin96_pair_fwd_kernel<3>), g, b, 0, stream, P);
+    TULIP_CHECK_LAUNCH();
+    return TULIP_OK;
+}
 extern "C" int tulip_swin96_block_fwd_profiled(const tulip_swin96_desc* d, uint64_t* stamps, hipStream_t stream) {
     return swin96_fwd_impl(d, (unsigned long long*)stamps, stream);
 }

@@ -812,8 +812,20 @@ class TulipEngine:
         """out_bf16: bf16 copy of the stage output, written by the last block's fc2 epilogue."""
         x = xin
         ln1_done = False
+        paired = False
         for k, sp in enumerate(specs):
             nxt = specs[k + 1] if k + 1 < len(specs) else None
+            if paired:                             # ran in the previous block's launch
+                paired = False
+                x = P[sp.prefix + ".out"]
+                continue
+            if nxt is not None and self._pair96_ok(P, sp, nxt):
+                self._pair96_fwd(P, sp, nxt, x)
+                if out_bf16 is not None and k + 2 == len(specs):
+                    ops.cast_f32_bf16(P[nxt.prefix + ".out"], out_bf16, P.B * nxt.H * nxt.W, nxt.C)
+                paired, ln1_done = True, False
+                x = P[sp.prefix + ".out"]
+                continue
             chain = (nxt is not None and self._unfused(sp, P.B) and self._unfused(nxt, P.B) and nxt.C == sp.C
                      and nxt.H == sp.H and nxt.W == sp.W)
             self._block_fwd(P, sp, x, P[sp.prefix + ".out"], out_bf16 if k == len(specs) - 1 else None, ln1_done=ln1_done,
@@ -822,6 +834,41 @@ class TulipEngine:
             ln1_done = chain
             x = P[sp.prefix + ".out"]
         return x
+
+    def _pair96_ok(self, P: Plan, sp: BlockSpec, nxt: BlockSpec) -> bool:
+        """Two consecutive C = 96 blocks as ONE launch (tulip_swin96_pair_fwd): the un-shifted block and the shifted block behind
+        it, where the stage is one round of the chip (every workgroup resident: <= 256 tiles of 8 windows)."""
+        if not (self.pair96 and self.fuse_block96 and self._fusable96(sp) and self._fusable96(nxt)):
+            return False
+        if self._recomp96(sp) or self._recomp96(nxt) or (nxt.H, nxt.W) != (sp.H, sp.W):
+            return False
+        if not self._no_save and not (self._hgrad96(sp) and self._hgrad96(nxt)):     # the training form built: gelu'(h) in fc1_pre
+            return False
+        return P.B * (sp.H // 2) * (sp.W // 64) <= self.pair96_max_tiles
+
+    def _desc96(self, P: Plan, sp: BlockSpec, xin, xout) -> dict:
+        W_, p = self.params, sp.prefix
+        sv = (lambda k: None) if self._no_save else (lambda k: P[p + k])
+        return dict(
+            x_in=xin, x1=sv(".x1"), x_out=xout, xn1=sv(".xn1"), qkv=sv(".qkv"), attn_out=sv(".o"),
+            xn2=sv(".xn2"), fc1_pre=sv(".h"), fc1_act=sv(".g"), mean1=sv(".mean1"),
+            rstd1=sv(".rstd1"), mean2=sv(".mean2"), rstd2=sv(".rstd2"),
+            w_qkv=W_.p16(p + ".attn.qkv.weight"), w_proj=W_.p16(p + ".attn.proj.weight"),
+            w_fc1=W_.p16(p + ".mlp.fc1.weight"), w_fc2=W_.p16(p + ".mlp.fc2.weight"),
+            b_qkv=W_.p32(p + ".attn.qkv.bias"), b_proj=W_.p32(p + ".attn.proj.bias"),
+            b_fc1=W_.p32(p + ".mlp.fc1.bias"), b_fc2=W_.p32(p + ".mlp.fc2.bias"),
+            norm1_weight=W_.p32(p + ".norm1.weight"), norm1_bias=W_.p32(p + ".norm1.bias"),
+            norm2_weight=W_.p32(p + ".norm2.weight"), norm2_bias=W_.p32(p + ".norm2.bias"),
+            bias_table=W_.p32(p + ".attn.relative_position_bias_table"), rel_index=self._rel32,
+            drop_scale_attn=self._ds(P, sp, 0), drop_scale_mlp=self._ds(P, sp, 1), B=P.B, H=sp.H, W=sp.W,
+            shift_h=sp.sft[0], shift_w=sp.sft[1], masked=self._mask_arg(sp, P.B), eps=self.eps)
+
+    def _pair96_fwd(self, P: Plan, sp: BlockSpec, nxt: BlockSpec, xin):
+        nb = ops.swin96_pair_sync_bytes(P.B, sp.H, sp.W)
+        P.scratch("xchg.pair." + sp.prefix, (nb + 3) // 4)      # zero at birth, epoch-stamped from then on (Plan.reset_exchange)
+        mid = P[sp.prefix + ".out"]
+        ops.swin96_pair_fwd(self._desc96(P, sp, xin, mid), self._desc96(P, nxt, mid, P[nxt.prefix + ".out"]),
+                            P.bufs["xchg.pair." + sp.prefix])
 
     def _unmerge_fwd(self, P: Plan, prefix: str, s: int):
         """PatchUnmerging (tulip.py:117-123) of the level-s stream (its bf16 copy lvl{s}.xb, written by the producing
@@ -845,6 +892,10 @@ class TulipEngine:
 
     # round 6: the stage boundaries as one launch each (csrc/glue.hip).  TULIP_FUSE_GLUE=0: the LayerNorm / GEMM launches
     fuse_glue = knobs.on("TULIP_FUSE_GLUE", True)
+    # two consecutive C = 96 blocks in one launch with tile-to-tile hand-off (csrc/swin96.hip, swin96_pair_fwd_kernel): review item 3's
+    # prototype, forward only; kept or dropped on the measurement in profiles/README.md
+    pair96 = knobs.on("TULIP_PAIR96", False)
+    pair96_max_tiles = 256
 
     # Where the one-launch forms win (tools/bench_glue.py, profiles/r6_bench_glue_*.txt): every workgroup streams the boundary's whole
     # weight set through its CU, so with many row blocks the GEMM launches' tiles (weights shared by a whole tile column) take over.
@@ -1860,7 +1911,7 @@ class TulipEngine:
         # what the captured launch sequence depends on besides the caller's key: the fuse switches, the DropPath seed (a launch
         # argument) and the number of draw slots
         key = key + (self.fuse_wide, self.fuse_wide_bwd, self.fuse_block96, self.fuse_block96_bwd, self.split_wide, self.split_wide_bwd,
-                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd, self.fuse_glue,
+                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd, self.fuse_glue, self.pair96,
                      int(self._drop_seed), int(self.n_drop_slots))
         ent = graphs.get(key)
         if not self.graph_module or ent is None:

@@ -394,6 +394,29 @@ def swin96_block_fwd(stamps=None, **kw):
     check(_lib.load().tulip_swin96_block_fwd(ctypes.byref(d), _stream()), "tulip_swin96_block_fwd")
 
 
+def _swin96_desc(kw):
+    d = _lib.Swin96Desc()
+    kw = dict(kw)
+    for name, _t in _lib.Swin96Desc._fields_:
+        v = kw.pop(name, None)
+        setattr(d, name, _p(v) if name not in ("B", "H", "W", "shift_h", "shift_w", "masked", "eps") else v)
+    if kw:
+        raise TypeError(f"unknown fields {sorted(kw)}")
+    return d
+
+
+def swin96_pair_sync_bytes(B, H, W) -> int:
+    return int(_lib.load().tulip_swin96_pair_sync_bytes(B, H, W))
+
+
+def swin96_pair_fwd(first: dict, second: dict, sync):
+    """tulip_swin96_pair_fwd: two consecutive C = 96 blocks in one launch; first / second hold the fields of tulip_swin96_desc,
+    sync is the zero-initialised uint8 / int32 device tensor of swin96_pair_sync_bytes that these launches own."""
+    d0, d1 = _swin96_desc(first), _swin96_desc(second)
+    check(_lib.load().tulip_swin96_pair_fwd(ctypes.byref(d0), ctypes.byref(d1), _p(sync), sync.numel() * sync.element_size(),
+                                            _stream()), "tulip_swin96_pair_fwd")
+
+
 def swinw_supported(C, H, W) -> bool:
     return bool(_lib.load().tulip_swinw_supported(C, H, W))
 
