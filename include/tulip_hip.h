@@ -474,7 +474,8 @@ int tulip_swin96_block_fwd_profiled(const tulip_swin96_desc* d, uint64_t* stamps
  * d1->x_in; B (H/2) (W/64) <= the number of CUs (one workgroup per tile, all resident; TULIP_ERR_ARG beyond); both descriptors in the same form (inference, or training with TULIP_BLOCK_FC1_GRAD); same tensors and bits as the
  * two launches.  sync: tulip_swin96_pair_sync_bytes(B, H, W) bytes, 16-byte aligned, ZERO before the first launch and owned by
  * these launches from then on (epoch-stamped flags: nothing to clear between launches or graph replays; words 2 / 3 are a test
- * hook that holds the tiles of one parity back, see csrc/swin96.hip). */
+ * hook that holds the tiles of one parity back, see csrc/swin96.hip; word 4 counts polls that gave up after ~0.5 s -- it stays 0 unless
+ * a producer never ran, and the results of such a launch are undefined). */
 int tulip_swin96_pair_sync_bytes(int B, int H, int W);
 int tulip_swin96_pair_fwd(const tulip_swin96_desc* d0, const tulip_swin96_desc* d1, void* sync, size_t sync_bytes,
                           hipStream_t stream);

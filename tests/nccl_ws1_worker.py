@@ -63,6 +63,8 @@ def main():
                      ("captured", dict(force_segments=True, bucket_mb=0.05)),
                      ("captured_bucket_adamw", dict(force_segments=True, bucket_mb=0.05, bucket_adamw=True)),
                      ("captured_bf16", dict(force_segments=True, bucket_mb=0.05, grad_dtype="bf16")),
+                     # a backend that cannot capture its collective: the first one raises inside the capture -> the segmented rung
+                     ("captured_fallback", dict(force_segments=True, bucket_mb=0.05)),
                      ("eager_plain", dict(use_graph=False)),
                      ("eager_segments", dict(force_segments=True, bucket_mb=0.05, use_graph=False))]:
         torch.manual_seed(11)
@@ -72,6 +74,14 @@ def main():
         os.environ["TULIP_DETACH_BUCKETS"] = "0" if name == "segments_joined" else "1"
         os.environ["TULIP_GRAPH_COLLECTIVES"] = "1" if name.startswith("captured") else "0"
         tr = Trainer(m, 4, lr=5e-4, betas=(0.9, 0.95), weight_decay=0.01, **kw)
+        if name == "captured_fallback":
+            real = tr.bucketer.on_group_done
+
+            def refusing(tag, gflat, keep=True, _real=real):
+                if tr.graph_collectives and torch.cuda.is_current_stream_capturing() and tag in tr.bucketer.by_tag:
+                    raise RuntimeError("this backend cannot capture its collectives (test)")
+                return _real(tag, gflat, keep=keep)
+            tr.bucketer.on_group_done = refusing
         tr.load_batch(lo.cuda(), hi.cuda())
         losses = [tr.step().clone() for _ in range(steps)]
         tr.gather_state()              # (exchange="sharded": the master whole again; a no-op otherwise)

@@ -86,6 +86,7 @@ def test_pair_launch_is_the_two_launches_bit_for_bit(ops, B, fp8, save):
         torch.cuda.synchronize()
         launches += 1
         assert sync[0].item() == launches and sync[1].item() == 0          # the epoch advanced once, everybody left
+        assert sync[4].item() == 0                                          # no poll gave up
         for r, g in zip(ref, got):
             for k in (NAMES + ["out"]) if save else ["out"]:
                 assert torch.equal(r[k], g[k]), (hold, k)

@@ -43,6 +43,10 @@ def test_forced_segments_over_rccl_match_the_plain_step_bit_for_bit(tmp_path):
     for name in ("captured", "captured_bucket_adamw", "captured_bf16"):
         assert got[name]["form"] == "one_graph_captured_collectives" and got[name]["segments"] == 1 and got[name]["detached"] == 0, got[name]["form"]
     assert got["segments"]["form"] == "segments"
+    # a capture of the collectives that fails half-way leaves capture mode, and the step falls to the segmented rung: same bits
+    fb = got["captured_fallback"]
+    assert fb["form"] == "segments" and fb["segments"] == fb["buckets"] + 1, (fb["form"], fb["segments"])
+    assert torch.equal(fb["losses"], plain["losses"]) and torch.equal(fb["flat"], plain["flat"])
     for name in ("segments", "segments_joined", "segments_bucket_adamw", "segments_sharded", "eager_segments", "captured",
                  "captured_bucket_adamw"):
         g = got[name]

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NT) void swin96_fwd_kernel(const Swin96Args a) {
 // its second-block tile reads, and goes on.  First-block tiles never wait, so the launch cannot deadlock whatever is resident.
 // sync: [0] epoch (a flag is "set" when it holds epoch + 1; the last workgroup to leave advances it: no clearing between graph
 // replays), [1] workgroups that left, [2] / [3] dev: tiles of parity [2] - 1 idle [3] sleep quanta before their first block
-// (forces the arrival order in the tests), [16 + 4 tile] flags.
+// (forces the arrival order in the tests), [4] polls that gave up (stays 0), [16 + 4 tile] flags.
 #ifndef TULIP_PAIR_HAND
 #define TULIP_PAIR_HAND 3              // dev (tools/bench_pair96.py): 0 = plain loads / stores, with TULIP_PAIR_NOSYNC=1 the bare cost of the form
 #endif
@@ -463,8 +463,10 @@ __global__ __launch_bounds__(NT) void swin96_pair_fwd_kernel(const Swin96Pair P)
         if (tid < 4) {
             const unsigned* f = sync + 16 + 4 * pair_source_tile(a1->H, a1->W, a1->sh - P.a0.sh, a1->sw - P.a0.sw, tile, tid);
             // (bounded: ~0.5 s of polling, then on with whatever is there -- a wrong result a test can see instead of a hung queue)
-            for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want; ++spin)
+            unsigned spin = 0;
+            for (; spin < (1u << 24) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want; ++spin)
                 __builtin_amdgcn_s_sleep(1);
+            if (spin == (1u << 24)) __hip_atomic_fetch_add(sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // gave up: the host can see it
         }
         __syncthreads();
     }

@@ -69,6 +69,16 @@ class GradBucketer:
             self.pending.append(work)
         return work, a, b
 
+    def prime(self, gflat: torch.Tensor) -> None:
+        """Every bucket's all-reduce once, eagerly, on the buffer and at the sizes the step will use, and waited for: the
+        communicator and whatever the backend sets up on the first use of an algorithm / message size exist before the step is
+        captured into a graph (a first collective INSIDE a capture would have to allocate and connect there).  The caller restores
+        the buffer's contents."""
+        if not self.active or self.dry:
+            return
+        for _tag, a, b in self.buckets:
+            dist.all_reduce(gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True).wait()
+
     def wait_all(self) -> None:
         for w in self.pending:
             w.wait()          # stream-level dependency for NCCL/RCCL; blocking for gloo

@@ -456,6 +456,28 @@ class Trainer:
                                       "exp_avg_sq": self.v[sl].view(W.shape[n]).clone()}
 
     # ------------------------------------------------------------------ graph capture
+    def _abort_capture(self, g, origin):
+        """Leave capture mode after an exception inside a capture (the caller captures again in another form).  HIP keeps EVERY
+        stream of a capture in capture mode when hipStreamEndCapture finds forked work that was never joined (CUDA ends the
+        capture there), so: back on the stream the capture began on -- the engine may have been on its side stream when the
+        exception passed through --, join every stream the capture forked into, then end it.  The graph is dropped."""
+        torch.cuda.set_stream(origin)
+        for st in (getattr(self.eng, "_side_stream", None), self._opt_stream, self._det_stream):
+            if st is None or st == origin:
+                continue
+            with torch.cuda.stream(st):
+                forked = torch.cuda.is_current_stream_capturing()
+            if forked:
+                origin.wait_stream(st)
+        try:
+            self.bucketer.wait_all()         # (collectives captured before the failure: their stream joins through work.wait())
+        except Exception:                    # noqa: BLE001
+            self.bucketer.pending.clear()
+        try:
+            g.capture_end()
+        except Exception as e:               # noqa: BLE001
+            sys.stderr.write(f"tulip_amd.Trainer: ending the failed capture: {type(e).__name__}: {str(e)[:200]}\n")
+
     def _capture_one_graph(self):
         """The N > 1 optimizer step as ONE graph: collectives captured as branches off the side queue (graph_collectives)."""
         side = self._side
@@ -464,8 +486,12 @@ class Trainer:
             g = torch.cuda.CUDAGraph()
             g.capture_begin(capture_error_mode="thread_local")
             self.eng.detach_buckets = False
-            self._fwd_bwd(lambda tag: self._bucket_done(tag, cast=True), True, bucket_on_side=True)
-            self._finish_buckets()           # joins the collectives (and the per-bucket optimizer) / the end-of-step AdamW
+            try:
+                self._fwd_bwd(lambda tag: self._bucket_done(tag, cast=True), True, bucket_on_side=True)
+                self._finish_buckets()       # joins the collectives (and the per-bucket optimizer) / the end-of-step AdamW
+            except BaseException:
+                self._abort_capture(g, side)
+                raise
             g.capture_end()
         torch.cuda.current_stream().wait_stream(side)
         return [(g, None)]
@@ -522,6 +548,9 @@ class Trainer:
             self.eng.detach_buckets = bool(update and self.segmented and self.detach_buckets)
             try:
                 self._fwd_bwd(hook, update, apply_adamw=update and self._adam_mask is not None)
+            except BaseException:
+                self._abort_capture(cur, side)      # (the caller sees the exception; the streams are out of capture mode)
+                raise
             finally:
                 self.eng.detach_buckets = False
             if not update:
@@ -613,6 +642,8 @@ class Trainer:
             if self.fuse_adamw:
                 self._plan_fused_adamw(self.eng.adam_probe)
                 self.eng.adam_probe = None
+            if self.exchange == "allreduce":     # the collectives once outside capture too (g is restored below, gb is scratch)
+                self.bucketer.prime(self.g if self.gb is None else self.gb)
             scratch = torch.zeros(64, dtype=torch.float32, device=self.device)
             ops.adamw(scratch, scratch.clone(), scratch.clone(), scratch.clone(), None, 64, self.hyper, None)
             ops.grad_norm(scratch, 64, self._norm_part, self.grad_norm)
