@@ -74,6 +74,12 @@ typedef struct ihipStream_t* hipStream_t;
  * TULIP_GEMM_NO_MID is accepted and means the default (never, unless asked). */
 #define TULIP_GEMM_NO_MID 0x400
 #define TULIP_GEMM_MID 0x800
+/* TULIP_GEMM_B_PACKED: B is the FRAGMENT-MAJOR copy (tulip_pack_bf16_multi) of the [N][K] matrix -- for a data gradient, of the
+ * transposed weight -- and the launch is the small-K form (csrc/gemm.hip, gemm_stream_kernel): 32 x 96 output tiles, the whole K
+ * range of a split in flight at once.  a_trans = b_trans = 0, ldb ignored; tulip_gemm_packed_supported(M, N, K, splits) says where
+ * it exists (M % 32 == 0, N % 96 == 0, K per split in {96, 384, 768}), TULIP_ERR_ARG elsewhere.  Same epilogues, same bits as the
+ * plain call on the row-major matrix. */
+#define TULIP_GEMM_B_PACKED 0x1000
 int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,
                     int epi, const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                     const float* rowscale, int rows_per_sample, int accumulate, int psH, int psW, int splits,
@@ -151,6 +157,7 @@ int tulip_wgrad_group_profiled(const tulip_wgrad_item* items, int n, void* works
 
 /* number of K-splits tulip_gemm_bf16 actually launches for (K, splits): K is cut in multiples of 32 */
 int tulip_gemm_effective_splits(int K, int splits);
+int tulip_gemm_packed_supported(int M, int N, int K, int splits);
 
 /* REDUCTIONS.  No kernel in this library funnels many workgroups into same-address atomics (on gfx950 a
  * chain of same-address device-scope fp32 atomics costs ~0.1-0.5 us per link).  Every cross-workgroup sum

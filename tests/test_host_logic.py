@@ -197,8 +197,12 @@ def test_weight_copies_of_the_fused_stage_boundaries_and_the_pack_mark():
     W = eng.params
     glue = sorted(n for n, w in W.pk_width.items() if w == 0)
     assert glue == sorted([f"layers.{s}.downsample.reduction.weight" for s in range(3)] + [f"skip_connection_layers.{i}.weight" for i in range(3)]
-                          + ["layers_up.0.upsample.expand.weight", "layers_up.1.upsample.expand.weight"])
-    assert "first_patch_expanding.expand.weight" not in W.pk_width          # C = 768: the GEMM launches stay, no copy
+                          + ["layers_up.0.upsample.expand.weight", "layers_up.1.upsample.expand.weight",
+                             "first_patch_expanding.expand.weight"])        # (C = 768: no fused form, but its GEMM launches read the copies)
+    # the small-K GEMM form reads boundary copies only (pseudo-width 0), at a row-tile offset for a sub-block of the transpose
+    assert eng._pk("first_patch_expanding.expand.weight") == W.p16p("first_patch_expanding.expand.weight")
+    assert eng._pk("layers.1.blocks.0.attn.qkv.weight") is None
+    assert eng._pk("skip_connection_layers.2.weight", transposed=True, row0=96, K=96) == W.p16t("skip_connection_layers.2.weight") + 2 * 6 * 3 * 512
     assert W.pk_active == {0, 192, 384} and 768 in {w for w in W.pk_width.values()}
     names = lambda part: {n for (w, q), ent in W._pk_entries.items() if q == part for n, _ in ent}
     assert "layers.0.downsample.reduction.weight" in names(0) and "skip_connection_layers.0.weight" in names(1)
@@ -214,4 +218,5 @@ def test_weight_copies_of_the_fused_stage_boundaries_and_the_pack_mark():
     gl = {n for n, w in el.params.pk_width.items() if w == 0}
     assert "layers.3.downsample.reduction.weight" not in gl and "layers.2.downsample.reduction.weight" in gl
     assert "skip_connection_layers.0.weight" not in gl and "skip_connection_layers.1.weight" in gl        # [768][1536] / [384][768]
-    assert {"layers_up.1.upsample.expand.weight", "layers_up.2.upsample.expand.weight"} <= gl and "layers_up.0.upsample.expand.weight" not in gl
+    assert {"layers_up.0.upsample.expand.weight", "layers_up.1.upsample.expand.weight", "layers_up.2.upsample.expand.weight"} <= gl
+    assert "first_patch_expanding.expand.weight" not in gl                   # C = 1536

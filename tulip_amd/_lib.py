@@ -83,6 +83,7 @@ class SkipUnmergeBwdDesc(ctypes.Structure):    # tulip_skip_unmerge_bwd_desc
 
 REDUCE_REGIONS_MAX, WGRAD_GROUP_MAX, PACK_MAX = 48, 16, 64
 GEMM_NO_TOUCH, GEMM_CHECKED, GEMM_NO_MID, GEMM_MID, WGRAD_SMALL_TILES, BLOCK_NO_WARM = 0x100, 0x200, 0x400, 0x800, 0x100, 8     # per-call flag bits (tulip_hip.h)
+GEMM_B_PACKED = 0x1000
 ABI_VERSION = 6      # TULIP_ABI_VERSION of include/tulip_hip.h: the ctypes structs above mirror that layout
 
 # name -> argtypes (must mirror include/tulip_hip.h; tests/test_cabi.py cross-checks against the header)
@@ -133,6 +134,7 @@ SIGNATURES = {
     "tulip_wgrad_group_adamw": [P, I, P, I, P, L, I, P, P],
     "tulip_wgrad_group_profiled": [P, I, P, L, I, P, P],
     "tulip_gemm_effective_splits": [I, I],
+    "tulip_gemm_packed_supported": [I, I, I, I],
     "tulip_cast_flat": [P, P, L, P],
     "tulip_cast_bf16_f32": [P, P, L, P],
     "tulip_tail_fwd": [P, P, P, P, P, I, I, I, I, P],

@@ -272,6 +272,79 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, float
     }
 }
 
+// The staged fp32 tile (ROWS x 96 at row pitch STG_PITCH, first row = global row mrow0) -> memory through the epilogues: contiguous
+// 8-column chunks with consecutive lanes along the row (16-B bf16 / 32-B fp32 per lane) instead of 8-B pieces scattered over 16 rows
+// per instruction -- the MFMA-layout stores were the bottleneck of every output-heavy GEMM here.
+constexpr int STG_PITCH = BN * 4 + 16;                 // fp32 staging row pitch (bank-spread)
+template <int ROWS>
+__device__ __forceinline__ void write_out_staged(const GemmArgs& p, const unsigned char* smem, const int mrow0, const int n0, const int bz,
+                                                 const int tid) {
+    if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_PIXSHUF2_F32 && (p.N & 31) == 0 && p.vec_ok) {                        // (uniform)
+        // PixelShuffle(2) write-out, vectorised: an item is (row, sub-position q = 2i + j, 8 output channels) -- its eight values
+        // sit 16 B apart in the staged row (columns 4c + q) and leave as ONE 16-byte bf16 store (+ two fp32 ones) into the fine
+        // token (2h + i, 2w + j); epilogue8's form of it is eight scattered 2-byte stores per thread
+#pragma unroll
+        for (int it = 0; it < (ROWS * (BN / 8) + 255) / 256; ++it) {
+            const int c = tid + it * 256;
+            const int rl = c / (BN / 8), c8 = c - rl * (BN / 8);
+            const int q = c8 & 3, cg = c8 >> 2;
+            const int m = mrow0 + rl, nb = n0 + cg * 32;
+            if (rl < ROWS && m < p.M && nb < p.N) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *(const float*)(smem + rl * STG_PITCH + (cg * 32 + 4 * k + q) * 4);
+                if (p.bias) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += p.bias[nb + 4 * k + q];
+                }
+                const int t = fast_div(m, p.psW), w = m - t * p.psW;
+                const int b = fast_div(t, p.psH), h = t - b * p.psH;
+                const size_t tok = ((size_t)b * 2 * p.psH + 2 * h + (q >> 1)) * (2 * p.psW) + 2 * w + (q & 1);
+                const int cb = nb >> 2;
+                if (p.out) {
+                    float* o = (float*)p.out + tok * (p.N >> 2) + cb;
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (p.out2) *(uint4*)((bf16_t*)p.out2 + tok * p.ldo2 + cb) = pack8(v);
+            }
+        }
+    } else if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_UNSHUF2_BF16 && !p.bias && (p.M & 1) == 0 && p.vec_ok) {     // (uniform)
+        // inverse shuffle: fine tokens 2w, 2w + 1 of one row (staged rows rl, rl + 1) are neighbours in the coarse token's
+        // channel quadruple -- an item is (row pair, 8 columns): eight 4-byte stores instead of sixteen 2-byte ones
+#pragma unroll
+        for (int it = 0; it < (ROWS / 2 * (BN / 8) + 255) / 256; ++it) {
+            const int c = tid + it * 256;
+            const int rp = c / (BN / 8), c8 = c - rp * (BN / 8);
+            const int rl = 2 * rp, m = mrow0 + rl, n = n0 + c8 * 8;
+            if (rp < ROWS / 2 && m < p.M && n < p.N) {
+                const float4 a0 = *(const float4*)(smem + rl * STG_PITCH + c8 * 32), a1 = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
+                const float4 b0 = *(const float4*)(smem + (rl + 1) * STG_PITCH + c8 * 32), b1 = *(const float4*)(smem + (rl + 1) * STG_PITCH + c8 * 32 + 16);
+                const int W2 = 2 * p.psW, H2 = 2 * p.psH;
+                const int t = fast_div(m, W2), wf = m - t * W2;
+                const int b = fast_div(t, H2), hf = t - b * H2;
+                bf16_t* o = (bf16_t*)p.out + (((size_t)b * p.psH + (hf >> 1)) * p.psW + (wf >> 1)) * p.ldo + 2 * (hf & 1);
+                const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) *(uint32_t*)(o + 4 * (n + r)) = pack_bf16x2(va[r], vb[r]);
+            }
+        }
+    } else {
+#pragma unroll
+    for (int it = 0; it < (ROWS * (BN / 8) + 255) / 256; ++it) {
+        const int c = tid + it * 256;
+        const int rl = c / (BN / 8), c8 = c - rl * (BN / 8);
+        const int m = mrow0 + rl, n = n0 + c8 * 8;
+        if (rl < ROWS && m < p.M && n < p.N) {
+            const float4 lo = *(const float4*)(smem + rl * STG_PITCH + c8 * 32);
+            const float4 hi = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
+            epilogue8(p, m, n, lo, hi, bz);
+        }
+    }
+    }
+}
+
 // one output tile (bx, by) of K range bz: the body of both the plain and the grouped launch
 template <int BM, bool A_T, bool B_T, int KSUB, bool FULL = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const int by, const int bz) {
@@ -281,7 +354,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
     using SB = Stage<BN, B_T, KSUB, FULL>;
     constexpr int A_BYTES = KSUB * SA::SUB_BYTES, B_BYTES = KSUB * SB::SUB_BYTES;
     constexpr int BKS = BK * KSUB;  // k depth of one pipeline stage
-    constexpr int STG_PITCH = BN * 4 + 16;                 // fp32 staging row pitch (bank-spread)
     constexpr int STG_BYTES = 64 * STG_PITCH;              // 64 output rows per write-out pass
     constexpr int PIPE_BYTES = 2 * (A_BYTES + B_BYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem[PIPE_BYTES > STG_BYTES ? PIPE_BYTES : STG_BYTES];
@@ -421,70 +493,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int bx, const
             }
         }
         __syncthreads();
-        if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_PIXSHUF2_F32 && (p.N & 31) == 0 && p.vec_ok) {                        // (uniform)
-            // PixelShuffle(2) write-out, vectorised: an item is (row, sub-position q = 2i + j, 8 output channels) -- its eight values
-            // sit 16 B apart in the staged row (columns 4c + q) and leave as ONE 16-byte bf16 store (+ two fp32 ones) into the fine
-            // token (2h + i, 2w + j); epilogue8's form of it is eight scattered 2-byte stores per thread
-#pragma unroll
-            for (int it = 0; it < (64 * (BN / 8)) / 256; ++it) {
-                const int c = tid + it * 256;
-                const int rl = c / (BN / 8), c8 = c - rl * (BN / 8);
-                const int q = c8 & 3, cg = c8 >> 2;
-                const int m = m0 + ps * 64 + rl, nb = n0 + cg * 32;
-                if (m < p.M && nb < p.N) {
-                    float v[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = *(const float*)(smem + rl * STG_PITCH + (cg * 32 + 4 * k + q) * 4);
-                    if (p.bias) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += p.bias[nb + 4 * k + q];
-                    }
-                    const int t = fast_div(m, p.psW), w = m - t * p.psW;
-                    const int b = fast_div(t, p.psH), h = t - b * p.psH;
-                    const size_t tok = ((size_t)b * 2 * p.psH + 2 * h + (q >> 1)) * (2 * p.psW) + 2 * w + (q & 1);
-                    const int cb = nb >> 2;
-                    if (p.out) {
-                        float* o = (float*)p.out + tok * (p.N >> 2) + cb;
-                        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                    if (p.out2) *(uint4*)((bf16_t*)p.out2 + tok * p.ldo2 + cb) = pack8(v);
-                }
-            }
-        } else if (TULIP_GEMM_FAST_SHUF && p.epi == TULIP_EPI_UNSHUF2_BF16 && !p.bias && (p.M & 1) == 0 && p.vec_ok) {     // (uniform)
-            // inverse shuffle: fine tokens 2w, 2w + 1 of one row (staged rows rl, rl + 1) are neighbours in the coarse token's
-            // channel quadruple -- an item is (row pair, 8 columns): eight 4-byte stores instead of sixteen 2-byte ones
-#pragma unroll
-            for (int it = 0; it < (32 * (BN / 8) + 255) / 256; ++it) {
-                const int c = tid + it * 256;
-                const int rp = c / (BN / 8), c8 = c - rp * (BN / 8);
-                const int rl = 2 * rp, m = m0 + ps * 64 + rl, n = n0 + c8 * 8;
-                if (rp < 32 && m < p.M && n < p.N) {
-                    const float4 a0 = *(const float4*)(smem + rl * STG_PITCH + c8 * 32), a1 = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
-                    const float4 b0 = *(const float4*)(smem + (rl + 1) * STG_PITCH + c8 * 32), b1 = *(const float4*)(smem + (rl + 1) * STG_PITCH + c8 * 32 + 16);
-                    const int W2 = 2 * p.psW, H2 = 2 * p.psH;
-                    const int t = fast_div(m, W2), wf = m - t * W2;
-                    const int b = fast_div(t, H2), hf = t - b * H2;
-                    bf16_t* o = (bf16_t*)p.out + (((size_t)b * p.psH + (hf >> 1)) * p.psW + (wf >> 1)) * p.ldo + 2 * (hf & 1);
-                    const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    const float vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) *(uint32_t*)(o + 4 * (n + r)) = pack_bf16x2(va[r], vb[r]);
-                }
-            }
-        } else {
-#pragma unroll
-        for (int it = 0; it < (64 * (BN / 8)) / 256; ++it) {
-            const int c = tid + it * 256;
-            const int rl = c / (BN / 8), c8 = c - rl * (BN / 8);
-            const int m = m0 + ps * 64 + rl, n = n0 + c8 * 8;
-            if (m < p.M && n < p.N) {
-                const float4 lo = *(const float4*)(smem + rl * STG_PITCH + c8 * 32);
-                const float4 hi = *(const float4*)(smem + rl * STG_PITCH + c8 * 32 + 16);
-                epilogue8(p, m, n, lo, hi, bz);
-            }
-        }
-        }
+        write_out_staged<64>(p, smem, m0 + ps * 64, n0, bz, tid);
         if (ps + 1 < NPASS) __syncthreads();
     }
     if (A_T && do_rowsum && g == 0) {
@@ -514,6 +523,95 @@ __global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_kernel_full(con
 
 // Several independent GEMMs in ONE launch (the weight gradients of a Swin block: each alone fills a fraction of the
 // chip and costs a launch on the side queue).  Workgroups [first[i], first[i+1]) belong to problem i.
+// ---------------------------------------------------------------------------------------------------------------------
+// The small-K form (TULIP_GEMM_B_PACKED): a 32 x 96 output tile whose whole K range (KS 32-deep steps, K <= 768 per split) is in
+// flight at once.  B is the FRAGMENT-MAJOR copy of the [N][K] matrix (tulip_pack_bf16_multi; csrc/swin_stream.h): the operand of
+// one MFMA is one contiguous 1-KiB wave load straight into registers, up to eight steps ahead and issued before anything else (the
+// weights are the cold bytes); the 32 x K panel of A is fetched with every load issued before the first LDS write.  One latency
+// instead of K / 128 dependent stages: the stage-boundary GEMMs of the batch-8 step (512 .. 2 048 rows, K <= 768) were 8-13 us of
+// launch + dependent round trips on 128 workgroups.  Same MFMA order per output element as gemm_tile (k steps in sequence, weights
+// as the first operand): the same bits.
+template <int KS>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(const GemmArgs p) {
+    constexpr int BMS = 32, NTW = 3, PF = KS < 8 ? KS : 8;
+    constexpr int PANEL = KS * BMS * 64, STG = BMS * STG_PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PANEL > STG ? PANEL : STG];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BMS, bz = blockIdx.z, kbeg = bz * p.kchunk;
+    const bf16_t* wt[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+        wt[j] = p.B + ((size_t)((n0 >> 4) + wn * NTW + j) * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 8;
+    // Cold weights: in the step the copies were written at the end of the previous one and come from HBM; a ring of PF steps would walk
+    // them at miss latency (the fused boundary launches of csrc/glue.hip were worth 6 us of the step before their warm-up and 42 with
+    // it).  The workgroup first touches its [96][K range] slice beyond the ring's first PF steps -- each KiB one LDS-destination wave
+    // load whose data is dropped (warm_touch16) --, everything in flight at once; the stream below then hits L2.
+    __shared__ __attribute__((aligned(16))) unsigned char warm_sink[1024];
+    if (p.touch && KS > PF) {
+        constexpr int KR = KS - PF, NB = 2 * NTW * KR;        // (the first PF steps are the ring's own first loads, issued right below)
+#pragma unroll
+        for (int i = 0; i < (NB + 3) / 4; ++i) {
+            const int blk = wid + 4 * i;                       // (tile, k step) pairs of the slice, one KiB each
+            if (NB % 4 == 0 || blk < NB) {
+                const int tile = blk / KR, ks = PF + blk - tile * KR;
+                warm_touch16(p.B + ((size_t)((n0 >> 4) + tile) * (p.K >> 5) + (kbeg >> 5) + ks) * 512 + lane * 8, warm_sink);
+            }
+        }
+    }
+    bf16x8 ring[PF][NTW];
+    static_for<PF>([&](auto Q_) {
+        constexpr int q = decltype(Q_)::value;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) ring[q][j] = *(const bf16x8*)(wt[j] + 512 * q);
+    });
+    // the A panel: [k tile][32 rows][64 B], 16-B chunks XOR-swizzled by row (frag_n's layout)
+    constexpr int CPR = KS * 4, NCH = BMS * CPR, PER = (NCH + 255) / 256;
+    uint4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + i * 256;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (NCH % 256 == 0 || c < NCH) {
+            const int row = c / CPR, kc = c - row * CPR;
+            v[i] = *(const uint4*)(p.A + (size_t)(m0 + row) * p.lda + kbeg + kc * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + i * 256;
+        if (NCH % 256 == 0 || c < NCH) {
+            const int row = c / CPR, kc = c - row * CPR;
+            *(uint4*)(smem + (kc >> 2) * (BMS * 64) + row * 64 + (((kc & 3) ^ swz4(row)) << 4)) = v[i];
+        }
+    }
+    __syncthreads();
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&](auto K_) {
+        constexpr int ks = decltype(K_)::value;
+        bf16x8 a[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) a[j] = ring[ks % PF][j];
+        if constexpr (ks + PF < KS) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) ring[ks % PF][j] = *(const bf16x8*)(wt[j] + 512 * (ks + PF));
+        }
+        const bf16x8 x = frag_n(smem + ks * (BMS * 64), wm * 16 + li, g);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], x, acc[j], 0, 0, 0);
+    });
+    __syncthreads();                                   // the panel is dead: its LDS becomes the staged output tile
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) *(f32x4*)(smem + (wm * 16 + li) * STG_PITCH + (wn * 48 + j * 16 + g * 4) * 4) = acc[j];
+    __syncthreads();
+    write_out_staged<BMS>(p, smem, m0, n0, bz, tid);
+}
+static bool stream_shape_ok(int M, int N, int K, int kchunk) {
+    return M % 32 == 0 && N % BN == 0 && K % kchunk == 0 && (kchunk == 96 || kchunk == 384 || kchunk == 768);
+}
+
 constexpr int GROUP_MAX = TULIP_WGRAD_GROUP_MAX;
 struct GemmGroup {
     GemmArgs g[GROUP_MAX];
@@ -1151,6 +1249,12 @@ static int effective_splits(int K, int splits) {
 }
 
 extern "C" int tulip_gemm_effective_splits(int K, int splits) { return K > 0 ? effective_splits(K, splits) : 1; }
+extern "C" int tulip_gemm_packed_supported(int M, int N, int K, int splits) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 31)) return 0;
+    if (splits < 1) splits = 1;
+    const int kchunk = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
+    return stream_shape_ok(M, N, K, kchunk) ? 1 : 0;
+}
 
 extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N,
                                int K, int epi, const float* bias, void* out, int ldo, void* out2, int ldo2,
@@ -1189,6 +1293,15 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
         q.epi = TULIP_EPI_SPLIT_F32; q.bias = nullptr; q.out = workspace; q.ldo = N; q.out2 = nullptr;
     }
     int rc;
+    if (accumulate & TULIP_GEMM_B_PACKED) {           // B: the fragment-major copy of the [N][K] matrix (gemm_stream_kernel)
+        if (a_trans || b_trans || !stream_shape_ok(M, N, K, kchunk)) return TULIP_ERR_ARG;
+        const dim3 grid(N / BN, M / 32, splits);
+        if (kchunk == 768) hipLaunchKernelGGL((gemm_stream_kernel<24>), grid, dim3(256), 0, stream, q);
+        else if (kchunk == 384) hipLaunchKernelGGL((gemm_stream_kernel<12>), grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((gemm_stream_kernel<3>), grid, dim3(256), 0, stream, q);
+        hipError_t e__ = hipGetLastError();
+        rc = e__ != hipSuccess ? -(1000 + (int)e__) : TULIP_OK;
+    } else
     if (!a_trans && !b_trans) rc = launch<false, false>(q, splits, stream);
     else if (!a_trans && b_trans) rc = launch<false, true>(q, splits, stream);
     else if (a_trans && b_trans) rc = launch<true, true>(q, splits, stream);

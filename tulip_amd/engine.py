@@ -483,7 +483,7 @@ class TulipEngine:
                     return c // 4 in (96, 192, 384)
                 if n.startswith("skip_connection_layers."):     # [Cs][2 Cs]: merge_bwd (Cs = 192, 384), unmerge (Cs = 96, 192)
                     return r in (96, 192, 384)
-                return c in (192, 384)                  # expand [2C][C]
+                return c in (192, 384, 768)             # expand [2C][C]: the fused unmerge (C = 192, 384), the small-K GEMM form (C <= 768)
             by_width[0] = [n for n in glue if n in self.params.offset and ok(n)]
         self.params.make_packed(by_width, with_transposes=self.fuse_wide_bwd or self.fuse_deep or bool(by_width.get(0)))
         # the wide widths (a few MB of copies) keep their fragment-major copies fresh from the start; the DEEP widths (57 MB read +
@@ -887,8 +887,11 @@ class TulipEngine:
                                 P[f"lvl{s}.emean"], P[f"lvl{s}.erstd"], B, H, W, 2, C // 2, self.eps,
                                 out_bf16=P[f"dec{s - 1}.cat"], ld=C)
             return
+        pk = self._pk(prefix + ".expand.weight")
+        if pk is not None:
+            self._join_pack(part=1)
         self._gemm(P[f"lvl{s}.xb"], W_.p16(prefix + ".expand.weight"), M, 2 * C, C, lda=C, ldb=C, epi=EPI_PIXSHUF2_F32,
-                 bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W)
+                 bias=W_.p32(prefix + ".expand.bias"), out=None, out2=P[f"dec{s - 1}.cat"], ldo2=C, psH=H, psW=W, packed=pk)
 
     # round 6: the stage boundaries as one launch each (csrc/glue.hip).  TULIP_FUSE_GLUE=0: the LayerNorm / GEMM launches
     fuse_glue = knobs.on("TULIP_FUSE_GLUE", True)
@@ -1010,8 +1013,11 @@ class TulipEngine:
             else:
                 self._unmerge_fwd(P, up, s + 1)
                 # dec{s}.cat = cat[unmerged stream, x_save[s]] (tulip.py:715) was filled by its two producers
+                pk = self._pk(pre + ".weight")
+                if pk is not None:
+                    self._join_pack(part=1)
                 self._gemm(P[f"dec{s}.cat"], W_.p16(pre + ".weight"), Ms, Cs, 2 * Cs, lda=2 * Cs, ldb=2 * Cs, epi=EPI_F32,
-                           bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"])
+                           bias=W_.p32(pre + ".bias"), out=P[f"dec{s}.in"], packed=pk)
             x = self._stage_fwd(P, self.dec_blocks[i], P[f"dec{s}.in"],
                                 out_bf16=P[f"lvl{s}.xb"] if i < nl - 2 else None)
         M0 = B * H0 * W0
@@ -1098,17 +1104,39 @@ class TulipEngine:
                 return s
             s = e
 
-    def _gemm(self, A, B, M, N, K, **kw):
+    # round 6: the stage-boundary GEMMs that no fused launch owns read the fragment-major weight copy in the small-K form
+    # (TULIP_GEMM_B_PACKED, csrc/gemm.hip gemm_stream_kernel: 32 x 96 tiles, the whole K range of a split in flight) while the launch
+    # is at most this many tiles -- 54 -> 41 us for the six of the batch-8 step in isolation (profiles/r6_bench_gemm_packed.txt)
+    packed_gemm = True
+    packed_gemm_max_tiles = 1024
+
+    def _pk(self, name: str, transposed: bool = False, row0: int = 0, K: int = 0) -> Optional[int]:
+        """Address of the fragment-major copy of weight `name` (transposed: of its transpose), from matrix row `row0` on (a multiple
+        of 16; K = the copy's row length), or None where no fresh copy exists."""
+        W_ = self.params
+        if not (self.packed_gemm and self.fuse_glue and 0 in getattr(W_, "pk_active", ()) and W_.pk_width.get(name) == 0):
+            return None
+        return (W_.p16t(name) if transposed else W_.p16p(name)) + 2 * (row0 // 16) * (K // 32) * 512
+
+    def _gemm(self, A, B, M, N, K, packed: Optional[int] = None, **kw):
         """Forward / dgrad GEMM.  Launches that cannot fill the chip and have a deep K (the M=512..2048 GEMMs
         of stages 2-3 stream megabytes of weights through a few dozen workgroups) are split along K; the
-        library folds the partial slabs and applies the fused epilogue in a second kernel."""
+        library folds the partial slabs and applies the fused epilogue in a second kernel.
+        packed: address of the fragment-major copy of the [N][K] operand (_pk) -- taken where the small-K form exists."""
         gn = (N + 95) // 96
         blocks = ((M + 63) // 64) * gn if ((M + 127) // 128) * gn < 256 else ((M + 127) // 128) * gn
+        s = 1
         if blocks <= 96 and K >= 768:
             s = max(1, min(256 // blocks, K // 256, (self.WS_ELEMS * 4) // (M * N * 4)))
-            if s > 1:
-                ops.gemm(A, B, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, **kw)
+        if packed is not None and not kw.get("a_trans"):
+            sp = ops.gemm_effective_splits(K, s)
+            if ops.gemm_packed_supported(M, N, K, sp) and (M // 32) * (N // 96) * sp <= self.packed_gemm_max_tiles:
+                kw2 = dict(kw, b_trans=False, ldb=K)
+                ops.gemm(A, packed, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, b_packed=True, **kw2)
                 return
+        if s > 1:
+            ops.gemm(A, B, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, **kw)
+            return
         # round 5: the narrow-output / deep-K shapes of the mid-size stages (fc2 forward, the fc1 / qkv data gradients: N = C,
         # K = 3C .. 4C at M >= 4096 -- the deep stage at batch 64, stage 3 of tulip_large at 32 x 2048) run 330-410 TFLOP/s on
         # gemm_tile's tiles; the 192 x 192 loader-wave kernel (csrc/gemm.hip, gemm_mid_tile) with the K split that fills the chip
@@ -1609,7 +1637,8 @@ class TulipEngine:
             self._release_deferred()
             return
         self._gemm(dz, W_.p16(prefix + ".expand.weight"), M, C, 2 * C, lda=2 * C, ldb=C, b_trans=True, epi=EPI_F32,
-                 out=dx_out, ldo=C, out2=cb, ldo2=C if cb is not None else 0, rowscale=cs, rows_per_sample=ct)
+                 out=dx_out, ldo=C, out2=cb, ldo2=C if cb is not None else 0, rowscale=cs, rows_per_sample=ct,
+                 packed=self._pk(prefix + ".expand.weight", transposed=True))
         self._release_deferred()
 
     # Gradients are WRITTEN, not accumulated (run_backward(overwrite=True), the Trainer with accum_iter == 1): every parameter has
@@ -1791,7 +1820,8 @@ class TulipEngine:
                     cast_rows_per_sample=ct, B=B, H=H0 >> (s + 1), W=W0 >> (s + 1), C=2 * Cs)
             elif m.patch_unmerging:
                 self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True,
-                           epi=EPI_UNSHUF2_BF16, out=P[f"lvl{s + 1}.dz2"], ldo=4 * Cs, psH=H0 >> (s + 1), psW=W0 >> (s + 1))
+                           epi=EPI_UNSHUF2_BF16, out=P[f"lvl{s + 1}.dz2"], ldo=4 * Cs, psH=H0 >> (s + 1), psW=W0 >> (s + 1),
+                           packed=self._pk(pre + ".weight", transposed=True))          # rows 0 .. Cs-1 of W^T: the unmerged half
             else:       # PatchExpanding: fine-token order; its LayerNorm backward does the un-rearrange (_unmerge_bwd)
                 self._gemm(dys, W_.p16(pre + ".weight"), Ms, Cs, Cs, lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_BF16,
                            out=P[f"lvl{s + 1}.dfine"], ldo=Cs)
@@ -1838,7 +1868,8 @@ class TulipEngine:
                 # (for 0 < s the sum is also what the PatchMerging backward below consumes: bf16 copy from the epilogue)
                 self._gemm(P[f"dec{s}.dyskip"], W_.p16(f"skip_connection_layers.{i}.weight") + 2 * Cs, Ms, Cs, Cs,
                          lda=Cs, ldb=2 * Cs, b_trans=True, epi=EPI_F32, out=dx, ldo=Cs, accumulate=True,
-                         out2=P[f"enc{s}.dyb"] if s > 0 else None, ldo2=Cs if s > 0 else 0)
+                         out2=P[f"enc{s}.dyb"] if s > 0 else None, ldo2=Cs if s > 0 else 0,
+                         packed=self._pk(f"skip_connection_layers.{i}.weight", transposed=True, row0=Cs, K=Cs))    # rows Cs .. of W^T
             if s > 0:
                 # PatchMerging backward of level s-1
                 Cp = E << (s - 1)
@@ -1849,7 +1880,7 @@ class TulipEngine:
                 self._wgrad(dyb, 2 * Cp, P[f"enc{s - 1}.xm"], 4 * Cp, 2 * Cp, 4 * Cp, rows,
                             G(pre + ".reduction.weight"))
                 self._gemm(dyb, W_.p16(pre + ".reduction.weight"), rows, 4 * Cp, 2 * Cp, lda=2 * Cp, ldb=4 * Cp,
-                         b_trans=True, epi=EPI_BF16, out=dxm, ldo=4 * Cp)
+                         b_trans=True, epi=EPI_BF16, out=dxm, ldo=4 * Cp, packed=self._pk(pre + ".reduction.weight", transposed=True))
                 xprev = P[self.enc_blocks[s - 1][-1].prefix + ".out"]
                 self._ln_bwd(P, dxm, xprev, P[f"enc{s - 1}.mmean"], P[f"enc{s - 1}.mrstd"], W_.p32(pre + ".norm.weight"),
                              None, P[f"enc{s - 1}.dx"], rows, 4 * Cp, G(pre + ".norm.weight"), G(pre + ".norm.bias"),
@@ -1911,7 +1942,7 @@ class TulipEngine:
         # what the captured launch sequence depends on besides the caller's key: the fuse switches, the DropPath seed (a launch
         # argument) and the number of draw slots
         key = key + (self.fuse_wide, self.fuse_wide_bwd, self.fuse_block96, self.fuse_block96_bwd, self.split_wide, self.split_wide_bwd,
-                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd, self.fuse_glue, self.pair96,
+                     self.fc1_grad_wide, self.fc1_grad96, self.recompute96, self.fuse_deep, self.fuse_tail_fwd, self.fuse_tail_bwd, self.fuse_glue, self.pair96, self.packed_gemm,
                      int(self._drop_seed), int(self.n_drop_slots))
         ent = graphs.get(key)
         if not self.graph_module or ent is None:

@@ -34,13 +34,14 @@ def _chk(t: torch.Tensor, dtype, name: str):
 
 def gemm(A, B, M, N, K, *, lda, ldb, a_trans=False, b_trans=False, epi=EPI_BF16, bias=None, out=None, ldo=None,
          out2=None, ldo2=0, aux=None, ldaux=0, rowscale=None, rows_per_sample=1, accumulate=False, psH=0, psW=0,
-         splits=1, workspace=None, workspace_bytes=0, touch=True, checked=False, mid=None):
+         splits=1, workspace=None, workspace_bytes=0, touch=True, checked=False, mid=None, b_packed=False):
     """C[M,N] = opA . opB^T with a fused epilogue (see include/tulip_hip.h).  A/B/out may be views
     with an element offset (row strides passed as lda/ldb/ldo).  touch=False / checked=True: TULIP_GEMM_NO_TOUCH /
     TULIP_GEMM_CHECKED (measurement and bit-compare switches, per call)."""
     lib = _lib.load()
     accumulate = int(bool(accumulate)) | (0 if touch else _lib.GEMM_NO_TOUCH) | (_lib.GEMM_CHECKED if checked else 0)
     accumulate |= 0 if mid is None else (_lib.GEMM_MID if mid else _lib.GEMM_NO_MID)     # the 192 x 192 mid-size kernel: forced / never
+    accumulate |= _lib.GEMM_B_PACKED if b_packed else 0      # B = the fragment-major copy of the [N][K] matrix: the small-K form
     rc = lib.tulip_gemm_bf16(_p(A), lda, int(a_trans), _p(B), ldb, int(b_trans), M, N, K, epi, _p(bias), _p(out),
                              ldo if ldo is not None else N, _p(out2), ldo2, _p(aux), ldaux, _p(rowscale),
                              rows_per_sample, int(accumulate), psH, psW, splits, _p(workspace), workspace_bytes,
@@ -215,6 +216,10 @@ def cast_f32_bf16(x, y, rows, cols, rowscale=None, rows_per_sample=1):
 
 def reduce_splits(slabs, out, n, splits):
     check(_lib.load().tulip_reduce_splits(_p(slabs), _p(out), n, splits, _stream()), "tulip_reduce_splits")
+
+
+def gemm_packed_supported(M, N, K, splits=1) -> bool:
+    return bool(_lib.load().tulip_gemm_packed_supported(M, N, K, splits))
 
 
 def gemm_effective_splits(K, splits):
