@@ -77,7 +77,7 @@ typedef struct ihipStream_t* hipStream_t;
 /* TULIP_GEMM_B_PACKED: B is the FRAGMENT-MAJOR copy (tulip_pack_bf16_multi) of the [N][K] matrix -- for a data gradient, of the
  * transposed weight -- and the launch is the small-K form (csrc/gemm.hip, gemm_stream_kernel): 32 x 96 output tiles, the whole K
  * range of a split in flight at once.  a_trans = b_trans = 0, ldb ignored; tulip_gemm_packed_supported(M, N, K, splits) says where
- * it exists (M % 32 == 0, N % 96 == 0, K per split in {96, 384, 768}), TULIP_ERR_ARG elsewhere.  Same epilogues, same bits as the
+ * it exists (M % 32 == 0, N % 96 == 0, K per split in {96, 384, 768, 1536}), TULIP_ERR_ARG elsewhere.  Same epilogues, same bits as the
  * plain call on the row-major matrix. */
 #define TULIP_GEMM_B_PACKED 0x1000
 int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* B, int ldb, int b_trans, int M, int N, int K,

@@ -28,6 +28,7 @@ CASES = [
     (2048, 384, 768, False, "f32_bias_out2", 1),
     (2048, 384, 384, True, "unshuf", 1),
     (512, 768, 1536, True, "f32", 4),
+    (512, 768, 1536, True, "f32_bias_out2", 1),         # the same unsplit: the whole K = 1536 in one workgroup
     (512, 1536, 768, True, "bf16", 1),
     (32768, 96, 96, True, "f32_acc", 1),
     (64, 96, 768, False, "resid", 1),
@@ -97,7 +98,7 @@ def test_packed_form_matches_the_plain_gemm_bit_for_bit(ops, M, N, K, bt, epi, s
 
 def test_packed_form_refuses_shapes_it_does_not_have(ops):
     assert not ops.gemm_packed_supported(48, 96, 768) and not ops.gemm_packed_supported(64, 64, 768)
-    assert not ops.gemm_packed_supported(64, 96, 1536) and ops.gemm_packed_supported(64, 96, 1536, 2)
+    assert ops.gemm_packed_supported(64, 96, 1536) and ops.gemm_packed_supported(64, 96, 1536, 2) and not ops.gemm_packed_supported(64, 96, 3072)
     assert not ops.gemm_packed_supported(64, 96, 256)
     A = torch.zeros(64, 256, dtype=torch.bfloat16, device=DEV)
     W = torch.zeros(96 * 256, dtype=torch.bfloat16, device=DEV)

@@ -40,6 +40,11 @@ for M, N, K, bt, splits in [(512, 1536, 768, 0, 1), (2048, 384, 768, 0, 1), (204
                                 workspace=ws, workspace_bytes=ws.numel() * 4))
     t1 = timed(lambda: ops.gemm(A, Wp, M, N, K, lda=K, ldb=K, epi=ops.EPI_F32, out=o, splits=splits, workspace=ws,
                                 workspace_bytes=ws.numel() * 4, b_packed=True))
+    extra = ""
+    if splits > 1 and ops.gemm_packed_supported(M, N, K, 1):
+        t2 = timed(lambda: ops.gemm(A, Wp, M, N, K, lda=K, ldb=K, epi=ops.EPI_F32, out=o, b_packed=True))
+        extra = f"   packed, unsplit {t2:6.2f}"
+        t1 = t2
+    print(f"{M:6d} {N:5d} {K:5d} {bt:2d} {splits:3d} {t0:10.2f} {t1:10.2f}{extra}", flush=True)
     tot[0] += t0; tot[1] += t1
-    print(f"{M:6d} {N:5d} {K:5d} {bt:2d} {splits:3d} {t0:10.2f} {t1:10.2f}", flush=True)
 print(f"six launches: plain {tot[0]:.1f} us, packed {tot[1]:.1f} us")

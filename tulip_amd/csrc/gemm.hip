@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, (KSUB == 1 ? 2 : 1)) void gemm_kernel_full(con
 // Several independent GEMMs in ONE launch (the weight gradients of a Swin block: each alone fills a fraction of the
 // chip and costs a launch on the side queue).  Workgroups [first[i], first[i+1]) belong to problem i.
 // ---------------------------------------------------------------------------------------------------------------------
-// The small-K form (TULIP_GEMM_B_PACKED): a 32 x 96 output tile whose whole K range (KS 32-deep steps, K <= 768 per split) is in
+// The small-K form (TULIP_GEMM_B_PACKED): a 32 x 96 output tile whose whole K range (KS 32-deep steps, K <= 1536 per split) is in
 // flight at once.  B is the FRAGMENT-MAJOR copy of the [N][K] matrix (tulip_pack_bf16_multi; csrc/swin_stream.h): the operand of
 // one MFMA is one contiguous 1-KiB wave load straight into registers, up to eight steps ahead and issued before anything else (the
 // weights are the cold bytes); the 32 x K panel of A is fetched with every load issued before the first LDS write.  One latency
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const GemmArgs p) {
     write_out_staged<BMS>(p, smem, m0, n0, bz, tid);
 }
 static bool stream_shape_ok(int M, int N, int K, int kchunk) {
-    return M % 32 == 0 && N % BN == 0 && K % kchunk == 0 && (kchunk == 96 || kchunk == 384 || kchunk == 768);
+    return M % 32 == 0 && N % BN == 0 && K % kchunk == 0 && (kchunk == 96 || kchunk == 384 || kchunk == 768 || kchunk == 1536);
 }
 
 constexpr int GROUP_MAX = TULIP_WGRAD_GROUP_MAX;
@@ -1296,7 +1296,8 @@ extern "C" int tulip_gemm_bf16(const void* A, int lda, int a_trans, const void* 
     if (accumulate & TULIP_GEMM_B_PACKED) {           // B: the fragment-major copy of the [N][K] matrix (gemm_stream_kernel)
         if (a_trans || b_trans || !stream_shape_ok(M, N, K, kchunk)) return TULIP_ERR_ARG;
         const dim3 grid(N / BN, M / 32, splits);
-        if (kchunk == 768) hipLaunchKernelGGL((gemm_stream_kernel<24>), grid, dim3(256), 0, stream, q);
+        if (kchunk == 1536) hipLaunchKernelGGL((gemm_stream_kernel<48>), grid, dim3(256), 0, stream, q);
+        else if (kchunk == 768) hipLaunchKernelGGL((gemm_stream_kernel<24>), grid, dim3(256), 0, stream, q);
         else if (kchunk == 384) hipLaunchKernelGGL((gemm_stream_kernel<12>), grid, dim3(256), 0, stream, q);
         else hipLaunchKernelGGL((gemm_stream_kernel<3>), grid, dim3(256), 0, stream, q);
         hipError_t e__ = hipGetLastError();

@@ -1129,10 +1129,12 @@ class TulipEngine:
         if blocks <= 96 and K >= 768:
             s = max(1, min(256 // blocks, K // 256, (self.WS_ELEMS * 4) // (M * N * 4)))
         if packed is not None and not kw.get("a_trans"):
-            sp = ops.gemm_effective_splits(K, s)
+            # unsplit where the form holds the whole K (<= 1536: a 96-KB panel): the fold launch and its slabs go, 128 workgroups with
+            # everything in flight take what 512 + a fold took (the deepest expand conv's data gradient: 12.9 -> 8.6 us isolated)
+            sp = 1 if ops.gemm_packed_supported(M, N, K, 1) else ops.gemm_effective_splits(K, s)
             if ops.gemm_packed_supported(M, N, K, sp) and (M // 32) * (N // 96) * sp <= self.packed_gemm_max_tiles:
                 kw2 = dict(kw, b_trans=False, ldb=K)
-                ops.gemm(A, packed, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, b_packed=True, **kw2)
+                ops.gemm(A, packed, M, N, K, splits=sp, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, b_packed=True, **kw2)
                 return
         if s > 1:
             ops.gemm(A, B, M, N, K, splits=s, workspace=self._ws_ptr, workspace_bytes=self.WS_ELEMS * 4, **kw)
