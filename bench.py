@@ -93,7 +93,7 @@ def kernel_source_stamp():
 
 FAMILIES = {   # kernel-name prefixes per family: shared with tools/instep_summary.py, pmc_summary.py, mfma_summary.py
     "wgrad": ("wgrad_group_kernel", "gemm_group_kernel"),
-    "gemm": ("gemm_kernel",),
+    "gemm": ("gemm_kernel", "gemm_stream_kernel"),
     "swin96_fwd": ("swin96_fwd_kernel",), "swin96_bwd": ("swin96_bwd_kernel",),
     "swinw_fwd": ("swinw_fwd_kernel",), "swinw_bwd": ("swinw_bwd_kernel",),
     "fold": ("reduce_rows_multi_kernel",), "adamw": ("adamw_kernel",),
@@ -162,7 +162,12 @@ def kernel_rooflines(trainer, reps=5):
     def gemm(A, B, M, N, K, **kw):
         f = 2.0 * M * N * K
         by = 2.0 * (M * K + N * K) + M * N * (4.0 if kw.get("epi", 0) in (3, 4, 5, 6, 7) else 2.0)
-        name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
+        if kw.get("b_packed"):        # the small-K form on the fragment-major copy (csrc/gemm.hip gemm_stream_kernel<K per split / 32>)
+            from tulip_amd import ops as _o
+            eff = _o.gemm_effective_splits(K, kw.get("splits", 1))
+            name = f"gemm_stream_kernel<{-(-K // eff) // 32}>"
+        else:
+            name = _gemm_instance(M, N, K, kw.get("a_trans", False), kw.get("b_trans", False), kw.get("splits", 1))
         rec.append(("gemm", name, lambda: real["gemm"](A, B, M, N, K, **kw), f, by, by))
         real["gemm"](A, B, M, N, K, **kw)
 
@@ -251,7 +256,7 @@ def kernel_rooflines(trainer, reps=5):
     kernels = {
         "wgrad": "wgrad_group_kernel (every weight + bias gradient of a stage in one grouped launch; gemm_group_kernel for "
                  "shapes without a large tile)",
-        "gemm": "gemm_kernel<BM,A_T,B_T,KSUB> (every linear / 1x1 conv forward and data gradient outside the fused blocks)",
+        "gemm": "gemm_kernel<BM,A_T,B_T,KSUB> / gemm_stream_kernel<KS> (every linear / 1x1 conv forward and data gradient outside the fused blocks; the small-K form on the fragment-major weight copies for the stage boundaries)",
         "swin96_fwd": "swin96_fwd_kernel (whole C=96 Swin block, forward)", "swin96_bwd": "swin96_bwd_kernel",
         "swinw_fwd": "swinw_fwd_kernel<C,G> (whole C=192/384 Swin block, forward)", "swinw_bwd": "swinw_bwd_kernel<C,G>",
         "adamw": "adamw_kernel (fp32 master + moments + bf16 shadow, 30 B / parameter; only the tensors whose step was not taken in "

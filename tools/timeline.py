@@ -1,4 +1,4 @@
-"""dev tool: per-stream timeline of the LAST training step in a rocprofv3 rocpd db (kernel-trace):
+"""dev tool: per-stream timeline of one of the last training steps (the median one by wall time) in a rocprofv3 rocpd db (kernel-trace):
 wall, busy union, per-stream busy, overlap, and the main stream's longest kernels / idle gaps."""
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
@@ -9,8 +9,16 @@ sc = os.environ.get("TL_COL", "queue_id")
 rows = cur.execute(f"select name, start, end, {sc} from kernels order by start").fetchall()
 # a step ends with adamw_kernel: take the kernels between the last two adamw launches
 ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
-lo, hi = ad[-2] + 1, ad[-1] + 1
+# ... of the last five steps the one with the median wall time (the very last one of a trace is sometimes stretched by the tracer's flush)
+cands = []
+for k in range(2, min(7, len(ad) + 1)):
+    st = rows[ad[-k] + 1: ad[-k + 1] + 1]
+    cands.append((max(r[2] for r in st) - st[0][1], k))
+cands.sort()
+kk = cands[len(cands) // 2][1]
+lo, hi = ad[-kk] + 1, ad[-kk + 1] + 1
 step = rows[lo:hi]
+print(f"(step -{kk - 1} of the trace: the median wall of the last {len(cands)})")
 t0, t1 = step[0][1], max(r[2] for r in step)
 print(f"step: {len(step)} kernels, wall {(t1 - t0) / 1e3:.1f} us (stream column: {sc})")
 def union(iv):
